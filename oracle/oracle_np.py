@@ -193,8 +193,8 @@ def smooth_window(data, window_length):
         right = data[end_tail - d_right - 1:n]
         nr = numer[T - d_left:T + 1 + d_right]
         shape = (-1,) + (1,) * (data.ndim - 1)
-        out[tail_end - 1] = np.asarray((left.astype(LD) * nr.reshape(shape)).sum(axis=0), dtype=np.float64) / den
-        out[end_tail - 1] = np.asarray((right.astype(LD) * nr[::-1].reshape(shape)).sum(axis=0), dtype=np.float64) / den
+        out[tail_end - 1] = np.asarray((left * nr.reshape(shape)).astype(LD).sum(axis=0), dtype=np.float64) / den
+        out[end_tail - 1] = np.asarray((right * nr[::-1].reshape(shape)).astype(LD).sum(axis=0), dtype=np.float64) / den
     return out
 
 

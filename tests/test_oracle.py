@@ -1,0 +1,303 @@
+"""CPU tests: the two oracles (NumPy + plain C) against the reference's own
+golden data and literal test vectors, and against each other.
+
+Reference goldens used:
+  * data/infercnv_object_example.rda (count.data -> expr.data of a real run)
+  * tests/testthat/test_infer_cnv.R literal matrices (cited per test)
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_c as oc
+import oracle_np as onp
+
+
+@pytest.fixture(scope="module")
+def example(golden_dir):
+    d = np.load(os.path.join(golden_dir, "infercnv_object_example.npz"))
+    return {k: d[k] for k in d.files}
+
+
+@pytest.fixture(scope="module")
+def example_log(example):
+    return onp.log2xplus1(onp.normalize_counts_by_seq_depth(example["count_data"]))
+
+
+# ---------------------------------------------------------------- golden run
+def test_numpy_chain_reproduces_reference_object(example, example_log):
+    """Steps 3,4,8,9,10,11,12,14,22 replayed from @count.data must give the
+    @expr.data stored in the reference's example object."""
+    out = onp.run_chain(example_log, example["chr_codes"], [example["ref_normal"]], 101, 3.0, 1.5, True)
+    assert np.abs(out - example["expr_data"]).max() < 1e-12
+
+
+def test_c_chain_reproduces_reference_object(example, example_log):
+    cs = oc.chr_starts_from_codes(example["chr_codes"])
+    out, pre, (mu, s) = oc.smooth_chain(example_log, cs, [example["ref_normal"]], 101, 3.0, True, 1.5,
+                                        want_pre_denoise=True)
+    assert np.abs(out - example["expr_data"]).max() < 1e-12
+    # mu = 1.012490474117089, s = 0.24026284554325056 on this fixture
+    assert abs(mu - 1.012490474117089) < 1e-12 and abs(s - 0.24026284554325056) < 1e-12
+    assert (out == mu).mean() > 0.8
+
+
+def test_direct_pyramid_formula_equals_reference_order(example, example_log):
+    x = onp.apply_max_threshold_bounds(onp.subtract_ref_expr_from_obs(example_log, [example["ref_normal"]]), 3.0)
+    a = onp.smooth_by_chromosome(x, example["chr_codes"], 101)
+    b = onp.smooth_direct(x, example["chr_codes"], 101)
+    assert np.abs(a - b).max() < 1e-13
+
+
+# ------------------------------------------- testthat literal goldens (R file)
+def _fake(matrix_rows_are_cells, ref_lists):
+    """make_fake_infercnv_obj (tests/testthat/test_infer_cnv.R:36-66): input is
+    t(matrix) i.e. genes x cells after transpose; refs 1-based."""
+    return np.asarray(matrix_rows_are_cells, dtype=np.float64), [np.asarray(r) - 1 for r in ref_lists]
+
+
+matrix_one = np.arange(1, 6, dtype=float).reshape(5, 1)
+matrix_two = np.arange(1, 11, dtype=float).reshape(2, 5).T
+matrix_three = np.arange(1, 16, dtype=float).reshape(3, 5).T
+matrix_five = np.arange(1, 26, dtype=float).reshape(5, 5).T
+matrix_zeros = np.zeros((5, 1))
+
+averef_five = np.array([[-101, -100, -100, -100, -99], [-101, -100, -99, -98, -99], [1, 1, 2, 3, 0],
+                        [110, 103, 90, 80, 70], [0, 0, 0, 0, 0], [100, 102, 100, 102, 102],
+                        [0, -1, -4, -1, -1], [105, 95, 80, 97, 80], [100, 99, 100, 101, 100],
+                        [0, 0, 0, 0, 0]], dtype=float).reshape(5, 10)  # t(matrix(..., ncol=5)): 5 genes x 10 cells
+averef_five_answer = np.array([[-1, 0, 0, 0, 0, -1, 0, 0, 1, 0], [0, 0, 0, 0, -1, 40, 33, 20, 10, 0],
+                               [0] * 10, [0, 0, -3, 0, 0, 25, 15, 0, 17, 0],
+                               [1, 0, 1, 2, 1, 0, 0, 0, 0, 0]], dtype=float)
+
+SUBTRACT_CASES = [  # tests/testthat/test_infer_cnv.R:117-151
+    (matrix_one.T, [[1]], np.arange(0, 5, dtype=float).reshape(5, 1).T),
+    (matrix_two.T, [[1]], np.tile(np.arange(0, 5, dtype=float), (2, 1))),
+    (matrix_three.T, [[1, 3]], np.tile(np.arange(-1, 4, dtype=float), (3, 1))),
+    (matrix_five.T, [[2, 5]], np.tile(np.arange(-3, 2) + 0.5, (5, 1)).T.reshape(5, 5, order="F").T),
+    (matrix_zeros.T, [[1]], matrix_zeros.T),
+]
+
+
+@pytest.mark.parametrize("impl", ["np", "c"])
+def test_subtract_ref_literal_goldens(impl):
+    f = onp.subtract_ref_expr_from_obs if impl == "np" else oc.subtract_ref_expr_from_obs
+    # cases 1-5: expr = t(matrix_k) is (genes=1.., cells) -- the R test passes
+    # t(matrix) so genes are ROWS of t(matrix): shape (ncol, 5)
+    for mat_t, refs, ans in SUBTRACT_CASES:
+        expr, ref_groups = _fake(mat_t, refs)
+        got = f(expr, ref_groups, use_bounds=True)
+        if ans.shape != got.shape:
+            ans = ans.reshape(got.shape)
+        if mat_t is matrix_five.T:
+            # avref_answer_4 = matrix(rep(-3:1 + .5, 5), ncol=5); expected t(answer):
+            ans = np.tile((np.arange(-3, 2) + 0.5)[None, :], (5, 1))
+        np.testing.assert_allclose(got, ans, rtol=0, atol=1e-12)
+    # case 6: 3 ref groups with bounds (:146-151)
+    expr, ref_groups = _fake(averef_five, [[2], [4, 6, 8], [10]])
+    got = f(expr, ref_groups, use_bounds=True)
+    np.testing.assert_allclose(got, averef_five_answer, rtol=0, atol=1e-12)
+
+
+def test_center_columns_mean_literal():
+    # tests/testthat/test_infer_cnv.R:156-172
+    m = np.arange(1, 22, dtype=float).reshape(3, 7).T
+    ans = np.tile(np.array([-3, -2, -1, 0, 1, 2, 3.0])[:, None], (1, 3))
+    np.testing.assert_allclose(onp.center_columns(m, "mean"), ans, atol=1e-12)
+    np.testing.assert_allclose(oc.center_columns(m, "mean"), ans, atol=1e-12)
+    np.testing.assert_allclose(onp.center_columns(m, "median"), ans, atol=1e-12)
+    np.testing.assert_allclose(oc.center_columns(m, "median"), ans, atol=1e-12)
+
+
+def test_clear_noise_literal():
+    # tests/testthat/test_infer_cnv.R:222-262 (.clear_noise, center_pos = 0)
+    cases = [(matrix_one, 0, matrix_one), (matrix_one, 4, np.array([0, 0, 0, 4, 5.0]).reshape(5, 1)),
+             (matrix_one, 6, matrix_zeros), (matrix_three, 0, matrix_three),
+             (matrix_three, 12, np.array([0] * 11 + [12, 13, 14, 15], dtype=float).reshape(3, 5).T),
+             (matrix_three, 100, np.zeros((5, 3)))]
+    for m, thr, ans in cases:
+        np.testing.assert_array_equal(onp.clear_noise_bounds(m, 0.0, thr), ans)
+        np.testing.assert_array_equal(oc.denoise_apply(m, 0.0, thr), ans)
+
+
+SMOOTH_IN = np.array([1, 2, 4, 7, 9, 11, 12, 14, 17, 19, 16, 14, 13, 11, 10, 7, 6, 4, 3, 1], dtype=float)
+SMOOTH_ANS_2_20 = np.array([2.88, 4.44, 6.67, 8.78, 10.67, 12.44, 14.44, 16.11, 16.78, 16, 14.44, 12.78,
+                            11.11, 9.44, 7.56, 5.89, 4.22, 3.13, 2.17])
+
+
+@pytest.mark.parametrize("impl", ["np", "c"])
+def test_smooth_window_literal(impl):
+    """tests/testthat/test_infer_cnv.R:316-360.  The reference's assertions are
+    vacuous (isTRUE(all.equal()) without expect_*), its golden drops element 1
+    and is rounded to 2 dp; elements 2..20 agree to 0.006."""
+    def sm(v, w):
+        v = np.asarray(v, dtype=float).reshape(-1, 1)
+        if impl == "np":
+            return onp.smooth_window(v, w)[:, 0]
+        return oc.smooth_by_chromosome(v, np.array([0, v.shape[0]], dtype=np.int32), w)[:, 0]
+    np.testing.assert_array_equal(sm(matrix_one[:, 0], 0), matrix_one[:, 0])     # window 0 -> unchanged
+    np.testing.assert_array_equal(sm(matrix_one[:, 0], 1), matrix_one[:, 0])     # window 1 -> unchanged
+    got = sm(SMOOTH_IN, 5)
+    assert abs(got[0] - 11.0 / 6.0) < 1e-12                                      # 1.83, missing in the golden
+    assert np.abs(got[1:] - SMOOTH_ANS_2_20).max() < 0.006
+    # window longer than the data (current code, not the stale smooth_answer_5)
+    got = sm(matrix_one[:, 0], 101)
+    w = lambda i: np.array([51 - abs(j - i) for j in range(5)], dtype=float)
+    exp = np.array([(w(i) * matrix_one[:, 0]).sum() / w(i).sum() for i in range(5)])
+    np.testing.assert_allclose(got, exp, rtol=1e-14)
+
+
+def test_average_bounds_literal():
+    # tests/testthat/test_infer_cnv.R:413-433 (out_method="average_bound")
+    m = np.stack([np.arange(1, 16), np.array([-5, -4] + list(range(3, 14)) + [21, 26]),
+                  np.arange(1, 16), np.arange(1, 16)], axis=1).astype(float)
+    for f in (onp.get_average_bounds, oc.get_average_bounds):
+        lo, hi = f(m)
+        assert lo == -0.5 and hi == 17.75
+
+
+# ------------------------------------------------------- oracle cross-checks
+def test_c_vs_numpy_each_step(example, example_log):
+    cs = oc.chr_starts_from_codes(example["chr_codes"])
+    ref = [example["ref_normal"]]
+    a = onp.subtract_ref_expr_from_obs(example_log, ref)
+    b = oc.subtract_ref_expr_from_obs(example_log, ref)
+    np.testing.assert_array_equal(a, b)
+    a, b = onp.apply_max_threshold_bounds(a, 0.5), oc.apply_max_threshold_bounds(b, 0.5)
+    np.testing.assert_array_equal(a, b)
+    a, b = onp.smooth_by_chromosome(a, example["chr_codes"], 101), oc.smooth_by_chromosome(b, cs, 101)
+    np.testing.assert_array_equal(a, b)          # same evaluation order -> bit-identical
+    a, b = onp.center_columns(a), oc.center_columns(b)
+    np.testing.assert_array_equal(a, b)
+    for w in (3, 5, 11, 51, 201, 9999):          # windows shorter/longer than chromosomes
+        np.testing.assert_allclose(onp.smooth_by_chromosome(a, example["chr_codes"], w),
+                                   oc.smooth_by_chromosome(b, cs, w), rtol=0, atol=1e-15)
+
+
+def test_multi_ref_groups_and_no_bounds():
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(57, 23))
+    groups = [np.array([0, 5, 7]), np.array([22, 1]), np.array([3])]
+    for ub in (True, False):
+        np.testing.assert_allclose(onp.subtract_ref_expr_from_obs(x, groups, use_bounds=ub),
+                                   oc.subtract_ref_expr_from_obs(x, groups, use_bounds=ub), rtol=0, atol=1e-15)
+    np.testing.assert_allclose(onp.get_normal_gene_mean_bounds(x, groups, inv_log=True),
+                               oc.ref_group_means(x, groups, inv_log=True), rtol=0, atol=1e-14)
+
+
+def test_log_and_pnorm_restatements_agree_and_are_accurate():
+    from scipy.special import log_ndtr
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([np.exp(rng.uniform(-700, 700, 20000)), rng.uniform(0.2, 1.0, 20000),
+                         1 + rng.uniform(-1e-6, 1e-6, 2000), [1.0, 2.0, 0.5, 5e-324, 2.2250738585072014e-308]])
+    a, b = onp.icnv_log(xs), oc.log(xs)
+    np.testing.assert_array_equal(a, b)                       # bit-identical restatements
+    assert np.max(np.abs(a - np.log(xs)) / np.maximum(np.abs(np.log(xs)), 1e-300)) < 4.5e-16
+    assert np.isneginf(oc.log(np.array([0.0]))[0]) and np.isnan(oc.log(np.array([-1.0]))[0])
+    ys = np.concatenate([np.linspace(0, 40, 40001), rng.uniform(0, 8, 20000), [0.67448975, 5.656854249492380]])
+    p, q = onp.pnorm_log_upper(ys), oc.pnorm_log_upper(ys)
+    np.testing.assert_array_equal(p, q)
+    assert np.max(np.abs(p - log_ndtr(-ys)) / np.abs(log_ndtr(-ys))) < 3e-15
+
+
+I6_MEANS = np.array([0.41234766, 0.84075773, 1.01693983, 1.12238786, 1.23842619, 1.44298781])
+I6_SDS = np.array([0.02889, 0.16455, 0.10555, 0.19057, 0.24409, 0.29007])
+
+
+def _synthetic_hmm_input(rng, G, C, chr_sizes):
+    x = rng.normal(1.0, 0.12, size=(G, C))
+    starts = np.concatenate([[0], np.cumsum(chr_sizes)])
+    for c in range(C):
+        k = rng.integers(0, len(chr_sizes))
+        a = starts[k] + rng.integers(0, max(1, chr_sizes[k] // 2))
+        b = min(starts[k + 1], a + rng.integers(5, 80))
+        x[a:b, c] *= rng.choice([0.5, 1.5, 2.0, 0.05])
+    return x, starts.astype(np.int32)
+
+
+def test_viterbi_c_vs_numpy_bit_exact():
+    rng = np.random.default_rng(11)
+    chr_sizes = [120, 1, 33, 2, 75, 260]
+    G = sum(chr_sizes)
+    x, cs = _synthetic_hmm_input(rng, G, 48, chr_sizes)
+    Pi, delta = onp.get_HMM_i6(1e-6)
+    sd = float(onp.r_median(I6_SDS))
+    chr_codes = np.repeat(np.arange(len(chr_sizes)), chr_sizes)
+    a = onp.predict_cnv_on_indiv_cells(x, chr_codes, I6_MEANS, I6_SDS, Pi, delta)
+    b, bad = oc.viterbi_cells(x, cs, I6_MEANS, sd, np.log(Pi), np.log(delta))
+    assert bad == 0
+    np.testing.assert_array_equal(a.astype(np.uint8), b)
+    assert set(np.unique(b)) - {1, 2, 3, 4, 5, 6} == set()
+    assert len(np.unique(b)) >= 3                      # the inputs do exercise several states
+    assert (b[120] == 3).all()                         # 1-gene chr -> neutral state 3 (R/inferCNV_HMM.R:1104)
+    # literal scalar transcription with the reference's own traceback agrees too
+    for c in range(6):
+        s = onp.viterbi_scalar(x[0:120, c], I6_MEANS, sd, np.log(Pi), np.log(delta))
+        np.testing.assert_array_equal(s.astype(np.uint8), b[0:120, c])
+    # i3 (unnormalised 1-5t diagonal kept)
+    Pi3, d3 = onp.get_HMM_i3(1e-6)
+    m3 = np.array([1.0 - 0.2, 1.0, 1.0 + 0.2])
+    a3 = onp.predict_cnv_on_indiv_cells(x, chr_codes, m3, np.array([0.12] * 3), Pi3, d3)
+    b3, _ = oc.viterbi_cells(x, cs, m3, 0.12, np.log(Pi3), np.log(d3))
+    np.testing.assert_array_equal(a3.astype(np.uint8), b3)
+    assert (b3[120] == 3).all()                        # n<2 returns 3 even under i3
+
+
+def test_viterbi_groups_c_vs_numpy():
+    rng = np.random.default_rng(5)
+    chr_sizes = [90, 40, 1, 64]
+    G = sum(chr_sizes)
+    x, cs = _synthetic_hmm_input(rng, G, 30, chr_sizes)
+    groups = [np.array([3, 1, 2, 0, 9]), np.arange(10, 24), np.array([29, 25])]
+    Pi, delta = onp.get_HMM_i6(1e-6)
+    sds = [I6_SDS * f for f in (0.5, 0.3, 0.8)]
+    chr_codes = np.repeat(np.arange(len(chr_sizes)), chr_sizes)
+    a = onp.predict_cnv_on_groups(x, chr_codes, groups, I6_MEANS, sds, Pi, delta)
+    b, bad = oc.viterbi_groups(x, cs, groups, I6_MEANS, [float(onp.r_median(s)) for s in sds], np.log(Pi),
+                               np.log(delta))
+    assert bad == 0
+    member = np.concatenate(groups)
+    np.testing.assert_array_equal(a[:, member].astype(np.uint8), b[:, member])
+    others = np.setdiff1d(np.arange(30), member)
+    assert (b[:, others] == 255).all() and (a[:, others] == -1).all()
+    np.testing.assert_allclose(onp.group_means(x, groups), oc.group_means(x, groups), rtol=0, atol=1e-15)
+    np.testing.assert_array_equal(onp.assign_HMM_states_to_proxy_expr_vals(b[:, member]),
+                                  oc.states_to_proxy(b[:, member], 6))
+
+
+def test_hmm_states_fixture_sanity(golden_dir, example, example_log):
+    """data/HMM_states.rda came from RNG-derived emission parameters, so it can
+    only be approached (<= 99.1 %).  Guard against gross errors."""
+    hs = np.load(os.path.join(golden_dir, "hmm_states_example.npz"))
+    gold, mu = hs["HMM_states"], hs["mu"]
+    cs = oc.chr_starts_from_codes(example["chr_codes"])
+    _, pre, _ = oc.smooth_chain(example_log, cs, [example["ref_normal"]], want_pre_denoise=True)
+    groups = [example["obs_tumor"], example["ref_normal"]]
+    Pi, delta = onp.get_HMM_i6(1e-6)
+    st, _ = oc.viterbi_groups(pre, cs, groups, mu, [0.24, 0.24], np.log(Pi), np.log(delta))
+    agree = (st == gold.astype(np.uint8)).mean()
+    assert agree > 0.97, agree
+
+
+def test_median_filter_c_vs_numpy():
+    rng = np.random.default_rng(2)
+    chr_sizes = [23, 5, 1, 12]
+    G = sum(chr_sizes)
+    x = rng.normal(size=(G, 21))
+    x[3, :] = 0.0                                         # ties
+    cs = np.concatenate([[0], np.cumsum(chr_sizes)]).astype(np.int32)
+    tiles = [np.array([4, 2, 9, 11, 0, 1, 3, 20, 19, 5, 6]), np.array([7, 8]), np.array([10]),
+             np.arange(12, 19)]
+    chr_codes = np.repeat(np.arange(len(chr_sizes)), chr_sizes)
+    for w in (3, 7):
+        a = onp.apply_median_filtering(x, chr_codes, tiles, w)
+        b = oc.median_filter(x, cs, tiles, w)
+        np.testing.assert_array_equal(a, b)
+
+
+def test_i3_params_c_vs_numpy(example, example_log):
+    mu, sigma, delta = onp.i3_params(example_log, example["ref_normal"], 0.05)
+    mu2, sigma2 = oc.mean_sd_of_cells(example_log, example["ref_normal"])
+    assert abs(mu - mu2) < 1e-14 and abs(sigma - sigma2) < 1e-14
+    assert abs(delta - 1.6448536269514722 * sigma) < 1e-12
