@@ -1,0 +1,206 @@
+/*
+ * icnv.h -- C ABI of libicnv_hip.so: inferCNV's expression-smoothing chain,
+ * i6/i3 HMM Viterbi and 2-D median denoise as hand-written HIP kernels for
+ * AMD MI355X (gfx950).
+ *
+ * The reference (broadinstitute/infercnv, pure R, NeedsCompilation: no) has no
+ * FFI layer; the boundary this library sits behind is the step-function
+ * contract of infercnv::run()  f(infercnv_obj, scalars) -> infercnv_obj  on
+ * infercnv_obj@expr.data (R/inferCNV_ops.R:771,817,865,911,952,1031,
+ * 1255-1304,1469-1471,1573-1588; scripts/inferCNV.R:1116).  Each entry point
+ * below names the reference function(s) it replaces.  INTEGRATION.md shows
+ * the R-side .Call shim and the Python ctypes binding.
+ *
+ * Conventions
+ *   - Matrices are column-major genes x cells, element (g, c) at x[g + G*c]:
+ *     exactly R's layout of expr.data (R/inferCNV.R:18) and at the same time
+ *     the "cell-major" HBM layout (one cell's genes are contiguous).
+ *   - All indices are 0-based int32.  Genes of one chromosome are contiguous
+ *     (.order_reduce, R/inferCNV.R:407): chr_start[] holds n_chr+1 offsets,
+ *     chr_start[0] = 0, chr_start[n_chr] = G.
+ *   - Group lists are "packed": idx[] concatenates the member cell indices of
+ *     all groups, off[] holds n_grp+1 offsets into idx[].
+ *   - Every function returns ICNV_OK (0) or an error code; the message is
+ *     available from icnv_last_error() (thread-local).  The library never
+ *     longjmps/aborts: an R shim turns codes into stop() after cleanup.
+ *   - *_dev entry points take DEVICE pointers for matrices/outputs and enqueue
+ *     all work on `stream` (a hipStream_t passed as void*, NULL = default
+ *     stream) without synchronising the host.  Small descriptor arrays
+ *     (chr_start, group lists, HMM parameters) are HOST pointers in both
+ *     flavours and are copied to the device by the library.
+ *   - The host-buffer flavours upload, run the *_dev path and download.
+ *   - Caller owns every buffer it passes; inputs are never modified.
+ */
+#ifndef ICNV_H
+#define ICNV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICNV_OK 0
+#define ICNV_ERR_ARG 1        /* invalid argument                                   */
+#define ICNV_ERR_HIP 2        /* HIP runtime error (message has the hipError string) */
+#define ICNV_ERR_UNSUPPORTED 3 /* size/config outside what the kernels support        */
+#define ICNV_ERR_UNDERFLOW 4  /* "Problems With Underflow" (R/inferCNV_HMM.R:1165)   */
+#define ICNV_ERR_NOMEM 5
+
+/* Stages of the smoothing chain, named by run()'s step numbers
+ * (R/inferCNV_ops.R:771-1589).  Stages always execute in this order. */
+#define ICNV_ST_SUBTRACT_REF_1 0x01u /* step  8 subtract_ref_expr_from_obs       :1678-1786 */
+#define ICNV_ST_MAX_THRESH     0x02u /* step  9 apply_max_threshold_bounds       :2970-2983 */
+#define ICNV_ST_SMOOTH         0x04u /* step 10 smooth_by_chromosome             :2406-2532 */
+#define ICNV_ST_CENTER         0x08u /* step 11 center_cell_expr_across_chromosome (median) :2074-2109 */
+#define ICNV_ST_SUBTRACT_REF_2 0x10u /* step 12 subtract_ref_expr_from_obs (again)         */
+#define ICNV_ST_INVERT_LOG2    0x20u /* step 14 invert_log2                      :2814-2826 */
+#define ICNV_ST_DENOISE        0x40u /* step 22 clear_noise_via_ref_mean_sd / clear_noise :2232-2346 */
+#define ICNV_ST_ALL            0x7Fu
+#define ICNV_ST_CENTER_MEAN    0x80u /* modifier: step 11 subtracts the mean instead of the median */
+
+/* ---- library state ------------------------------------------------------ */
+int icnv_version(void);
+const char *icnv_last_error(void);
+/* Selects the HIP device for the calling thread's subsequent calls (-1 = keep
+ * current).  Fails with ICNV_ERR_HIP when no gfx950-class GPU is usable. */
+int icnv_init(int device);
+/* Frees cached device workspaces. */
+void icnv_shutdown(void);
+
+/* ---- smoothing chain ---------------------------------------------------- */
+typedef struct icnv_chain_cfg {
+    int64_t G;               /* genes                                              */
+    int64_t C;               /* cells in this (local) matrix                       */
+    const int32_t *chr_start; /* HOST, n_chr+1 offsets                              */
+    int32_t n_chr;
+    int32_t window_length;   /* odd; < 2 = no smoothing (R/inferCNV_ops.R:2444)    */
+    double max_thresh;       /* step 9 threshold; NaN = skip                       */
+    int32_t use_bounds;      /* steps 8/12: 1 = min/max-of-group-means bounds      */
+    double sd_amplifier;     /* step 22 (clear_noise_via_ref_mean_sd)              */
+    double noise_filter;     /* step 22: NaN = sd-based; else clear_noise(threshold) */
+    uint32_t stage_mask;     /* ICNV_ST_* bits                                     */
+    const int32_t *ref_idx;  /* HOST packed LOCAL reference cell indices (or, with */
+    const int32_t *ref_off;  /* no references, one group of all observation cells, */
+    int32_t n_ref_grp;       /* R/inferCNV_ops.R:1686-1688); HOST n_ref_grp+1      */
+} icnv_chain_cfg;
+
+/* One-call form, host buffers.  Replaces the R functions listed at the
+ * ICNV_ST_* bits; with stage_mask = a single bit it is the stand-alone step
+ * (so run(up_to_step=), resume files and the .hspike mirror keep working).
+ * pre_denoise (nullable) receives the matrix before step 22 (the HMM's input,
+ * R/inferCNV_ops.R:1237-1309 reads the step-14..16 object). */
+int icnv_smooth_chain(const double *expr_in, double *expr_out, double *pre_denoise,
+                      const icnv_chain_cfg *cfg);
+/* Same with device-resident matrices; expr_out may alias expr_in. */
+int icnv_smooth_chain_dev(const double *expr_in, double *expr_out, double *pre_denoise,
+                          const icnv_chain_cfg *cfg, void *stream);
+
+/* Split-phase form for cell-sharded multi-GPU runs (one process per GPU).
+ * The chain has one "reference round" per reference-dependent stage present
+ * in stage_mask (steps 8, 12, 22, in that order).  For round r the caller
+ *   1. icnv_chain_round_partial_dev(): enqueues this rank's partial statistic
+ *      over its LOCAL reference cells into a device buffer of *n doubles --
+ *      subtract rounds: [G*n_ref_grp gene sums | n_ref_grp cell counts],
+ *      denoise round:   [sum x, sum_c sd_c, n_ref_cells, n_ref_values];
+ *   2. all-reduces (sum) that buffer across ranks (RCCL; nothing to do on 1 GPU);
+ *   3. icnv_chain_round_finish_dev(): turns the reduced buffer into the
+ *      stage's parameters (bounds / mu,s) on the device.
+ * Then icnv_chain_apply_dev() streams every local cell through the fused pass. */
+typedef struct icnv_chain icnv_chain_t;
+int icnv_chain_begin(icnv_chain_t **chain, const icnv_chain_cfg *cfg);
+int icnv_chain_num_rounds(const icnv_chain_t *chain);
+int icnv_chain_round_partial_dev(icnv_chain_t *chain, int round, const double *expr_in,
+                                 double **partial_dev, int64_t *n, void *stream);
+int icnv_chain_round_finish_dev(icnv_chain_t *chain, int round, void *stream);
+int icnv_chain_apply_dev(icnv_chain_t *chain, const double *expr_in, double *expr_out,
+                         double *pre_denoise, void *stream);
+/* Copies {mu, s} of the denoise stage to the host (synchronises the stream). */
+int icnv_chain_get_denoise(icnv_chain_t *chain, double *mu_s, void *stream);
+void icnv_chain_end(icnv_chain_t *chain);
+
+/* get_average_bounds (R/inferCNV_ops.R:2723-2742): out2 = {mean_c min_g x,
+ * mean_c max_g x}; threshold "auto" of step 9 is mean(abs(out2)). */
+int icnv_average_bounds(const double *expr, int64_t G, int64_t C, double *out2);
+int icnv_average_bounds_dev(const double *expr, int64_t G, int64_t C, double *out2_host, void *stream);
+
+/* ---- HMM ---------------------------------------------------------------- */
+/* Viterbi.dthmm.adj (R/inferCNV_HMM.R:1101-1176) for every (cell, chromosome):
+ * predict_CNV_via_HMM_on_indiv_cells (R/inferCNV_HMM.R:284-324) with K = 6 and
+ * i3HMM_predict_CNV_via_HMM_on_indiv_cells (R/inferCNV_i3HMM.R:180-225) with
+ * K = 3.  Host-prepared parameters, exactly as the reference prepares them in
+ * R: mean[K]; sd_shared = median(pm$sd) (:1122); logPi = log(Pi) K x K
+ * column-major (logPi[j + K*k] = log Pi[j,k]); logDelta = log(delta).
+ * states[g + G*c] in 1..K (uint8); chromosomes with < 2 genes get 3 (:1104).
+ * n_underflow (nullable, HOST) receives the number of sequences for which the
+ * reference would stop("Problems With Underflow"); the host flavour returns
+ * ICNV_ERR_UNDERFLOW when it is non-zero. */
+int icnv_viterbi_cells(const double *expr, uint8_t *states, int64_t G, int64_t C,
+                       const int32_t *chr_start, int32_t n_chr, int32_t K, const double *mean,
+                       double sd_shared, const double *logPi, const double *logDelta);
+int icnv_viterbi_cells_dev(const double *expr, uint8_t *states, int64_t G, int64_t C,
+                           const int32_t *chr_start, int32_t n_chr, int32_t K, const double *mean,
+                           double sd_shared, const double *logPi, const double *logDelta,
+                           int32_t *n_underflow_dev, void *stream);
+
+/* predict_CNV_via_HMM_on_tumor_subclusters / _whole_tumor_samples
+ * (R/inferCNV_HMM.R:345-408, 509-567) and the i3 variants
+ * (R/inferCNV_i3HMM.R:249-389): Viterbi on rowMeans over each group's cells
+ * with that group's shared sd, trace broadcast to all member cells.  Cells in
+ * no group get 0xFF (the reference leaves -1).  For the per-chromosome
+ * grouping of ..._tumor_subclusters_per_chr (:412-487) call once per
+ * chromosome with n_chr = 1 windows. */
+int icnv_viterbi_groups(const double *expr, uint8_t *states, int64_t G, int64_t C,
+                        const int32_t *chr_start, int32_t n_chr, const int32_t *grp_idx,
+                        const int32_t *grp_off, int32_t n_grp, int32_t K, const double *mean,
+                        const double *sd_shared_per_grp, const double *logPi,
+                        const double *logDelta);
+int icnv_viterbi_groups_dev(const double *expr, uint8_t *states, int64_t G, int64_t C,
+                            const int32_t *chr_start, int32_t n_chr, const int32_t *grp_idx,
+                            const int32_t *grp_off, int32_t n_grp, int32_t K, const double *mean,
+                            const double *sd_shared_per_grp, const double *logPi,
+                            const double *logDelta, int32_t *n_underflow_dev, void *stream);
+
+/* rowMeans(expr.data[, group_cells]) per group (R/inferCNV_HMM.R:383):
+ * out[g + G*q], device pointers. */
+int icnv_group_means_dev(const double *expr, int64_t G, int64_t C, const int32_t *grp_idx,
+                         const int32_t *grp_off, int32_t n_grp, double *out, void *stream);
+
+/* assign_HMM_states_to_proxy_expr_vals (R/inferCNV_HMM.R:1191-1206; K = 6:
+ * {0,0.5,1,1.5,2,3}) and i3HMM_assign_... (R/inferCNV_i3HMM.R:405-417; K = 3:
+ * {0.5,1,1.5}).  n = G*C elements. */
+int icnv_states_to_proxy(const uint8_t *states, double *out, int64_t n, int32_t K);
+int icnv_states_to_proxy_dev(const uint8_t *states, double *out, int64_t n, int32_t K, void *stream);
+
+/* Mean and sd over ALL values of the listed cells (i3 parameters,
+ * R/inferCNV_i3HMM.R:17-80; also clear_noise's centre).  out2_host = {mu, sigma}. */
+int icnv_cells_mean_sd_dev(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx,
+                           int64_t n_cells, double *out2_host, void *stream);
+
+/* ---- 2-D median denoise -------------------------------------------------- */
+/* apply_median_filtering / .median_filter (R/noise_reduction.R:43-113): for
+ * every (tile, chromosome) block -- tile = one tumour subcluster or one whole
+ * reference group, cells in stored order -- out[p,q] = median over the clamped
+ * (window_size+2)^2 neighbourhood.  Cells in no tile are copied through. */
+int icnv_median_filter(const double *expr_in, double *expr_out, int64_t G, int64_t C,
+                       const int32_t *chr_start, int32_t n_chr, const int32_t *tile_idx,
+                       const int32_t *tile_off, int32_t n_tiles, int32_t window_size);
+int icnv_median_filter_dev(const double *expr_in, double *expr_out, int64_t G, int64_t C,
+                           const int32_t *chr_start, int32_t n_chr, const int32_t *tile_idx,
+                           const int32_t *tile_off, int32_t n_tiles, int32_t window_size,
+                           void *stream);
+
+/* ---- profiling hooks (used by bench.py) --------------------------------- */
+/* When enabled, every kernel launch is bracketed by hipEvents recorded on the
+ * launch stream; icnv_timing_get() synchronises those events and returns the
+ * accumulated milliseconds and launch count of one kernel family:
+ * "chain_apply", "chain_gene_sums", "chain_cell_stats", "viterbi",
+ * "group_means", "broadcast_states", "median_filter", ... */
+void icnv_timing_enable(int on);
+void icnv_timing_reset(void);
+int icnv_timing_get(const char *kernel, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICNV_H */

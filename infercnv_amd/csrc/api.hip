@@ -1,0 +1,734 @@
+// extern "C" surface of libicnv_hip.so (see include/icnv.h) + host-side
+// orchestration: device workspace pool, descriptor uploads, reference rounds.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "icnv_internal.h"
+
+namespace icnv {
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    g_err = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what + " (" + file + ":" +
+            std::to_string(line) + ")";
+    (void)hipGetLastError();
+    return ICNV_ERR_HIP;
+}
+
+int num_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// ------------------------------------------------------------------ device memory pool
+// Grow-only caching allocator so that steady-state calls never hipMalloc/hipFree.
+namespace {
+std::mutex g_pool_mu;
+std::multimap<size_t, void *> g_free;    // size -> block
+std::map<void *, size_t> g_live;         // block -> size
+
+size_t round_size(size_t n) {
+    if (n < 256) n = 256;
+    size_t r = 256;
+    while (r < n) r <<= 1;
+    // above 64 MiB round to a multiple of 64 MiB instead of a power of two
+    if (n > (64u << 20)) r = ((n + (64u << 20) - 1) / (64u << 20)) * (64u << 20);
+    return r;
+}
+}  // namespace
+
+int pool_alloc(void **p, size_t bytes) {
+    const size_t sz = round_size(bytes);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_free.lower_bound(sz);
+        if (it != g_free.end() && it->first <= sz * 2) {
+            *p = it->second;
+            g_live[*p] = it->first;
+            g_free.erase(it);
+            return ICNV_OK;
+        }
+    }
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, sz);
+    if (e != hipSuccess) {
+        // release cached blocks and retry once
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            for (auto &kv : g_free) (void)hipFree(kv.second);
+            g_free.clear();
+        }
+        e = hipMalloc(&q, sz);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("out of device memory allocating " + std::to_string(sz) + " bytes");
+            return ICNV_ERR_NOMEM;
+        }
+    }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_live[q] = sz;
+    *p = q;
+    return ICNV_OK;
+}
+
+void pool_free(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_live.find(p);
+    if (it == g_live.end()) return;
+    g_free.emplace(it->second, p);
+    g_live.erase(it);
+}
+
+struct DevBuf {  // RAII over the pool
+    void *p = nullptr;
+    ~DevBuf() { pool_free(p); }
+    int alloc(size_t bytes) { pool_free(p); p = nullptr; return pool_alloc(&p, bytes); }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// ------------------------------------------------------------------ kernel timing
+namespace {
+bool g_timing = false;
+struct TimedRec { std::string name; hipEvent_t e0, e1; };
+std::vector<TimedRec> g_pending;
+std::map<std::string, std::pair<double, int64_t>> g_times;
+std::mutex g_time_mu;
+}  // namespace
+
+KernelTimer::KernelTimer(const char *n, hipStream_t s) : name(n), stream(s) {
+    on = g_timing;
+    if (on) {
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(e0, stream);
+    }
+}
+KernelTimer::~KernelTimer() {
+    if (on) {
+        (void)hipEventRecord(e1, stream);
+        std::lock_guard<std::mutex> lk(g_time_mu);
+        g_pending.push_back({name, e0, e1});
+    }
+}
+
+static void drain_timers() {
+    std::lock_guard<std::mutex> lk(g_time_mu);
+    for (auto &r : g_pending) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(r.e1);
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            auto &acc = g_times[r.name];
+            acc.first += ms;
+            acc.second += 1;
+        }
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    g_pending.clear();
+}
+
+// ------------------------------------------------------------------ helpers
+static int validate_chr(const int32_t *chr_start, int32_t n_chr, int64_t G) {
+    if (!chr_start || n_chr < 1) ICNV_FAIL(ICNV_ERR_ARG, "chr_start/n_chr missing");
+    if (chr_start[0] != 0 || chr_start[n_chr] != G) ICNV_FAIL(ICNV_ERR_ARG, "chr_start must run from 0 to G");
+    for (int k = 0; k < n_chr; ++k)
+        if (chr_start[k + 1] < chr_start[k]) ICNV_FAIL(ICNV_ERR_ARG, "chr_start must be non-decreasing");
+    return ICNV_OK;
+}
+
+static int validate_groups(const int32_t *idx, const int32_t *off, int32_t n_grp, int64_t C, const char *what) {
+    if (n_grp < 0 || (n_grp > 0 && (!off || off[0] != 0))) ICNV_FAIL(ICNV_ERR_ARG, std::string(what) + ": bad offsets");
+    for (int q = 0; q < n_grp; ++q)
+        if (off[q + 1] < off[q]) ICNV_FAIL(ICNV_ERR_ARG, std::string(what) + ": offsets must be non-decreasing");
+    const int64_t n = n_grp > 0 ? off[n_grp] : 0;
+    if (n > 0 && !idx) ICNV_FAIL(ICNV_ERR_ARG, std::string(what) + ": index vector missing");
+    for (int64_t i = 0; i < n; ++i)
+        if (idx[i] < 0 || idx[i] >= C) ICNV_FAIL(ICNV_ERR_ARG, std::string(what) + ": cell index out of range");
+    return ICNV_OK;
+}
+
+template <typename T>
+static int upload(DevBuf &b, const T *host, size_t n, hipStream_t s) {
+    int rc = b.alloc(std::max<size_t>(n, 1) * sizeof(T));
+    if (rc) return rc;
+    if (n) ICNV_HIP(hipMemcpyAsync(b.p, host, n * sizeof(T), hipMemcpyHostToDevice, s));
+    return ICNV_OK;
+}
+
+}  // namespace icnv
+
+using namespace icnv;
+
+// =================================================================== chain object
+struct icnv_chain {
+    icnv_chain_cfg cfg;
+    std::vector<int32_t> chr_start, ref_idx, ref_off;
+    std::vector<int> round_stage;  // ICNV_ST_* bit of each reference round
+    int T = 0;
+    uint32_t mask = 0;
+    DevBuf d_chr, d_ref, d_b1, d_b2, d_den, d_partial, d_sums, d_cellstats, d_stats;
+    bool uploaded = false;
+};
+
+static uint32_t stages_before(uint32_t mask, uint32_t stage_bit) { return mask & (stage_bit - 1u); }
+
+extern "C" {
+
+int icnv_version(void) { return 100; }
+const char *icnv_last_error(void) { return g_err.c_str(); }
+
+int icnv_init(int device) {
+    int n = 0;
+    ICNV_HIP(hipGetDeviceCount(&n));
+    if (n <= 0) ICNV_FAIL(ICNV_ERR_HIP, "no HIP device visible");
+    if (device >= 0) {
+        if (device >= n) ICNV_FAIL(ICNV_ERR_ARG, "device ordinal out of range");
+        ICNV_HIP(hipSetDevice(device));
+    }
+    int dev = 0;
+    ICNV_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    ICNV_HIP(hipGetDeviceProperties(&prop, dev));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        ICNV_FAIL(ICNV_ERR_UNSUPPORTED, std::string("libicnv_hip is built for gfx950 only, found ") + prop.gcnArchName);
+    return ICNV_OK;
+}
+
+void icnv_shutdown(void) {
+    drain_timers();
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto &kv : g_free) (void)hipFree(kv.second);
+    g_free.clear();
+}
+
+void icnv_timing_enable(int on) { g_timing = on != 0; }
+void icnv_timing_reset(void) {
+    drain_timers();
+    std::lock_guard<std::mutex> lk(g_time_mu);
+    g_times.clear();
+}
+int icnv_timing_get(const char *kernel, double *total_ms, int64_t *launches) {
+    drain_timers();
+    std::lock_guard<std::mutex> lk(g_time_mu);
+    auto it = g_times.find(kernel ? kernel : "");
+    if (it == g_times.end()) {
+        if (total_ms) *total_ms = 0.0;
+        if (launches) *launches = 0;
+        return ICNV_OK;
+    }
+    if (total_ms) *total_ms = it->second.first;
+    if (launches) *launches = it->second.second;
+    return ICNV_OK;
+}
+
+// ------------------------------------------------------------------ chain
+int icnv_chain_begin(icnv_chain_t **out, const icnv_chain_cfg *cfg) {
+    if (!out || !cfg) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->G < 1 || cfg->C < 0 || cfg->G > 0x7fffffff || cfg->C > 0x7fffffff)
+        ICNV_FAIL(ICNV_ERR_ARG, "bad matrix dimensions");
+    int rc = validate_chr(cfg->chr_start, cfg->n_chr, cfg->G);
+    if (rc) return rc;
+    uint32_t mask = cfg->stage_mask & (ICNV_ST_ALL | ICNV_ST_CENTER_MEAN);
+    if ((mask & ICNV_ST_MAX_THRESH) && std::isnan(cfg->max_thresh)) mask &= ~ICNV_ST_MAX_THRESH;
+    if ((mask & ICNV_ST_SMOOTH) && cfg->window_length < 2) mask &= ~ICNV_ST_SMOOTH;  // R/inferCNV_ops.R:2444
+    if ((mask & ICNV_ST_SMOOTH) && (cfg->window_length % 2 == 0))
+        ICNV_FAIL(ICNV_ERR_ARG, "window_length must be odd (the reference is undefined for even windows)");
+    if ((mask & ICNV_ST_DENOISE) && !std::isnan(cfg->noise_filter) && cfg->noise_filter == 0.0)
+        mask &= ~ICNV_ST_DENOISE;  // clear_noise(threshold = 0) is a no-op, R/inferCNV_ops.R:2236
+    if (cfg->G > chain_max_genes())
+        ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "fused smoothing chain supports at most " + std::to_string(chain_max_genes()) +
+                                            " genes (LDS-resident cell vector)");
+    const bool needs_ref = mask & (ICNV_ST_SUBTRACT_REF_1 | ICNV_ST_SUBTRACT_REF_2 | ICNV_ST_DENOISE);
+    if (needs_ref) {
+        if (cfg->n_ref_grp < 1) ICNV_FAIL(ICNV_ERR_ARG, "reference groups required for steps 8/12/22");
+        rc = validate_groups(cfg->ref_idx, cfg->ref_off, cfg->n_ref_grp, cfg->C, "ref groups");
+        if (rc) return rc;
+    }
+    icnv_chain *ch = new icnv_chain();
+    ch->cfg = *cfg;
+    ch->mask = mask;
+    ch->T = (mask & ICNV_ST_SMOOTH) ? (cfg->window_length - 1) / 2 : 0;
+    ch->chr_start.assign(cfg->chr_start, cfg->chr_start + cfg->n_chr + 1);
+    if (needs_ref) {
+        ch->ref_off.assign(cfg->ref_off, cfg->ref_off + cfg->n_ref_grp + 1);
+        ch->ref_idx.assign(cfg->ref_idx, cfg->ref_idx + cfg->ref_off[cfg->n_ref_grp]);
+    } else {
+        ch->cfg.n_ref_grp = 0;
+    }
+    ch->cfg.chr_start = ch->chr_start.data();
+    ch->cfg.ref_idx = ch->ref_idx.data();
+    ch->cfg.ref_off = ch->ref_off.data();
+    for (uint32_t bit : {ICNV_ST_SUBTRACT_REF_1, ICNV_ST_SUBTRACT_REF_2, ICNV_ST_DENOISE})
+        if (mask & bit) ch->round_stage.push_back((int)bit);
+    *out = ch;
+    return ICNV_OK;
+}
+
+int icnv_chain_num_rounds(const icnv_chain_t *ch) { return ch ? (int)ch->round_stage.size() : 0; }
+
+static int chain_upload(icnv_chain *ch, hipStream_t s) {
+    if (ch->uploaded) return ICNV_OK;
+    const int64_t G = ch->cfg.G;
+    const int ng = std::max(ch->cfg.n_ref_grp, 1);
+    int rc;
+    if ((rc = upload(ch->d_chr, ch->chr_start.data(), ch->chr_start.size(), s))) return rc;
+    if ((rc = upload(ch->d_ref, ch->ref_idx.data(), ch->ref_idx.size(), s))) return rc;
+    if ((rc = ch->d_b1.alloc(2 * G * sizeof(double)))) return rc;
+    if ((rc = ch->d_b2.alloc(2 * G * sizeof(double)))) return rc;
+    if ((rc = ch->d_den.alloc(2 * sizeof(double)))) return rc;
+    if ((rc = ch->d_partial.alloc((size_t)256 * G * sizeof(double)))) return rc;
+    if ((rc = ch->d_sums.alloc(((size_t)G * ng + ng) * sizeof(double)))) return rc;
+    if ((rc = ch->d_cellstats.alloc(std::max<size_t>(ch->ref_idx.size(), 1) * 2 * sizeof(double)))) return rc;
+    if ((rc = ch->d_stats.alloc(4 * sizeof(double)))) return rc;
+    ch->uploaded = true;
+    return ICNV_OK;
+}
+
+static ChainArgs chain_args(icnv_chain *ch, const double *in) {
+    ChainArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = in;
+    a.G = (int32_t)ch->cfg.G;
+    a.chr_start = ch->d_chr.as<int32_t>();
+    a.n_chr = ch->cfg.n_chr;
+    a.T = ch->T;
+    a.use_bounds = ch->cfg.use_bounds;
+    a.max_thresh = ch->cfg.max_thresh;
+    a.b1 = ch->d_b1.as<double>();
+    a.b2 = ch->d_b2.as<double>();
+    a.denoise = ch->d_den.as<double>();
+    a.partial = ch->d_partial.as<double>();
+    a.cell_stats = ch->d_cellstats.as<double>();
+    return a;
+}
+
+int icnv_chain_round_partial_dev(icnv_chain_t *ch, int round, const double *expr_in, double **partial_dev,
+                                 int64_t *n, void *stream) {
+    if (!ch || !expr_in || round < 0 || round >= (int)ch->round_stage.size()) ICNV_FAIL(ICNV_ERR_ARG, "bad round");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = chain_upload(ch, s);
+    if (rc) return rc;
+    const uint32_t bit = (uint32_t)ch->round_stage[round];
+    const int64_t G = ch->cfg.G;
+    const int ng = ch->cfg.n_ref_grp;
+    ChainArgs a = chain_args(ch, expr_in);
+    a.mask = stages_before(ch->mask, bit) | (ch->mask & ICNV_ST_CENTER_MEAN);
+    if (bit == ICNV_ST_DENOISE) {
+        const int nref = (int)ch->ref_idx.size();
+        a.cells = ch->d_ref.as<int32_t>();
+        a.n_cells = nref;
+        if (nref > 0) {
+            if ((rc = launch_chain(a, MODE_CELL_STATS, s))) return rc;
+        }
+        if ((rc = launch_reduce_cell_stats(ch->d_cellstats.as<double>(), nref, (int32_t)G, ch->d_stats.as<double>(), s)))
+            return rc;
+        if (partial_dev) *partial_dev = ch->d_stats.as<double>();
+        if (n) *n = 4;
+        return ICNV_OK;
+    }
+    double *sums = ch->d_sums.as<double>();
+    for (int q = 0; q < ng; ++q) {
+        const int cnt = ch->ref_off[q + 1] - ch->ref_off[q];
+        double *dst = sums + (size_t)q * G;
+        double *cdst = sums + (size_t)ng * G + q;
+        if (cnt == 0) {
+            ICNV_HIP(hipMemsetAsync(dst, 0, G * sizeof(double), s));
+            ICNV_HIP(hipMemsetAsync(cdst, 0, sizeof(double), s));
+            continue;
+        }
+        a.cells = ch->d_ref.as<int32_t>() + ch->ref_off[q];
+        a.n_cells = cnt;
+        if ((rc = launch_chain(a, MODE_GENE_SUMS, s))) return rc;
+        const int nblk = std::min(cnt, 256);
+        if ((rc = launch_reduce_partials(a.partial, nblk, (int32_t)G, dst, (double)cnt, cdst, s))) return rc;
+    }
+    if (partial_dev) *partial_dev = sums;
+    if (n) *n = G * ng + ng;
+    return ICNV_OK;
+}
+
+int icnv_chain_round_finish_dev(icnv_chain_t *ch, int round, void *stream) {
+    if (!ch || round < 0 || round >= (int)ch->round_stage.size()) ICNV_FAIL(ICNV_ERR_ARG, "bad round");
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t bit = (uint32_t)ch->round_stage[round];
+    if (bit == ICNV_ST_DENOISE)
+        return launch_denoise_from_stats(ch->d_stats.as<double>(), ch->cfg.sd_amplifier, ch->cfg.noise_filter,
+                                         ch->d_den.as<double>(), s);
+    double *bounds = (bit == ICNV_ST_SUBTRACT_REF_1) ? ch->d_b1.as<double>() : ch->d_b2.as<double>();
+    return launch_bounds_from_sums(ch->d_sums.as<double>(), (int32_t)ch->cfg.G, ch->cfg.n_ref_grp, ch->cfg.use_bounds,
+                                   bounds, s);
+}
+
+int icnv_chain_apply_dev(icnv_chain_t *ch, const double *expr_in, double *expr_out, double *pre_denoise,
+                         void *stream) {
+    if (!ch || !expr_in || !expr_out) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = chain_upload(ch, s);
+    if (rc) return rc;
+    ChainArgs a = chain_args(ch, expr_in);
+    a.mask = ch->mask;
+    a.out = expr_out;
+    a.pre_out = pre_denoise;
+    a.cells = nullptr;
+    a.n_cells = (int32_t)ch->cfg.C;
+    if (pre_denoise && !(ch->mask & ICNV_ST_DENOISE)) {
+        // no denoise stage: the "pre-denoise" matrix is the output itself
+        a.pre_out = nullptr;
+        if ((rc = launch_chain(a, MODE_APPLY, s))) return rc;
+        ICNV_HIP(hipMemcpyAsync(pre_denoise, expr_out, (size_t)ch->cfg.G * ch->cfg.C * sizeof(double),
+                                hipMemcpyDeviceToDevice, s));
+        return ICNV_OK;
+    }
+    return launch_chain(a, MODE_APPLY, s);
+}
+
+int icnv_chain_get_denoise(icnv_chain_t *ch, double *mu_s, void *stream) {
+    if (!ch || !mu_s) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
+    if (!(ch->mask & ICNV_ST_DENOISE) || !ch->uploaded) ICNV_FAIL(ICNV_ERR_ARG, "no denoise stage in this chain");
+    hipStream_t s = (hipStream_t)stream;
+    ICNV_HIP(hipMemcpyAsync(mu_s, ch->d_den.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    ICNV_HIP(hipStreamSynchronize(s));
+    return ICNV_OK;
+}
+
+void icnv_chain_end(icnv_chain_t *ch) { delete ch; }
+
+int icnv_smooth_chain_dev(const double *expr_in, double *expr_out, double *pre_denoise, const icnv_chain_cfg *cfg,
+                          void *stream) {
+    icnv_chain_t *ch = nullptr;
+    int rc = icnv_chain_begin(&ch, cfg);
+    if (rc) return rc;
+    for (int q = 0; q < ch->cfg.n_ref_grp && !ch->round_stage.empty(); ++q)
+        if (ch->ref_off[q + 1] == ch->ref_off[q]) {
+            icnv_chain_end(ch);
+            ICNV_FAIL(ICNV_ERR_ARG, "empty reference group");
+        }
+    for (int r = 0; r < icnv_chain_num_rounds(ch) && !rc; ++r) {
+        rc = icnv_chain_round_partial_dev(ch, r, expr_in, nullptr, nullptr, stream);
+        if (!rc) rc = icnv_chain_round_finish_dev(ch, r, stream);
+    }
+    if (!rc) rc = icnv_chain_apply_dev(ch, expr_in, expr_out, pre_denoise, stream);
+    // device buffers of the chain go back to the pool; work already enqueued on
+    // `stream` keeps using them, and later pool users enqueue on streams that the
+    // caller orders after it (single-stream usage) -- see DESIGN.md "workspace".
+    icnv_chain_end(ch);
+    return rc;
+}
+
+int icnv_smooth_chain(const double *expr_in, double *expr_out, double *pre_denoise, const icnv_chain_cfg *cfg) {
+    if (!expr_in || !expr_out || !cfg) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
+    const size_t bytes = (size_t)cfg->G * (size_t)cfg->C * sizeof(double);
+    DevBuf din, dout, dpre;
+    int rc;
+    if ((rc = din.alloc(bytes))) return rc;
+    if ((rc = dout.alloc(bytes))) return rc;
+    if (pre_denoise && (rc = dpre.alloc(bytes))) return rc;
+    ICNV_HIP(hipMemcpy(din.p, expr_in, bytes, hipMemcpyHostToDevice));
+    rc = icnv_smooth_chain_dev(din.as<double>(), dout.as<double>(), pre_denoise ? dpre.as<double>() : nullptr, cfg,
+                               nullptr);
+    if (rc) return rc;
+    ICNV_HIP(hipMemcpy(expr_out, dout.p, bytes, hipMemcpyDeviceToHost));
+    if (pre_denoise) ICNV_HIP(hipMemcpy(pre_denoise, dpre.p, bytes, hipMemcpyDeviceToHost));
+    return ICNV_OK;
+}
+
+int icnv_average_bounds_dev(const double *expr, int64_t G, int64_t C, double *out2_host, void *stream) {
+    if (!expr || !out2_host || G < 1 || C < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf d;
+    int rc = d.alloc((size_t)C * 2 * sizeof(double));
+    if (rc) return rc;
+    if ((rc = launch_minmax_cells(expr, (int32_t)G, C, d.as<double>(), s))) return rc;
+    std::vector<double> h((size_t)C * 2);
+    ICNV_HIP(hipMemcpyAsync(h.data(), d.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    ICNV_HIP(hipStreamSynchronize(s));
+    // mean over cells, like R's mean(): long double accumulation + refinement
+    for (int k = 0; k < 2; ++k) {
+        long double acc = 0;
+        for (int64_t c = 0; c < C; ++c) acc += h[2 * c + k];
+        acc /= (long double)C;
+        long double t = 0;
+        for (int64_t c = 0; c < C; ++c) t += (h[2 * c + k] - acc);
+        acc += t / (long double)C;
+        out2_host[k] = (double)acc;
+    }
+    return ICNV_OK;
+}
+
+int icnv_average_bounds(const double *expr, int64_t G, int64_t C, double *out2) {
+    if (!expr || !out2) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
+    DevBuf d;
+    const size_t bytes = (size_t)G * C * sizeof(double);
+    int rc = d.alloc(bytes);
+    if (rc) return rc;
+    ICNV_HIP(hipMemcpy(d.p, expr, bytes, hipMemcpyHostToDevice));
+    return icnv_average_bounds_dev(d.as<double>(), G, C, out2, nullptr);
+}
+
+// ------------------------------------------------------------------ HMM
+static int fill_hmm(HmmParams &p, int32_t K, const double *mean, const double *logPi, const double *logDelta) {
+    if (K != 3 && K != 6) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "HMM kernels are built for K = 6 (i6) and K = 3 (i3)");
+    if (!mean || !logPi || !logDelta) ICNV_FAIL(ICNV_ERR_ARG, "null HMM parameter");
+    std::memset(&p, 0, sizeof(p));
+    p.K = K;
+    for (int k = 0; k < K; ++k) { p.mean[k] = mean[k]; p.logDelta[k] = logDelta[k]; }
+    for (int i = 0; i < K * K; ++i) p.logPi[i] = logPi[i];
+    return ICNV_OK;
+}
+
+static void chr_order_longest_first(const int32_t *chr_start, int32_t n_chr, std::vector<int32_t> &order) {
+    order.resize(n_chr);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        return (chr_start[a + 1] - chr_start[a]) > (chr_start[b + 1] - chr_start[b]);
+    });
+}
+
+// Viterbi over the columns of x (G x ncols), batched so that the back-pointer
+// scratch stays below ~4 GiB.
+static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t ncols, const int32_t *chr_start,
+                           int32_t n_chr, const HmmParams &p, const double *sd_per_col_dev, double sd_shared,
+                           int32_t *n_underflow_dev, hipStream_t s) {
+    DevBuf d_chr, d_ord, d_bp;
+    int rc;
+    std::vector<int32_t> order;
+    chr_order_longest_first(chr_start, n_chr, order);
+    if ((rc = upload(d_chr, chr_start, (size_t)n_chr + 1, s))) return rc;
+    if ((rc = upload(d_ord, order.data(), order.size(), s))) return rc;
+    int64_t batch = ((int64_t)4 << 30) / ((int64_t)G * 4);
+    batch = std::max<int64_t>(64, (batch / 64) * 64);
+    batch = std::min(batch, ((ncols + 63) / 64) * 64);
+    if ((rc = d_bp.alloc(viterbi_scratch_bytes((int32_t)G, batch)))) return rc;
+    for (int64_t c0 = 0; c0 < ncols; c0 += batch) {
+        const int64_t nc = std::min(batch, ncols - c0);
+        rc = launch_viterbi(x + c0 * G, states + c0 * G, (int32_t)G, nc, d_chr.as<int32_t>(), d_ord.as<int32_t>(), n_chr,
+                            0, p, sd_per_col_dev ? sd_per_col_dev + c0 : nullptr, sd_shared, d_bp.as<uint32_t>(),
+                            n_underflow_dev, s);
+        if (rc) return rc;
+    }
+    return ICNV_OK;
+}
+
+int icnv_viterbi_cells_dev(const double *expr, uint8_t *states, int64_t G, int64_t C, const int32_t *chr_start,
+                           int32_t n_chr, int32_t K, const double *mean, double sd_shared, const double *logPi,
+                           const double *logDelta, int32_t *n_underflow_dev, void *stream) {
+    if (!expr || !states || G < 1 || C < 0 || G > 0x7fffffff) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    int rc = validate_chr(chr_start, n_chr, G);
+    if (rc) return rc;
+    if (!(sd_shared > 0.0)) ICNV_FAIL(ICNV_ERR_ARG, "sd_shared must be positive");
+    HmmParams p;
+    if ((rc = fill_hmm(p, K, mean, logPi, logDelta))) return rc;
+    return viterbi_columns(expr, states, G, C, chr_start, n_chr, p, nullptr, sd_shared, n_underflow_dev,
+                           (hipStream_t)stream);
+}
+
+int icnv_viterbi_cells(const double *expr, uint8_t *states, int64_t G, int64_t C, const int32_t *chr_start,
+                       int32_t n_chr, int32_t K, const double *mean, double sd_shared, const double *logPi,
+                       const double *logDelta) {
+    if (!expr || !states) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
+    DevBuf dx, ds, dn;
+    int rc;
+    const size_t n = (size_t)G * (size_t)C;
+    if ((rc = dx.alloc(n * sizeof(double))) || (rc = ds.alloc(std::max<size_t>(n, 1))) || (rc = dn.alloc(sizeof(int32_t))))
+        return rc;
+    ICNV_HIP(hipMemcpy(dx.p, expr, n * sizeof(double), hipMemcpyHostToDevice));
+    ICNV_HIP(hipMemset(dn.p, 0, sizeof(int32_t)));
+    rc = icnv_viterbi_cells_dev(dx.as<double>(), ds.as<uint8_t>(), G, C, chr_start, n_chr, K, mean, sd_shared, logPi,
+                                logDelta, dn.as<int32_t>(), nullptr);
+    if (rc) return rc;
+    int32_t bad = 0;
+    ICNV_HIP(hipMemcpy(states, ds.p, n, hipMemcpyDeviceToHost));
+    ICNV_HIP(hipMemcpy(&bad, dn.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (bad) ICNV_FAIL(ICNV_ERR_UNDERFLOW, "Problems With Underflow in " + std::to_string(bad) + " sequences");
+    return ICNV_OK;
+}
+
+int icnv_group_means_dev(const double *expr, int64_t G, int64_t C, const int32_t *grp_idx, const int32_t *grp_off,
+                         int32_t n_grp, double *out, void *stream) {
+    if (!expr || !out || G < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    int rc = validate_groups(grp_idx, grp_off, n_grp, C, "groups");
+    if (rc) return rc;
+    if (n_grp == 0) return ICNV_OK;
+    if (n_grp > 65535) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "more than 65535 groups");
+    for (int q = 0; q < n_grp; ++q)
+        if (grp_off[q + 1] == grp_off[q]) ICNV_FAIL(ICNV_ERR_ARG, "empty group");
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf d_idx, d_off, d_part;
+    if ((rc = upload(d_idx, grp_idx, (size_t)grp_off[n_grp], s))) return rc;
+    if ((rc = upload(d_off, grp_off, (size_t)n_grp + 1, s))) return rc;
+    const int ns = group_means_nsplit((int32_t)G, n_grp);
+    if ((rc = d_part.alloc((size_t)n_grp * ns * G * sizeof(double)))) return rc;
+    return launch_group_means_ws(expr, (int32_t)G, d_idx.as<int32_t>(), d_off.as<int32_t>(), n_grp, ns,
+                                 d_part.as<double>(), out, s);
+}
+
+int icnv_viterbi_groups_dev(const double *expr, uint8_t *states, int64_t G, int64_t C, const int32_t *chr_start,
+                            int32_t n_chr, const int32_t *grp_idx, const int32_t *grp_off, int32_t n_grp, int32_t K,
+                            const double *mean, const double *sd_shared_per_grp, const double *logPi,
+                            const double *logDelta, int32_t *n_underflow_dev, void *stream) {
+    if (!expr || !states || G < 1 || C < 0 || G > 0x7fffffff) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    int rc = validate_chr(chr_start, n_chr, G);
+    if (rc) return rc;
+    if ((rc = validate_groups(grp_idx, grp_off, n_grp, C, "groups"))) return rc;
+    if (n_grp > 0 && !sd_shared_per_grp) ICNV_FAIL(ICNV_ERR_ARG, "sd_shared_per_grp missing");
+    for (int q = 0; q < n_grp; ++q)
+        if (!(sd_shared_per_grp[q] > 0.0)) ICNV_FAIL(ICNV_ERR_ARG, "group sd must be positive");
+    HmmParams p;
+    if ((rc = fill_hmm(p, K, mean, logPi, logDelta))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf d_gm, d_gs, d_sd, d_map;
+    std::vector<int32_t> cell_to_grp((size_t)std::max<int64_t>(C, 1), -1);
+    for (int q = 0; q < n_grp; ++q)
+        for (int i = grp_off[q]; i < grp_off[q + 1]; ++i) cell_to_grp[grp_idx[i]] = q;  // later groups win, as in R
+    if ((rc = upload(d_map, cell_to_grp.data(), (size_t)C, s))) return rc;
+    if (n_grp > 0) {
+        if ((rc = d_gm.alloc((size_t)G * n_grp * sizeof(double)))) return rc;
+        if ((rc = d_gs.alloc((size_t)G * n_grp))) return rc;
+        if ((rc = upload(d_sd, sd_shared_per_grp, (size_t)n_grp, s))) return rc;
+        if ((rc = icnv_group_means_dev(expr, G, C, grp_idx, grp_off, n_grp, d_gm.as<double>(), stream))) return rc;
+        if ((rc = viterbi_columns(d_gm.as<double>(), d_gs.as<uint8_t>(), G, n_grp, chr_start, n_chr, p,
+                                  d_sd.as<double>(), 0.0, n_underflow_dev, s)))
+            return rc;
+    }
+    return launch_broadcast_states(d_gs.as<uint8_t>(), (int32_t)G, C, d_map.as<int32_t>(), states, s);
+}
+
+int icnv_viterbi_groups(const double *expr, uint8_t *states, int64_t G, int64_t C, const int32_t *chr_start,
+                        int32_t n_chr, const int32_t *grp_idx, const int32_t *grp_off, int32_t n_grp, int32_t K,
+                        const double *mean, const double *sd_shared_per_grp, const double *logPi,
+                        const double *logDelta) {
+    if (!expr || !states) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
+    DevBuf dx, ds, dn;
+    int rc;
+    const size_t n = (size_t)G * (size_t)C;
+    if ((rc = dx.alloc(n * sizeof(double))) || (rc = ds.alloc(std::max<size_t>(n, 1))) || (rc = dn.alloc(sizeof(int32_t))))
+        return rc;
+    ICNV_HIP(hipMemcpy(dx.p, expr, n * sizeof(double), hipMemcpyHostToDevice));
+    ICNV_HIP(hipMemset(dn.p, 0, sizeof(int32_t)));
+    rc = icnv_viterbi_groups_dev(dx.as<double>(), ds.as<uint8_t>(), G, C, chr_start, n_chr, grp_idx, grp_off, n_grp, K,
+                                 mean, sd_shared_per_grp, logPi, logDelta, dn.as<int32_t>(), nullptr);
+    if (rc) return rc;
+    int32_t bad = 0;
+    ICNV_HIP(hipMemcpy(states, ds.p, n, hipMemcpyDeviceToHost));
+    ICNV_HIP(hipMemcpy(&bad, dn.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (bad) ICNV_FAIL(ICNV_ERR_UNDERFLOW, "Problems With Underflow in " + std::to_string(bad) + " sequences");
+    return ICNV_OK;
+}
+
+int icnv_states_to_proxy_dev(const uint8_t *states, double *out, int64_t n, int32_t K, void *stream) {
+    if (!states || !out || n < 0 || (K != 3 && K != 6)) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    return launch_states_to_proxy(states, out, n, K, (hipStream_t)stream);
+}
+
+int icnv_states_to_proxy(const uint8_t *states, double *out, int64_t n, int32_t K) {
+    if (!states || !out) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
+    DevBuf ds, dout;
+    int rc;
+    if ((rc = ds.alloc(std::max<int64_t>(n, 1))) || (rc = dout.alloc(std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
+    ICNV_HIP(hipMemcpy(ds.p, states, n, hipMemcpyHostToDevice));
+    if ((rc = icnv_states_to_proxy_dev(ds.as<uint8_t>(), dout.as<double>(), n, K, nullptr))) return rc;
+    ICNV_HIP(hipMemcpy(out, dout.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    return ICNV_OK;
+}
+
+int icnv_cells_mean_sd_dev(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx, int64_t n_cells,
+                           double *out2_host, void *stream) {
+    if (!expr || !out2_host || G < 1 || n_cells < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    // mean over all G*n values, then sd around that mean: one GENE_SUMS-free pass
+    // over the listed cells using the chain kernel's per-cell statistics.
+    icnv_chain_cfg cfg;
+    std::memset(&cfg, 0, sizeof(cfg));
+    std::vector<int32_t> cs = {0, (int32_t)G}, off = {0, (int32_t)n_cells};
+    cfg.G = G; cfg.C = C; cfg.chr_start = cs.data(); cfg.n_chr = 1; cfg.window_length = 0;
+    cfg.max_thresh = NAN; cfg.use_bounds = 1; cfg.sd_amplifier = 1.0; cfg.noise_filter = NAN;
+    cfg.stage_mask = ICNV_ST_DENOISE; cfg.ref_idx = cell_idx; cfg.ref_off = off.data(); cfg.n_ref_grp = 1;
+    icnv_chain_t *ch = nullptr;
+    int rc = icnv_chain_begin(&ch, &cfg);
+    if (rc) return rc;
+    double *part = nullptr;
+    rc = icnv_chain_round_partial_dev(ch, 0, expr, &part, nullptr, stream);
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<double> cstat((size_t)n_cells * 2);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(cstat.data(), ch->d_cellstats.p, cstat.size() * sizeof(double),
+                                      hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) rc = hip_fail(e, "copy cell stats", __FILE__, __LINE__);
+    }
+    icnv_chain_end(ch);
+    if (rc) return rc;
+    // combine per-cell (sum, sd): total mean, pooled sum of squares
+    long double tot = 0;
+    for (int64_t i = 0; i < n_cells; ++i) tot += cstat[2 * i];
+    const long double N = (long double)n_cells * (long double)G;
+    const long double mu = tot / N;
+    long double ss = 0;
+    for (int64_t i = 0; i < n_cells; ++i) {
+        const long double m_i = (long double)cstat[2 * i] / (long double)G;
+        const long double sd_i = cstat[2 * i + 1];
+        ss += sd_i * sd_i * (long double)(G - 1) + (long double)G * (m_i - mu) * (m_i - mu);
+    }
+    out2_host[0] = (double)mu;
+    out2_host[1] = (double)std::sqrt((double)(ss / (N - 1)));
+    return ICNV_OK;
+}
+
+// ------------------------------------------------------------------ median filter
+int icnv_median_filter_dev(const double *expr_in, double *expr_out, int64_t G, int64_t C, const int32_t *chr_start,
+                           int32_t n_chr, const int32_t *tile_idx, const int32_t *tile_off, int32_t n_tiles,
+                           int32_t window_size, void *stream) {
+    if (!expr_in || !expr_out || G < 1 || C < 0 || G > 0x7fffffff) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    if (expr_in == expr_out) ICNV_FAIL(ICNV_ERR_ARG, "median filter cannot run in place");
+    if (window_size < 1) ICNV_FAIL(ICNV_ERR_ARG, "window_size must be >= 1");
+    int rc = validate_chr(chr_start, n_chr, G);
+    if (rc) return rc;
+    if ((rc = validate_groups(tile_idx, tile_off, n_tiles, C, "tiles"))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    ICNV_HIP(hipMemcpyAsync(expr_out, expr_in, (size_t)G * C * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (n_tiles == 0) return ICNV_OK;
+    std::vector<int32_t> blk_off((size_t)n_tiles + 1, 0);
+    for (int t = 0; t < n_tiles; ++t)
+        blk_off[t + 1] = blk_off[t] + (tile_off[t + 1] - tile_off[t] + MEDIAN_CELLS_PER_PATCH - 1) / MEDIAN_CELLS_PER_PATCH;
+    DevBuf d_chr, d_idx, d_off, d_blk;
+    if ((rc = upload(d_chr, chr_start, (size_t)n_chr + 1, s))) return rc;
+    if ((rc = upload(d_idx, tile_idx, (size_t)tile_off[n_tiles], s))) return rc;
+    if ((rc = upload(d_off, tile_off, (size_t)n_tiles + 1, s))) return rc;
+    if ((rc = upload(d_blk, blk_off.data(), blk_off.size(), s))) return rc;
+    return launch_median_filter(expr_in, expr_out, (int32_t)G, C, d_chr.as<int32_t>(), n_chr, d_idx.as<int32_t>(),
+                                d_off.as<int32_t>(), n_tiles, d_blk.as<int32_t>(), chr_start, blk_off[n_tiles],
+                                window_size, s);
+}
+
+int icnv_median_filter(const double *expr_in, double *expr_out, int64_t G, int64_t C, const int32_t *chr_start,
+                       int32_t n_chr, const int32_t *tile_idx, const int32_t *tile_off, int32_t n_tiles,
+                       int32_t window_size) {
+    if (!expr_in || !expr_out) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
+    DevBuf din, dout;
+    int rc;
+    const size_t bytes = (size_t)G * (size_t)C * sizeof(double);
+    if ((rc = din.alloc(bytes)) || (rc = dout.alloc(bytes))) return rc;
+    ICNV_HIP(hipMemcpy(din.p, expr_in, bytes, hipMemcpyHostToDevice));
+    rc = icnv_median_filter_dev(din.as<double>(), dout.as<double>(), G, C, chr_start, n_chr, tile_idx, tile_off, n_tiles,
+                                window_size, nullptr);
+    if (rc) return rc;
+    ICNV_HIP(hipMemcpy(expr_out, dout.p, bytes, hipMemcpyDeviceToHost));
+    return ICNV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+// Internal declarations shared by the HIP translation units of libicnv_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/icnv.h"
+
+namespace icnv {
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define ICNV_HIP(call)                                                      \
+    do {                                                                    \
+        hipError_t _e = (call);                                             \
+        if (_e != hipSuccess) return ::icnv::hip_fail(_e, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define ICNV_FAIL(code, msg)        \
+    do {                            \
+        ::icnv::set_error(msg);     \
+        return (code);              \
+    } while (0)
+
+// Optional per-kernel timing with hipEvents recorded on the launch stream.
+struct KernelTimer {
+    KernelTimer(const char *name, hipStream_t s);
+    ~KernelTimer();
+    const char *name;
+    hipStream_t stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool on = false;
+};
+
+int num_cus();
+
+// ---- smoothing chain ------------------------------------------------------
+enum ChainMode { MODE_APPLY = 0, MODE_GENE_SUMS = 1, MODE_CELL_STATS = 2 };
+
+struct ChainArgs {
+    const double *in;       // G x C_total column-major
+    double *out;            // MODE_APPLY
+    double *pre_out;        // MODE_APPLY, nullable: matrix before step 22
+    int32_t G;
+    const int32_t *cells;   // nullable: columns to process (else 0..n_cells-1)
+    int32_t n_cells;
+    const int32_t *chr_start;  // device, n_chr+1
+    int32_t n_chr;
+    int32_t T;              // half window, (W-1)/2; 0 = no smoothing
+    uint32_t mask;          // ICNV_ST_* stages applied in this pass
+    int32_t use_bounds;
+    double max_thresh;
+    const double *b1;       // [2*G] lo | hi  (step 8)
+    const double *b2;       // [2*G] lo | hi  (step 12)
+    const double *denoise;  // [2] mu, s
+    double *partial;        // MODE_GENE_SUMS: [gridDim.x * G]
+    double *cell_stats;     // MODE_CELL_STATS: [n_cells * 2] {sum, sd}
+};
+
+int launch_chain(const ChainArgs &a, int mode, hipStream_t stream);
+int chain_max_genes();
+int launch_reduce_partials(const double *partial, int nblk, int32_t G, double *out, double count,
+                           double *count_out, hipStream_t stream);
+int launch_bounds_from_sums(const double *sums_counts, int32_t G, int32_t n_grp, int32_t use_bounds,
+                            double *bounds, hipStream_t stream);
+int launch_reduce_cell_stats(const double *cell_stats, int32_t n_cells, int32_t G, double *out4,
+                             hipStream_t stream);
+int launch_denoise_from_stats(const double *stats4, double sd_amplifier, double noise_filter,
+                              double *mu_s, hipStream_t stream);
+int launch_minmax_cells(const double *x, int32_t G, int64_t C, double *out2_dev, hipStream_t stream);
+
+// ---- HMM ------------------------------------------------------------------
+struct HmmParams {
+    int32_t K;
+    double mean[8];
+    double logPi[64];   // [j + K*k]
+    double logDelta[8];
+};
+
+int launch_viterbi(const double *x, uint8_t *states, int32_t G, int64_t n_seq_cols, const int32_t *chr_start_dev,
+                   const int32_t *chr_order_dev, int32_t n_chr, int32_t max_chr_len, const HmmParams &p,
+                   const double *sd_per_col_dev, double sd_shared, uint32_t *bp_scratch, int32_t *n_underflow,
+                   hipStream_t stream);
+size_t viterbi_scratch_bytes(int32_t G, int64_t n_cols);
+int group_means_nsplit(int32_t G, int32_t n_grp);
+int launch_group_means_ws(const double *x, int32_t G, const int32_t *grp_idx_dev, const int32_t *grp_off_dev,
+                          int32_t n_grp, int nsplit, double *part, double *out, hipStream_t stream);
+int launch_broadcast_states(const uint8_t *grp_states, int32_t G, int64_t C, const int32_t *cell_to_grp_dev,
+                            uint8_t *states, hipStream_t stream);
+int launch_states_to_proxy(const uint8_t *states, double *out, int64_t n, int32_t K, hipStream_t stream);
+
+// ---- median filter --------------------------------------------------------
+int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, const int32_t *chr_start_dev,
+                         int32_t n_chr, const int32_t *tile_idx_dev, const int32_t *tile_off_dev, int32_t n_tiles,
+                         const int32_t *blk_off_dev, const int32_t *chr_start_host, int32_t total_cell_patches,
+                         int32_t window_size, hipStream_t stream);
+constexpr int MEDIAN_CELLS_PER_PATCH = 8;
+
+}  // namespace icnv

@@ -1,0 +1,229 @@
+"""Device-resident entry points: thin wrappers that hand torch CUDA tensors'
+data pointers to the C ABI (`*_dev` functions of include/icnv.h).
+
+PyTorch is used only for device memory, streams and (in `sharded.py`)
+torch.distributed -- all arithmetic happens in libicnv_hip.so.
+
+Layout: an expression matrix is a contiguous float64 tensor of shape
+(C cells, G genes): row-major (C, G) is byte-identical to R's column-major
+genes x cells `expr.data` (R/inferCNV.R:18), i.e. element (gene g, cell c) sits
+at offset g + G*c.  State matrices are uint8 (C, G).
+"""
+from __future__ import annotations
+
+import ctypes as ct
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Cfg, check, f64, i32, pack_groups
+
+
+def _stream():
+    return ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ct.c_void_p(t.data_ptr()) if t is not None else ct.c_void_p(0)
+
+
+def _check_matrix(x, dtype=torch.float64):
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == dtype and x.dim() == 2 and x.is_contiguous()):
+        raise TypeError(f"expected a contiguous CUDA {dtype} tensor of shape (cells, genes)")
+    return x.shape[0], x.shape[1]
+
+
+def init(device=None):
+    """Bind the calling thread to `device` (defaults to torch's current device)."""
+    L = _lib.load()
+    if device is None:
+        device = torch.cuda.current_device()
+    check(L.icnv_init(int(device)))
+
+
+# ------------------------------------------------------------------ smoothing chain
+def smooth_chain(x, chr_start, ref_groups, window_length=101, max_thresh=3.0, use_bounds=True,
+                 sd_amplifier=1.5, noise_filter=None, stage_mask=_lib.ST_ALL, out=None, want_pre_denoise=False):
+    """Steps 8,9,10,11,12,14,22 of run() (R/inferCNV_ops.R:771-1589) fused on the
+    GPU.  Returns (out, pre_denoise or None)."""
+    L = _lib.load()
+    C, G = _check_matrix(x)
+    cfg = Cfg(G, C, chr_start, ref_groups, window_length, max_thresh, use_bounds, sd_amplifier, noise_filter,
+              stage_mask)
+    if out is None:
+        out = torch.empty_like(x)
+    pre = torch.empty_like(x) if want_pre_denoise else None
+    check(L.icnv_smooth_chain_dev(_ptr(x), _ptr(out), _ptr(pre), cfg.ptr(), _stream()))
+    return out, pre
+
+
+class ChainPlan:
+    """Split-phase chain (icnv_chain_* in include/icnv.h) for cell-sharded runs:
+    for each reference round r: partial(r) -> all-reduce(sum) -> finish(r); then apply()."""
+
+    def __init__(self, G, C, chr_start, ref_groups_local, **kw):
+        self.L = _lib.load()
+        self.cfg = Cfg(G, C, chr_start, ref_groups_local, **kw)
+        h = ct.c_void_p()
+        check(self.L.icnv_chain_begin(ct.byref(h), self.cfg.ptr()))
+        self.h = h
+        self.G, self.C = G, C
+
+    @property
+    def num_rounds(self):
+        return self.L.icnv_chain_num_rounds(self.h)
+
+    def round_partial(self, r, x):
+        """Enqueue this rank's partial statistic; returns a float64 CUDA tensor
+        *view* of the library's buffer (all-reduce it in place)."""
+        p, n = ct.c_void_p(), ct.c_int64()
+        check(self.L.icnv_chain_round_partial_dev(self.h, r, _ptr(x), ct.byref(p), ct.byref(n), _stream()))
+        return _wrap_f64(p.value, n.value, x.device)
+
+    def round_finish(self, r):
+        check(self.L.icnv_chain_round_finish_dev(self.h, r, _stream()))
+
+    def apply(self, x, out=None, want_pre_denoise=False):
+        if out is None:
+            out = torch.empty_like(x)
+        pre = torch.empty_like(x) if want_pre_denoise else None
+        check(self.L.icnv_chain_apply_dev(self.h, _ptr(x), _ptr(out), _ptr(pre), _stream()))
+        return out, pre
+
+    def denoise_params(self):
+        buf = (ct.c_double * 2)()
+        check(self.L.icnv_chain_get_denoise(self.h, buf, _stream()))
+        return buf[0], buf[1]
+
+    def close(self):
+        if self.h:
+            self.L.icnv_chain_end(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _DevView:
+    """Expose a raw device pointer through __cuda_array_interface__."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def _wrap_f64(ptr, n, device):
+    return torch.as_tensor(_DevView(ptr, n), device=device)
+
+
+def average_bounds(x):
+    """get_average_bounds (R/inferCNV_ops.R:2723-2742) -> (lower, upper)."""
+    L = _lib.load()
+    C, G = _check_matrix(x)
+    out = (ct.c_double * 2)()
+    check(L.icnv_average_bounds_dev(_ptr(x), G, C, out, _stream()))
+    return out[0], out[1]
+
+
+# ------------------------------------------------------------------ HMM
+def viterbi_cells(x, chr_start, means, sd_shared, logPi, logDelta, states=None):
+    """predict_CNV_via_HMM_on_indiv_cells (R/inferCNV_HMM.R:284-324) / i3 variant
+    (R/inferCNV_i3HMM.R:180-225).  Returns (states uint8 (C, G), n_underflow int32[1] tensor)."""
+    L = _lib.load()
+    C, G = _check_matrix(x)
+    cs, cp = i32(chr_start)
+    m, mp = f64(means)
+    lp = np.asfortranarray(logPi, dtype=np.float64)
+    ld, ldp = f64(logDelta)
+    if states is None:
+        states = torch.empty((C, G), dtype=torch.uint8, device=x.device)
+    bad = torch.zeros(1, dtype=torch.int32, device=x.device)
+    check(L.icnv_viterbi_cells_dev(_ptr(x), _ptr(states), G, C, cp, cs.size - 1, m.size, mp, float(sd_shared),
+                                   lp.ctypes.data_as(ct.POINTER(ct.c_double)), ldp, _ptr(bad), _stream()))
+    return states, bad
+
+
+def viterbi_groups(x, chr_start, groups, means, sd_shared_per_group, logPi, logDelta, states=None):
+    """predict_CNV_via_HMM_on_tumor_subclusters / _whole_tumor_samples
+    (R/inferCNV_HMM.R:345-408, 509-567; i3: R/inferCNV_i3HMM.R:249-389)."""
+    L = _lib.load()
+    C, G = _check_matrix(x)
+    cs, cp = i32(chr_start)
+    idx, off = pack_groups(groups)
+    idx, ip = i32(idx)
+    off, op = i32(off)
+    m, mp = f64(means)
+    sd, sdp = f64(sd_shared_per_group)
+    lp = np.asfortranarray(logPi, dtype=np.float64)
+    ld, ldp = f64(logDelta)
+    if states is None:
+        states = torch.empty((C, G), dtype=torch.uint8, device=x.device)
+    bad = torch.zeros(1, dtype=torch.int32, device=x.device)
+    check(L.icnv_viterbi_groups_dev(_ptr(x), _ptr(states), G, C, cp, cs.size - 1, ip, op, len(groups), m.size, mp,
+                                    sdp, lp.ctypes.data_as(ct.POINTER(ct.c_double)), ldp, _ptr(bad), _stream()))
+    return states, bad
+
+
+def group_means(x, groups):
+    """rowMeans(expr.data[, group]) per group -> (n_groups, G) tensor."""
+    L = _lib.load()
+    C, G = _check_matrix(x)
+    idx, off = pack_groups(groups)
+    idx, ip = i32(idx)
+    off, op = i32(off)
+    out = torch.empty((len(groups), G), dtype=torch.float64, device=x.device)
+    check(L.icnv_group_means_dev(_ptr(x), G, C, ip, op, len(groups), _ptr(out), _stream()))
+    return out
+
+
+def states_to_proxy(states, K):
+    """assign_HMM_states_to_proxy_expr_vals (R/inferCNV_HMM.R:1191-1206) / i3 (R/inferCNV_i3HMM.R:405-417)."""
+    L = _lib.load()
+    _check_matrix(states, torch.uint8)
+    out = torch.empty(states.shape, dtype=torch.float64, device=states.device)
+    check(L.icnv_states_to_proxy_dev(_ptr(states), _ptr(out), states.numel(), int(K), _stream()))
+    return out
+
+
+def cells_mean_sd(x, cell_idx):
+    """mean and sd over ALL values of the listed cells (R/inferCNV_i3HMM.R:17-80)."""
+    L = _lib.load()
+    C, G = _check_matrix(x)
+    idx, ip = i32(cell_idx)
+    out = (ct.c_double * 2)()
+    check(L.icnv_cells_mean_sd_dev(_ptr(x), G, C, ip, idx.size, out, _stream()))
+    return out[0], out[1]
+
+
+# ------------------------------------------------------------------ median filter
+def median_filter(x, chr_start, tiles, window_size=7, out=None):
+    """apply_median_filtering (R/noise_reduction.R:43-113) on device tensors."""
+    L = _lib.load()
+    C, G = _check_matrix(x)
+    cs, cp = i32(chr_start)
+    idx, off = pack_groups(tiles)
+    idx, ip = i32(idx)
+    off, op = i32(off)
+    if out is None:
+        out = torch.empty_like(x)
+    check(L.icnv_median_filter_dev(_ptr(x), _ptr(out), G, C, cp, cs.size - 1, ip, op, len(tiles), int(window_size),
+                                   _stream()))
+    return out
+
+
+# ------------------------------------------------------------------ timing hooks
+def timing_enable(on=True):
+    _lib.load().icnv_timing_enable(int(bool(on)))
+
+
+def timing_reset():
+    _lib.load().icnv_timing_reset()
+
+
+def timing_get(kernel):
+    ms, n = ct.c_double(), ct.c_int64()
+    check(_lib.load().icnv_timing_get(kernel.encode(), ct.byref(ms), ct.byref(n)))
+    return ms.value, n.value

@@ -1,0 +1,282 @@
+"""Host-side mirror of the reference's HMM predictors (R/inferCNV_HMM.R,
+R/inferCNV_i3HMM.R): same names and argument meaning; parameters are prepared
+on the host exactly as the reference prepares them in R, the Viterbi runs in
+libicnv_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as ct
+import math
+import statistics
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, f64, i32, pack_groups
+from .infercnv_object import InfercnvObject
+
+CNV_LEVELS = ("cnv:0.01", "cnv:0.5", "cnv:1", "cnv:1.5", "cnv:2", "cnv:3")
+
+
+def _get_HMM(cnv_mean_sd, t):
+    """.get_HMM (R/inferCNV_HMM.R:230-265)."""
+    Pi = np.full((6, 6), t, dtype=np.float64)
+    np.fill_diagonal(Pi, 1 - 5 * t)
+    delta = np.array([t, t, 1 - 5 * t, t, t, t], dtype=np.float64)
+    mean = np.array([cnv_mean_sd[k]["mean"] for k in CNV_LEVELS], dtype=np.float64)
+    sd = np.array([cnv_mean_sd[k]["sd"] for k in CNV_LEVELS], dtype=np.float64)
+    return {"state_transitions": Pi, "delta": delta, "state_emission_params": {"mean": mean, "sd": sd}}
+
+
+def _i3HMM_get_HMM(sd_trend, t, i3_p_val=0.05, use_KS=False):
+    """.i3HMM_get_HMM (R/inferCNV_i3HMM.R:99-156): note the 1-5t diagonal with K=3."""
+    Pi = np.full((3, 3), t, dtype=np.float64)
+    np.fill_diagonal(Pi, 1 - 5 * t)
+    delta = np.array([t, 1 - 5 * t, t], dtype=np.float64)
+    mu, sigma = sd_trend["mu"], sd_trend["sigma"]
+    mean_delta = sd_trend["KS_delta"] if use_KS else sd_trend["mean_delta"]
+    return {"state_transitions": Pi, "delta": delta,
+            "state_emission_params": {"mean": np.array([mu - mean_delta, mu, mu + mean_delta]),
+                                      "sd": np.array([sigma, sigma, sigma])}}
+
+
+def determine_mean_delta_via_Z(sigma, p):
+    """R/inferCNV_i3HMM.R:435-445: abs(qnorm(p, 0, sigma))."""
+    return abs(statistics.NormalDist(0.0, sigma).inv_cdf(p))
+
+
+def _log(a):
+    with np.errstate(divide="ignore"):
+        return np.log(np.asarray(a, dtype=np.float64))
+
+
+def _median(v):
+    """stats::median of the sd vector (R/inferCNV_HMM.R:1122)."""
+    v = np.sort(np.asarray(v, dtype=np.float64))
+    n = v.size
+    return float(v[n // 2]) if n % 2 else float((v[n // 2 - 1] + v[n // 2]) * 0.5)
+
+
+def _layout(obj):
+    perm, chr_start = obj.chr_layout()
+    x = np.asfortranarray(obj.expr_data if perm is None else obj.expr_data[perm], dtype=np.float64)
+    return perm, chr_start, x
+
+
+def _unpermute(states, perm):
+    if perm is None:
+        return states
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(perm.size)
+    return states[inv]
+
+
+def Viterbi_dthmm_adj(x, Pi, delta, mean, sd):
+    """Viterbi.dthmm.adj (R/inferCNV_HMM.R:1101-1176) for one observation vector."""
+    x = np.asarray(x, dtype=np.float64).reshape(-1, 1)
+    st = _viterbi_cells(np.asfortranarray(x), np.array([0, x.shape[0]], dtype=np.int32), mean, _median(sd), Pi, delta)
+    return st[:, 0].astype(np.int64)
+
+
+def _viterbi_cells(x, chr_start, mean, sd_shared, Pi, delta):
+    L = _lib.load()
+    G, C = x.shape
+    cs, cp = i32(chr_start)
+    m, mp = f64(mean)
+    lp = np.asfortranarray(_log(Pi))
+    ld, ldp = f64(_log(delta))
+    st = np.empty((G, C), dtype=np.uint8, order="F")
+    check(L.icnv_viterbi_cells(x.ctypes.data_as(ct.c_void_p), st.ctypes.data_as(ct.c_void_p), G, C, cp, cs.size - 1,
+                               m.size, mp, float(sd_shared), lp.ctypes.data_as(ct.POINTER(ct.c_double)), ldp))
+    return st
+
+
+def _viterbi_groups(x, chr_start, groups, mean, sd_per_group, Pi, delta):
+    L = _lib.load()
+    G, C = x.shape
+    cs, cp = i32(chr_start)
+    idx, off = pack_groups(groups)
+    idx, ip = i32(idx)
+    off, op = i32(off)
+    m, mp = f64(mean)
+    sd, sdp = f64(sd_per_group)
+    lp = np.asfortranarray(_log(Pi))
+    ld, ldp = f64(_log(delta))
+    st = np.empty((G, C), dtype=np.uint8, order="F")
+    check(L.icnv_viterbi_groups(x.ctypes.data_as(ct.c_void_p), st.ctypes.data_as(ct.c_void_p), G, C, cp, cs.size - 1,
+                                ip, op, len(groups), m.size, mp, sdp, lp.ctypes.data_as(ct.POINTER(ct.c_double)), ldp))
+    return st
+
+
+def _states_obj(obj, st, perm):
+    """The reference stores states as numeric with -1 for untouched entries
+    (R/inferCNV_HMM.R:294-295)."""
+    out = _unpermute(st, perm).astype(np.float64)
+    out[out == 255] = -1.0
+    new = obj.copy()
+    new.expr_data = out
+    return new
+
+
+# ------------------------------------------------------------------ i6
+def predict_CNV_via_HMM_on_indiv_cells(infercnv_obj: InfercnvObject, cnv_mean_sd, t=1e-6) -> InfercnvObject:
+    """R/inferCNV_HMM.R:284-324.  `cnv_mean_sd` = get_spike_dists(hspike) as a dict
+    {"cnv:0.01": {"mean":, "sd":}, ...} (host-side, R/inferCNV_HMM.R:15-31)."""
+    hmm = _get_HMM(cnv_mean_sd, t)
+    perm, chr_start, x = _layout(infercnv_obj)
+    pm = hmm["state_emission_params"]
+    st = _viterbi_cells(x, chr_start, pm["mean"], _median(pm["sd"]), hmm["state_transitions"], hmm["delta"])
+    return _states_obj(infercnv_obj, st, perm)
+
+
+def _group_sd(num_cells, cnv_mean_sd, cnv_level_to_mean_sd_fit):
+    """.get_state_emission_params (R/inferCNV_HMM.R:586-614): sd_k =
+    exp(predict(lm(log(sd) ~ log(num_cells)))).  `fit[level]` = (intercept, slope)
+    of that lm (the RNG-driven fit itself stays on the host, :154-212)."""
+    sds = []
+    for k in CNV_LEVELS:
+        if cnv_level_to_mean_sd_fit is None:
+            sds.append(cnv_mean_sd[k]["sd"])
+        else:
+            b0, b1 = cnv_level_to_mean_sd_fit[k]
+            sds.append(math.exp(b0 + b1 * math.log(num_cells)))
+    return _median(sds)
+
+
+def _predict_groups_i6(obj, groups, cnv_mean_sd, fit, t):
+    hmm = _get_HMM(cnv_mean_sd, t)
+    perm, chr_start, x = _layout(obj)
+    sd = [_group_sd(len(g), cnv_mean_sd, fit) for g in groups]
+    st = _viterbi_groups(x, chr_start, groups, hmm["state_emission_params"]["mean"], sd,
+                         hmm["state_transitions"], hmm["delta"])
+    return _states_obj(obj, st, perm)
+
+
+def _flatten_subclusters(obj):
+    """unlist(tumor_subclusters[["subclusters"]], recursive=FALSE) (R/inferCNV_HMM.R:371)."""
+    out = []
+    for grp in obj.tumor_subclusters["subclusters"].values():
+        for idx in grp.values():
+            out.append(np.asarray(idx, dtype=np.int32))
+    return out
+
+
+def _whole_sample_groups(obj, cluster_by_groups):
+    """R/inferCNV_HMM.R:529-533."""
+    if cluster_by_groups:
+        groups = list(obj.observation_grouped_cell_indices.values())
+    else:
+        groups = [np.concatenate([np.asarray(v) for v in obj.observation_grouped_cell_indices.values()])]
+    groups += list(obj.reference_grouped_cell_indices.values())
+    return [np.asarray(g, dtype=np.int32) for g in groups]
+
+
+def predict_CNV_via_HMM_on_whole_tumor_samples(infercnv_obj, cluster_by_groups, cnv_mean_sd,
+                                               cnv_level_to_mean_sd_fit=None, t=1e-6):
+    """R/inferCNV_HMM.R:509-567."""
+    return _predict_groups_i6(infercnv_obj, _whole_sample_groups(infercnv_obj, cluster_by_groups), cnv_mean_sd,
+                              cnv_level_to_mean_sd_fit, t)
+
+
+def predict_CNV_via_HMM_on_tumor_subclusters(infercnv_obj, cnv_mean_sd, cnv_level_to_mean_sd_fit=None, t=1e-6):
+    """R/inferCNV_HMM.R:345-408 (falls back to whole samples when no subclusters, :358-361)."""
+    if infercnv_obj.tumor_subclusters is None:
+        return predict_CNV_via_HMM_on_whole_tumor_samples(infercnv_obj, True, cnv_mean_sd, cnv_level_to_mean_sd_fit, t)
+    return _predict_groups_i6(infercnv_obj, _flatten_subclusters(infercnv_obj), cnv_mean_sd,
+                              cnv_level_to_mean_sd_fit, t)
+
+
+def predict_CNV_via_HMM_on_tumor_subclusters_per_chr(infercnv_obj, cnv_mean_sd, cnv_level_to_mean_sd_fit=None,
+                                                     t=1e-6):
+    """R/inferCNV_HMM.R:412-487: subclusters are defined per chromosome
+    (tumor_subclusters$subclusters[[chr]][[group]][[name]]); one device call per
+    chromosome.  (The reference's region-consensus post-processing :473-483 is
+    report-side and not part of the hot path.)"""
+    if infercnv_obj.tumor_subclusters is None:
+        return predict_CNV_via_HMM_on_whole_tumor_samples(infercnv_obj, True, cnv_mean_sd, cnv_level_to_mean_sd_fit, t)
+    hmm = _get_HMM(cnv_mean_sd, t)
+    chrs = np.asarray(infercnv_obj.gene_order.chr)
+    out = np.full(infercnv_obj.expr_data.shape, -1.0)
+    for chr_name, per_chr in infercnv_obj.tumor_subclusters["subclusters"].items():
+        rows = np.nonzero(chrs == chr_name)[0]
+        if rows.size == 0:
+            continue
+        groups = [np.asarray(idx, dtype=np.int32) for grp in per_chr.values() for idx in grp.values()]
+        x = np.asfortranarray(infercnv_obj.expr_data[rows], dtype=np.float64)
+        sd = [_group_sd(len(g), cnv_mean_sd, cnv_level_to_mean_sd_fit) for g in groups]
+        st = _viterbi_groups(x, np.array([0, rows.size], dtype=np.int32), groups,
+                             hmm["state_emission_params"]["mean"], sd, hmm["state_transitions"], hmm["delta"])
+        st = st.astype(np.float64)
+        st[st == 255] = -1.0
+        out[rows] = st
+    new = infercnv_obj.copy()
+    new.expr_data = out
+    return new
+
+
+def assign_HMM_states_to_proxy_expr_vals(infercnv_obj: InfercnvObject) -> InfercnvObject:
+    """R/inferCNV_HMM.R:1191-1206."""
+    return _proxy(infercnv_obj, 6)
+
+
+# ------------------------------------------------------------------ i3
+def i3HMM_get_sd_trend(infercnv_obj: InfercnvObject, i3_p_val=0.05):
+    """mu / sigma / mean_delta of .i3HMM_get_sd_trend_by_num_cells_fit
+    (R/inferCNV_i3HMM.R:17-80; the KS delta is RNG-driven and stays host-side)."""
+    idx = (infercnv_obj.get_reference_grouped_cell_indices() if infercnv_obj.has_reference_cells()
+           else np.concatenate([np.asarray(v) for v in infercnv_obj.observation_grouped_cell_indices.values()]))
+    vals = np.asarray(infercnv_obj.expr_data)[:, idx].astype(np.float64).ravel()
+    mu = float(np.mean(vals))
+    sigma = float(np.std(vals, ddof=1))
+    return {"mu": mu, "sigma": sigma, "mean_delta": determine_mean_delta_via_Z(sigma, i3_p_val), "KS_delta": None}
+
+
+def i3HMM_predict_CNV_via_HMM_on_indiv_cells(infercnv_obj, i3_p_val=0.05, sd_trend=None, t=1e-6, use_KS=False):
+    """R/inferCNV_i3HMM.R:180-225."""
+    sd_trend = sd_trend or i3HMM_get_sd_trend(infercnv_obj, i3_p_val)
+    hmm = _i3HMM_get_HMM(sd_trend, t, i3_p_val, use_KS)
+    perm, chr_start, x = _layout(infercnv_obj)
+    pm = hmm["state_emission_params"]
+    st = _viterbi_cells(x, chr_start, pm["mean"], _median(pm["sd"]), hmm["state_transitions"], hmm["delta"])
+    return _states_obj(infercnv_obj, st, perm)
+
+
+def _predict_groups_i3(obj, groups, i3_p_val, sd_trend, t, use_KS):
+    sd_trend = sd_trend or i3HMM_get_sd_trend(obj, i3_p_val)
+    hmm = _i3HMM_get_HMM(sd_trend, t, i3_p_val, use_KS)
+    perm, chr_start, x = _layout(obj)
+    pm = hmm["state_emission_params"]
+    st = _viterbi_groups(x, chr_start, groups, pm["mean"], [_median(pm["sd"])] * len(groups),
+                         hmm["state_transitions"], hmm["delta"])
+    return _states_obj(obj, st, perm)
+
+
+def i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples(infercnv_obj, cluster_by_groups, i3_p_val=0.05, sd_trend=None,
+                                                     t=1e-6, use_KS=False):
+    """R/inferCNV_i3HMM.R:332-389."""
+    return _predict_groups_i3(infercnv_obj, _whole_sample_groups(infercnv_obj, cluster_by_groups), i3_p_val, sd_trend,
+                              t, use_KS)
+
+
+def i3HMM_predict_CNV_via_HMM_on_tumor_subclusters(infercnv_obj, i3_p_val=0.05, sd_trend=None, t=1e-6, use_KS=False):
+    """R/inferCNV_i3HMM.R:249-308."""
+    if infercnv_obj.tumor_subclusters is None:
+        return i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples(infercnv_obj, True, i3_p_val, sd_trend, t, use_KS)
+    return _predict_groups_i3(infercnv_obj, _flatten_subclusters(infercnv_obj), i3_p_val, sd_trend, t, use_KS)
+
+
+def i3HMM_assign_HMM_states_to_proxy_expr_vals(infercnv_obj: InfercnvObject) -> InfercnvObject:
+    """R/inferCNV_i3HMM.R:405-417."""
+    return _proxy(infercnv_obj, 3)
+
+
+def _proxy(obj, K):
+    L = _lib.load()
+    st = np.asfortranarray(np.where(obj.expr_data < 0, 255, obj.expr_data).astype(np.uint8))
+    out = np.empty(st.shape, dtype=np.float64, order="F")
+    check(L.icnv_states_to_proxy(st.ctypes.data_as(ct.c_void_p), out.ctypes.data_as(ct.c_void_p), st.size, K))
+    # entries that were not HMM states (e.g. -1) stay as they were, like R's masked assignment
+    out = np.where(np.isnan(out), obj.expr_data, out)
+    new = obj.copy()
+    new.expr_data = out
+    return new

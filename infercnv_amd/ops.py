@@ -1,0 +1,171 @@
+"""Host-side mirror of the reference's smoothing-chain step functions
+(R/inferCNV_ops.R), same names / argument meaning / error behaviour, each one a
+thin call into libicnv_hip.so.  Every function takes an InfercnvObject and
+returns a new InfercnvObject whose `expr_data` was replaced -- and mirrors
+itself onto `hspike` where the reference does.
+
+These wrappers take host (numpy) matrices, like the R shim would hand over
+`expr.data`; use `infercnv_amd.device` for device-resident tensors.
+"""
+from __future__ import annotations
+
+import ctypes as ct
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import Cfg, check
+from .infercnv_object import InfercnvObject
+
+
+def _as_f(a):
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+def _run_chain(obj: InfercnvObject, stage_mask, *, window_length=101, max_thresh=None, use_bounds=True,
+               sd_amplifier=1.5, noise_filter=None, want_pre_denoise=False):
+    L = _lib.load()
+    perm, chr_start = obj.chr_layout()
+    x = _as_f(obj.expr_data if perm is None else obj.expr_data[perm])
+    G, C = x.shape
+    cfg = Cfg(G, C, chr_start, obj.ref_groups_or_proxy(), window_length, max_thresh, use_bounds, sd_amplifier,
+              noise_filter, stage_mask)
+    out = np.empty_like(x, order="F")
+    pre = np.empty_like(x, order="F") if want_pre_denoise else None
+    check(L.icnv_smooth_chain(x.ctypes.data_as(ct.c_void_p), out.ctypes.data_as(ct.c_void_p),
+                              pre.ctypes.data_as(ct.c_void_p) if pre is not None else None, cfg.ptr()))
+    if perm is not None:
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(perm.size)
+        out = out[inv]
+        pre = pre[inv] if pre is not None else None
+    return out, pre
+
+
+def _with_expr(obj, expr, hspike=None):
+    new = obj.copy()
+    new.expr_data = expr
+    if hspike is not None:
+        new.hspike = hspike
+    return new
+
+
+# ------------------------------------------------------------------ step 8 / 12
+def subtract_ref_expr_from_obs(infercnv_obj: InfercnvObject, inv_log=False, use_bounds=True) -> InfercnvObject:
+    """R/inferCNV_ops.R:1678-1702.  `inv_log=TRUE` (not used by run()) is not
+    offered by the kernels and raises, rather than silently computing something else."""
+    if inv_log:
+        raise NotImplementedError("inv_log=TRUE is not part of the run() path (R/inferCNV_ops.R:771,952 use FALSE)")
+    out, _ = _run_chain(infercnv_obj, _lib.ST_SUBTRACT_REF_1, use_bounds=use_bounds)
+    hs = None
+    if infercnv_obj.hspike is not None:  # :1695-1698
+        hs = subtract_ref_expr_from_obs(infercnv_obj.hspike, inv_log=inv_log, use_bounds=use_bounds)
+    return _with_expr(infercnv_obj, out, hs)
+
+
+# ------------------------------------------------------------------ step 9
+def get_average_bounds(infercnv_obj: InfercnvObject):
+    """R/inferCNV_ops.R:2723-2742 -> (lower, upper)."""
+    L = _lib.load()
+    x = _as_f(infercnv_obj.expr_data)
+    out = (ct.c_double * 2)()
+    check(L.icnv_average_bounds(x.ctypes.data_as(ct.c_void_p), x.shape[0], x.shape[1], out))
+    return out[0], out[1]
+
+
+def apply_max_threshold_bounds(infercnv_obj: InfercnvObject, threshold) -> InfercnvObject:
+    """R/inferCNV_ops.R:2970-2983; threshold may be "auto" like run()'s
+    max_centered_threshold (:802-817: mean(abs(get_average_bounds())))."""
+    if isinstance(threshold, str):
+        if threshold != "auto":
+            raise ValueError('threshold must be numeric or "auto"')
+        lo, hi = get_average_bounds(infercnv_obj)
+        threshold = (abs(lo) + abs(hi)) / 2.0
+    out, _ = _run_chain(infercnv_obj, _lib.ST_MAX_THRESH, max_thresh=float(threshold))
+    hs = None
+    if infercnv_obj.hspike is not None:  # :2977-2980
+        hs = apply_max_threshold_bounds(infercnv_obj.hspike, threshold)
+    return _with_expr(infercnv_obj, out, hs)
+
+
+# ------------------------------------------------------------------ step 10
+def smooth_by_chromosome(infercnv_obj: InfercnvObject, window_length, smooth_ends=True) -> InfercnvObject:
+    """R/inferCNV_ops.R:2406-2434 (pyramid weights, ends renormalised).  Like the
+    reference, window_length < 2 returns the data unchanged (:2444-2447)."""
+    if window_length >= 2 and int(window_length) % 2 == 0:
+        raise ValueError("window_length must be odd")
+    out, _ = _run_chain(infercnv_obj, _lib.ST_SMOOTH, window_length=int(window_length))
+    hs = None
+    if infercnv_obj.hspike is not None:  # :2427-2430
+        hs = smooth_by_chromosome(infercnv_obj.hspike, window_length, smooth_ends)
+    return _with_expr(infercnv_obj, out, hs)
+
+
+# ------------------------------------------------------------------ step 11
+def center_cell_expr_across_chromosome(infercnv_obj: InfercnvObject, method="mean") -> InfercnvObject:
+    """R/inferCNV_ops.R:2074-2088; method "median" (what run() passes, :911) or "mean"."""
+    mask = _lib.ST_CENTER | (0 if method == "median" else _lib.ST_CENTER_MEAN)
+    out, _ = _run_chain(infercnv_obj, mask)
+    hs = None
+    if infercnv_obj.hspike is not None:  # :2081-2084
+        hs = center_cell_expr_across_chromosome(infercnv_obj.hspike, method)
+    return _with_expr(infercnv_obj, out, hs)
+
+
+# ------------------------------------------------------------------ step 14
+def invert_log2(infercnv_obj: InfercnvObject) -> InfercnvObject:
+    """R/inferCNV_ops.R:2814-2826."""
+    out, _ = _run_chain(infercnv_obj, _lib.ST_INVERT_LOG2)
+    hs = invert_log2(infercnv_obj.hspike) if infercnv_obj.hspike is not None else None
+    return _with_expr(infercnv_obj, out, hs)
+
+
+# ------------------------------------------------------------------ step 22
+def clear_noise_via_ref_mean_sd(infercnv_obj: InfercnvObject, sd_amplifier=1.5, noise_logistic=False) -> InfercnvObject:
+    """R/inferCNV_ops.R:2302-2346.  hspike is NOT mirrored (commented out in the reference, :2340-2343)."""
+    if noise_logistic:
+        raise NotImplementedError("noise_logistic=TRUE lives in the plotting code (R/inferCNV_heatmap.R:2783-2810)")
+    out, _ = _run_chain(infercnv_obj, _lib.ST_DENOISE, sd_amplifier=sd_amplifier)
+    return _with_expr(infercnv_obj, out)
+
+
+def clear_noise(infercnv_obj: InfercnvObject, threshold, noise_logistic=False) -> InfercnvObject:
+    """R/inferCNV_ops.R:2232-2262 (threshold == 0 -> unchanged)."""
+    if noise_logistic:
+        raise NotImplementedError("noise_logistic=TRUE lives in the plotting code (R/inferCNV_heatmap.R:2783-2810)")
+    if threshold == 0:
+        return infercnv_obj
+    out, _ = _run_chain(infercnv_obj, _lib.ST_DENOISE, noise_filter=float(threshold))
+    return _with_expr(infercnv_obj, out)
+
+
+# ------------------------------------------------------------------ fused entry
+def hip_smooth_chain(infercnv_obj: InfercnvObject, window_length=101, max_centered_threshold=3.0,
+                     sd_amplifier=1.5, noise_filter=None, denoise=True, return_hmm_input=False):
+    """Steps 8,9,10,11,12,14(,22) of run() back to back in one fused device pass
+    (SURVEY.md 8b.1).  Equivalent to calling the stand-alone wrappers in run()'s
+    order.  With return_hmm_input=True also returns the object before step 22
+    (what step 17's HMM reads, R/inferCNV_ops.R:1237-1309)."""
+    thr = max_centered_threshold
+    mask = _lib.ST_ALL if denoise else (_lib.ST_ALL & ~_lib.ST_DENOISE)
+    if isinstance(thr, str):
+        if thr != "auto":
+            raise ValueError('max_centered_threshold must be numeric, NA/None or "auto"')
+        tmp_obj = infercnv_obj.copy()
+        tmp_obj.hspike = None
+        lo, hi = get_average_bounds(subtract_ref_expr_from_obs(tmp_obj))   # R/inferCNV_ops.R:802-806
+        thr = (abs(lo) + abs(hi)) / 2.0
+    if thr is None or (isinstance(thr, float) and math.isnan(thr)):
+        mask &= ~_lib.ST_MAX_THRESH
+        thr = None
+    out, pre = _run_chain(infercnv_obj, mask, window_length=window_length, max_thresh=thr,
+                          sd_amplifier=sd_amplifier, noise_filter=noise_filter, want_pre_denoise=return_hmm_input)
+    hs = None
+    if infercnv_obj.hspike is not None:
+        # the hspike mirrors steps 8..14 but not the denoise (reference: commented out)
+        hs = hip_smooth_chain(infercnv_obj.hspike, window_length, thr, sd_amplifier, noise_filter, denoise=False)
+    res = _with_expr(infercnv_obj, out, hs)
+    if return_hmm_input:
+        return res, _with_expr(infercnv_obj, pre if denoise else out, hs)
+    return res

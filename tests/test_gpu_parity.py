@@ -1,0 +1,397 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI of
+libicnv_hip.so, against the CPU oracle on identical seeded inputs, against the
+reference's golden object, and -- at BASELINE.json's full size -- through
+size-independent properties.
+
+Tolerances (stated by BASELINE.json's north_star):
+  * smoothing chain: 1e-5 relative.  We assert far tighter absolute bounds
+    (1e-10 .. 1e-12) because everything is computed in fp64.
+  * HMM state calls: bit-exact on identical inputs.
+  * median filter: exact (order statistics + one average).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import oracle_c as oc  # noqa: E402
+import oracle_np as onp  # noqa: E402
+
+RTOL_NORTH_STAR = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from infercnv_amd import device
+    torch.cuda.set_device(0)
+    device.init(0)
+    return device
+
+
+def to_dev(x_gc):
+    """(G, C) host matrix -> (C, G) contiguous CUDA tensor (same bytes as R's column-major G x C)."""
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x_gc, dtype=np.float64).T)).cuda()
+
+
+def to_host(t_cg):
+    return t_cg.cpu().numpy().T
+
+
+def rel_err(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def example(golden_dir):
+    d = np.load(os.path.join(golden_dir, "infercnv_object_example.npz"))
+    ex = {k: d[k] for k in d.files}
+    ex["log"] = onp.log2xplus1(onp.normalize_counts_by_seq_depth(ex["count_data"]))
+    ex["chr_start"] = oc.chr_starts_from_codes(ex["chr_codes"])
+    return ex
+
+
+# ------------------------------------------------------------------ smoothing chain
+def test_chain_reproduces_reference_golden_object(dev, example):
+    """HIP chain on the reference's own example: @count.data -> @expr.data."""
+    out, pre = dev.smooth_chain(to_dev(example["log"]), example["chr_start"], [example["ref_normal"]],
+                                want_pre_denoise=True)
+    got = to_host(out)
+    gold = example["expr_data"]
+    # denoise is a strict-threshold select: an element within rounding of the bound may flip
+    bad = np.abs(got - gold) > 1e-10
+    assert bad.mean() < 1e-4
+    ref_out, ref_pre, _ = oc.smooth_chain(example["log"], example["chr_start"], [example["ref_normal"]],
+                                          want_pre_denoise=True)
+    assert rel_err(to_host(pre), ref_pre) < RTOL_NORTH_STAR
+    assert np.abs(to_host(pre) - ref_pre).max() < 1e-12
+
+
+@pytest.mark.parametrize("G,C,nref", [(10000, 160, 2), (4613, 70, 1), (9999, 67, 3), (301, 33, 2), (37, 9, 1)])
+def test_chain_fused_vs_oracle(dev, G, C, nref):
+    from infercnv_amd import synth
+    x, cs = synth.make_matrix_np(G, C)
+    rng = np.random.default_rng(G)
+    perm = rng.permutation(C)
+    n_ref = max(nref, C // 5)
+    cuts = np.linspace(0, n_ref, nref + 1).astype(int)
+    refs = [perm[cuts[i]:cuts[i + 1]].astype(np.int32) for i in range(nref)]   # unsorted, non-contiguous
+    out, pre = dev.smooth_chain(to_dev(x), cs, refs, want_pre_denoise=True)
+    ref_out, ref_pre, (mu, s) = oc.smooth_chain(x, cs, refs, want_pre_denoise=True)
+    assert rel_err(to_host(pre), ref_pre) < RTOL_NORTH_STAR
+    assert np.abs(to_host(pre) - ref_pre).max() < 1e-11
+    got = to_host(out)
+    flips = np.abs(got - ref_out) > 1e-11
+    assert flips.mean() < 1e-4          # only threshold-edge elements of the denoise select may differ
+    assert np.isin(got[flips], [mu]).all() or np.isin(ref_out[flips], [mu]).all()
+
+
+STAGES = {"st8": 0x01, "st9": 0x02, "st10": 0x04, "st11": 0x08, "st12": 0x10, "st14": 0x20, "st22": 0x40,
+          "st11mean": 0x88}
+
+
+@pytest.mark.parametrize("stage", list(STAGES))
+def test_chain_each_stage_standalone(dev, stage):
+    """Every R-level wrapper is a single-bit stage_mask call (run(up_to_step=), resume)."""
+    from infercnv_amd import synth
+    G, C = 3001, 48          # odd G -> scalar-vector path
+    x, cs = synth.make_matrix_np(G, C)
+    x = x - 2.0
+    refs = [np.arange(0, 5, dtype=np.int32), np.arange(5, 9, dtype=np.int32)]
+    mask = STAGES[stage]
+    out, _ = dev.smooth_chain(to_dev(x), cs, refs, window_length=101, max_thresh=1.25, stage_mask=mask)
+    got = to_host(out)
+    if stage in ("st8", "st12"):
+        want = oc.subtract_ref_expr_from_obs(x, refs)
+    elif stage == "st9":
+        want = oc.apply_max_threshold_bounds(x, 1.25)
+    elif stage == "st10":
+        want = oc.smooth_by_chromosome(x, cs, 101)
+    elif stage == "st11":
+        want = oc.center_columns(x, "median")
+    elif stage == "st11mean":
+        want = oc.center_columns(x, "mean")
+    elif stage == "st14":
+        want = oc.invert_log2(x)
+    else:
+        mu, s = oc.denoise_params(x, np.concatenate(refs), 1.5)
+        want = oc.denoise_apply(x, mu, s)
+    assert np.abs(got - want).max() < 1e-11 * max(1.0, np.abs(want).max())
+
+
+def test_chain_options(dev):
+    """use_bounds=FALSE, no threshold, short / long / no window, fixed-threshold denoise, no denoise."""
+    from infercnv_amd import synth
+    G, C = 2500, 40
+    x, cs = synth.make_matrix_np(G, C)
+    refs = [np.arange(0, 6, dtype=np.int32)]
+    xd = to_dev(x)
+    for kw in ({"use_bounds": False}, {"max_thresh": None}, {"window_length": 3}, {"window_length": 5001},
+               {"window_length": 1}, {"noise_filter": 0.1}, {"noise_filter": 0.0}, {"stage_mask": 0x3F}):
+        out, _ = dev.smooth_chain(xd, cs, refs, **kw)
+        okw = dict(kw)
+        if "noise_filter" in okw and okw["noise_filter"] is not None:
+            okw["noise_filter"] = float(okw["noise_filter"])
+        want, _, _ = oc.smooth_chain(x, cs, refs, **okw)
+        got = to_host(out)
+        flips = np.abs(got - want) > 1e-11
+        assert flips.mean() < 1e-3, kw
+
+
+def test_chain_median_edge_cases(dev):
+    """Median select: ties, all-equal, many exact zeros, even/odd G, heavy outliers."""
+    rng = np.random.default_rng(7)
+    for G in (2, 3, 64, 1001, 4096):
+        cols = [np.zeros(G), np.ones(G) * 3.5, rng.normal(size=G), np.round(rng.normal(size=G), 1),
+                np.where(rng.random(G) < 0.7, 0.0, rng.normal(size=G)), rng.normal(size=G) * 1e-300,
+                np.concatenate([rng.normal(size=G - 1), [1e300]]), np.arange(G, dtype=float)]
+        x = np.stack(cols, axis=1)
+        cs = np.array([0, G], dtype=np.int32)
+        out, _ = dev.smooth_chain(to_dev(x), cs, [np.array([0], dtype=np.int32)], stage_mask=0x08)
+        want = onp.center_columns(x, "median")
+        np.testing.assert_array_equal(to_host(out), want)
+
+
+def test_chain_no_reference_cells_uses_all_observations(dev):
+    """R/inferCNV_ops.R:1686-1688: without references all cells form one proxy group (host mirror)."""
+    from infercnv_amd import GeneOrder, InfercnvObject, ops, synth
+    G, C = 1200, 24
+    x, cs = synth.make_matrix_np(G, C)
+    chr_names = np.repeat(np.array([f"chr{i + 1}" for i in range(len(cs) - 1)]), np.diff(cs))
+    obj = InfercnvObject(expr_data=x, gene_order=GeneOrder(chr=chr_names),
+                         observation_grouped_cell_indices={"a": np.arange(0, 10), "b": np.arange(10, C)})
+    got = ops.subtract_ref_expr_from_obs(obj).expr_data
+    want = oc.subtract_ref_expr_from_obs(x, [np.arange(C, dtype=np.int32)])
+    assert np.abs(got - want).max() < 1e-12
+
+
+# ------------------------------------------------------------------ HMM
+def _hmm_input(G, C, seed=0):
+    from infercnv_amd import synth
+    x, cs = synth.make_matrix_np(G, C, seed=synth.SEED + seed)
+    refs, _ = synth.groups(C)
+    _, pre, _ = oc.smooth_chain(x, cs, refs, want_pre_denoise=True)
+    return pre, cs
+
+
+@pytest.mark.parametrize("G,C", [(10000, 130), (4613, 64), (1003, 65), (257, 7)])
+def test_viterbi_cells_i6_bit_exact(dev, G, C):
+    from infercnv_amd import synth
+    pre, cs = _hmm_input(G, C, seed=G)
+    means, sd, logPi, logDelta = synth.hmm_params_i6()
+    st, bad = dev.viterbi_cells(to_dev(pre), cs, means, sd, logPi, logDelta)
+    want, wbad = oc.viterbi_cells(pre, cs, means, sd, logPi, logDelta)
+    assert int(bad.item()) == 0 and wbad == 0
+    np.testing.assert_array_equal(to_host(st), want)
+    assert len(np.unique(want)) >= 3
+
+
+def test_viterbi_adversarial_near_ties_bit_exact(dev):
+    """Inputs sitting on emission-branch boundaries and state mid-points, 1-gene and 2-gene chromosomes."""
+    from infercnv_amd import synth
+    means, sd, logPi, logDelta = synth.hmm_params_i6()
+    rng = np.random.default_rng(5)
+    sizes = [1, 2, 3, 700, 1, 64, 129, 100]
+    G, C = sum(sizes), 192
+    cs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    mids = (means[:-1] + means[1:]) / 2
+    pool = np.concatenate([means, mids, means + 0.67448975 * sd, means - 0.67448975 * sd,
+                           means + 5.656854249492380 * sd, [0.0, 1.0, 10.0, -3.0, 1e-300]])
+    x = rng.choice(pool, size=(G, C)) + rng.choice([0.0, 1e-16, -1e-16, 1e-12, 1e-9], size=(G, C))
+    x[:, :32] = rng.normal(1.0, 0.15, size=(G, 32))
+    for t in (1e-6, 1e-2, 0.1):
+        Pi, delta = onp.get_HMM_i6(t)
+        st, _ = dev.viterbi_cells(to_dev(x), cs, means, sd, np.log(Pi), np.log(delta))
+        want, _ = oc.viterbi_cells(x, cs, means, sd, np.log(Pi), np.log(delta))
+        np.testing.assert_array_equal(to_host(st), want)
+    # asymmetric (non-uniform) transition matrix exercises every back-pointer value
+    Pi = rng.dirichlet(np.ones(6), size=6)
+    delta = rng.dirichlet(np.ones(6))
+    st, _ = dev.viterbi_cells(to_dev(x), cs, means, sd, np.log(Pi), np.log(delta))
+    want, _ = oc.viterbi_cells(x, cs, means, sd, np.log(Pi), np.log(delta))
+    np.testing.assert_array_equal(to_host(st), want)
+
+
+def test_viterbi_i3_bit_exact(dev):
+    pre, cs = _hmm_input(3000, 100, seed=3)
+    refs = np.arange(10, dtype=np.int32)
+    mu, sigma = oc.mean_sd_of_cells(pre, refs)
+    gmu, gsigma = dev.cells_mean_sd(to_dev(pre), refs)
+    assert abs(gmu - mu) < 1e-13 and abs(gsigma - sigma) < 1e-13
+    delta_m = abs(-1.6448536269514722 * sigma)
+    m3 = np.array([mu - delta_m, mu, mu + delta_m])
+    Pi, delta = onp.get_HMM_i3(1e-6)
+    st, _ = dev.viterbi_cells(to_dev(pre), cs, m3, sigma, np.log(Pi), np.log(delta))
+    want, _ = oc.viterbi_cells(pre, cs, m3, sigma, np.log(Pi), np.log(delta))
+    np.testing.assert_array_equal(to_host(st), want)
+
+
+def test_viterbi_groups_and_broadcast(dev):
+    from infercnv_amd import synth
+    pre, cs = _hmm_input(4000, 150, seed=9)
+    rng = np.random.default_rng(1)
+    perm = rng.permutation(150)
+    groups = [perm[:40], perm[40:41], perm[41:120]]          # cells 120.. are in no group
+    means, _, logPi, logDelta = synth.hmm_params_i6()
+    sds = [0.08, 0.17, 0.05]
+    xd = to_dev(pre)
+    st, bad = dev.viterbi_groups(xd, cs, groups, means, sds, logPi, logDelta)
+    gm = dev.group_means(xd, groups).cpu().numpy().T          # (G, n_groups)
+    assert np.abs(gm - oc.group_means(pre, groups)).max() < 1e-14
+    got = to_host(st)
+    for q, g in enumerate(groups):
+        # identical inputs (the GPU's own group means) -> bit-exact trace, broadcast to every member
+        want, _ = oc.viterbi_cells(gm[:, q:q + 1], cs, means, sds[q], logPi, logDelta)
+        for c in g:
+            np.testing.assert_array_equal(got[:, c], want[:, 0])
+    assert (got[:, perm[120:]] == 255).all()
+    full, _ = oc.viterbi_groups(pre, cs, groups, means, sds, logPi, logDelta)
+    assert (got == full).mean() > 0.9999
+    proxy = dev.states_to_proxy(st, 6)
+    member = np.concatenate(groups)
+    np.testing.assert_array_equal(to_host(proxy)[:, member], oc.states_to_proxy(full, 6)[:, member])
+
+
+def test_underflow_is_reported(dev):
+    """-Inf in the last nu row -> the reference stop()s (R/inferCNV_HMM.R:1165); we return ICNV_ERR_UNDERFLOW."""
+    from infercnv_amd import IcnvError, hmm
+    x = np.ones(20)
+    Pi = np.full((6, 6), 1e-6)
+    np.fill_diagonal(Pi, 1 - 5e-6)
+    delta = np.zeros(6)                      # log(0) = -Inf everywhere
+    with pytest.raises(IcnvError) as e:
+        hmm.Viterbi_dthmm_adj(x, Pi, delta, np.linspace(0.4, 1.4, 6), np.full(6, 0.2))
+    assert e.value.code == 4
+
+
+# ------------------------------------------------------------------ median filter
+def test_median_filter_exact(dev):
+    rng = np.random.default_rng(4)
+    sizes = [40, 1, 7, 95, 9]
+    G, C = sum(sizes), 61
+    cs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    x = rng.normal(size=(G, C))
+    x[5:9, :] = 0.0
+    perm = rng.permutation(C)
+    tiles = [perm[:23], perm[23:24], perm[24:33], perm[33:55]]   # cells 55.. in no tile: copied through
+    for w in (3, 7, 9):
+        out = dev.median_filter(to_dev(x), cs, tiles, w)
+        want = oc.median_filter(x, cs, tiles, w)
+        np.testing.assert_array_equal(to_host(out), want)
+
+
+# ------------------------------------------------------------------ host mirror == device path == oracle
+def test_host_mirror_runs_reference_workflow(dev, example):
+    from infercnv_amd import GeneOrder, InfercnvObject, hmm, noise_reduction, ops
+    levels = example["chr_levels"][example["chr_codes"]]
+    obj = InfercnvObject(expr_data=example["log"], gene_order=GeneOrder(chr=levels),
+                         reference_grouped_cell_indices={"normal": example["ref_normal"]},
+                         observation_grouped_cell_indices={"tumor": example["obs_tumor"]},
+                         tumor_subclusters={"subclusters": {"tumor": {"tumor_s1": example["obs_tumor"]},
+                                                            "normal": {"normal_s1": example["ref_normal"]}}})
+    # run()'s order, one wrapper per step (R/inferCNV_ops.R:771-1031, 1573)
+    o = ops.subtract_ref_expr_from_obs(obj)
+    o = ops.apply_max_threshold_bounds(o, 3)
+    o = ops.smooth_by_chromosome(o, 101)
+    o = ops.center_cell_expr_across_chromosome(o, "median")
+    o = ops.subtract_ref_expr_from_obs(o)
+    o14 = ops.invert_log2(o)
+    o22 = ops.clear_noise_via_ref_mean_sd(o14, 1.5)
+    assert (np.abs(o22.expr_data - example["expr_data"]) > 1e-10).mean() < 1e-4
+    fused, hmm_in = ops.hip_smooth_chain(obj, return_hmm_input=True)
+    assert np.abs(hmm_in.expr_data - o14.expr_data).max() < 1e-12
+    assert (np.abs(fused.expr_data - o22.expr_data) > 1e-12).mean() < 1e-4
+    # i6 HMM on whole samples + proxy values + median filter
+    cnv = {k: {"mean": m, "sd": 0.2} for k, m in zip(hmm.CNV_LEVELS, [0.41, 0.84, 1.017, 1.12, 1.24, 1.44])}
+    h = hmm.predict_CNV_via_HMM_on_whole_tumor_samples(hmm_in, True, cnv)
+    want, _ = oc.viterbi_groups(hmm_in.expr_data, example["chr_start"], [example["obs_tumor"], example["ref_normal"]],
+                                [cnv[k]["mean"] for k in hmm.CNV_LEVELS], [0.2, 0.2], np.log(onp.get_HMM_i6()[0]),
+                                np.log(onp.get_HMM_i6()[1]))
+    assert (h.expr_data == want).mean() > 0.9999
+    p = hmm.assign_HMM_states_to_proxy_expr_vals(h)
+    assert set(np.unique(p.expr_data)) <= {0.0, 0.5, 1.0, 1.5, 2.0, 3.0}
+    hc = hmm.predict_CNV_via_HMM_on_indiv_cells(hmm_in, cnv)
+    wc, _ = oc.viterbi_cells(hmm_in.expr_data, example["chr_start"], [cnv[k]["mean"] for k in hmm.CNV_LEVELS], 0.2,
+                             np.log(onp.get_HMM_i6()[0]), np.log(onp.get_HMM_i6()[1]))
+    np.testing.assert_array_equal(hc.expr_data, wc)
+    mf = noise_reduction.apply_median_filtering(fused)
+    wmf = oc.median_filter(fused.expr_data, example["chr_start"], [example["obs_tumor"], example["ref_normal"]], 7)
+    np.testing.assert_array_equal(mf.expr_data, wmf)
+
+
+def test_split_phase_equals_one_call(dev):
+    """The multi-GPU split-phase API on one rank must equal the one-call form, and
+    two 'ranks' emulated on one GPU (partials summed by hand) must equal it too."""
+    from infercnv_amd import sharded, synth
+    G, C = 6000, 96
+    x, cs = synth.make_matrix_np(G, C)
+    refs, _ = synth.groups(C)
+    xd = to_dev(x)
+    one, one_pre = dev.smooth_chain(xd, cs, refs, want_pre_denoise=True)
+    plan = dev.ChainPlan(G, C, cs, refs)
+    out, pre = sharded.ShardedChain(plan).run(xd, want_pre_denoise=True)
+    assert torch.equal(out, one) and torch.equal(pre, one_pre)
+    # two shards on one device
+    bounds = [sharded.shard_bounds(C, 2, r) for r in range(2)]
+    plans = [dev.ChainPlan(G, b[1] - b[0], cs, sharded.localize_groups(refs, *b)) for b in bounds]
+    shards = [xd[b[0]:b[1]].contiguous() for b in bounds]
+    for r in range(plans[0].num_rounds):
+        bufs = [p.round_partial(r, s) for p, s in zip(plans, shards)]
+        tot = bufs[0] + bufs[1]
+        for b in bufs:
+            b.copy_(tot)
+        for p in plans:
+            p.round_finish(r)
+    outs = [p.apply(s)[0] for p, s in zip(plans, shards)]
+    got = torch.cat(outs, dim=0)
+    assert (torch.abs(got - one) > 1e-12).double().mean().item() < 1e-4
+
+
+# ------------------------------------------------------------------ full-size properties
+@pytest.mark.parametrize("C", [50000])
+def test_full_size_properties(dev, C):
+    """BASELINE.json configs[1]: 10 000 genes x 50 000 cells, smooth + i6 HMM on one GPU."""
+    from infercnv_amd import synth
+    G = 10000
+    x, cs = synth.make_matrix_torch(G, C, "cuda")
+    refs, _ = synth.groups(C)
+    out, pre = dev.smooth_chain(x, cs, refs, want_pre_denoise=True)
+    means, sd, logPi, logDelta = synth.hmm_params_i6()
+    st, bad = dev.viterbi_cells(pre, cs, means, sd, logPi, logDelta)
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0
+    assert torch.isfinite(pre).all() and (pre > 0).all()
+    smin, smax = int(st.min()), int(st.max())
+    assert 1 <= smin and smax <= 6
+    # (1) spot parity: random cells re-done by the oracle given the GPU's own reference statistics
+    rng = np.random.default_rng(0)
+    pick = np.sort(rng.choice(C, 48, replace=False))
+    pre_h = pre[torch.as_tensor(pick, device="cuda")].cpu().numpy().T
+    want_st, _ = oc.viterbi_cells(pre_h, cs, means, sd, logPi, logDelta)
+    np.testing.assert_array_equal(st[torch.as_tensor(pick, device="cuda")].cpu().numpy().T, want_st)
+    # (2) cells are independent given the reference statistics: recomputing a slice that contains all
+    #     reference cells reproduces those columns exactly
+    n_ref = sum(len(r) for r in refs)
+    sub = x[: n_ref + 512].contiguous()
+    out2, pre2 = dev.smooth_chain(sub, cs, refs, want_pre_denoise=True)
+    assert torch.equal(pre2, pre[: n_ref + 512])
+    assert torch.equal(out2, out[: n_ref + 512])
+    # (3) centring property: after steps 8-11 every cell's median is exactly removed
+    cen, _ = dev.smooth_chain(x[:4096].contiguous(), cs, [np.arange(64, dtype=np.int32)], stage_mask=0x0F)
+    med = torch.median(cen, dim=1).values  # lower median for even G
+    srt = torch.sort(cen, dim=1).values
+    mid = (srt[:, G // 2 - 1] + srt[:, G // 2]) * 0.5
+    assert mid.abs().max().item() < 1e-15
+    # (4) the tumour clones' arm-level events are called: clone 0 gains chr1, loses chr10
+    _, obs = synth.groups(C)
+    c0 = int(obs[0][0])
+    col = st[c0].cpu().numpy()
+    assert (col[cs[0]:cs[1]] >= 4).mean() > 0.9 and (col[cs[9]:cs[10]] <= 2).mean() > 0.9
+    # (5) checksum of checksums is reproducible run to run (deterministic reductions)
+    out3, _ = dev.smooth_chain(x, cs, refs)
+    assert torch.equal(out3, out)

@@ -1,0 +1,183 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol
+include/icnv.h declares (no compute without a GPU), argument validation, the
+S4-mirror's layout logic, the synthetic generator, and the cell-sharding logic
+of the multi-GPU path (world_size 2, gloo) with an oracle-backed engine.
+"""
+import ctypes as ct
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import infercnv_amd
+    from infercnv_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    L = infercnv_amd.load()
+    header = open(os.path.join(ROOT, "include", "icnv.h")).read()
+    declared = set(re.findall(r"\b(icnv_[a-z0-9_]+)\s*\(", header))
+    declared -= {"icnv_chain_cfg", "icnv_chain_t"}
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/icnv.h but not exported"
+    assert declared <= set(_lib.PROTOTYPES), declared - set(_lib.PROTOTYPES)
+    assert L.icnv_version() >= 100
+
+
+def test_no_gpu_fails_loudly_not_silently():
+    """Without a GPU the product path must raise -- there is no CPU fallback."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from infercnv_amd import GeneOrder, IcnvError, InfercnvObject, ops
+    obj = InfercnvObject(expr_data=np.zeros((4, 3)), gene_order=GeneOrder(chr=np.array(["a"] * 4)),
+                         reference_grouped_cell_indices={"n": np.array([0])},
+                         observation_grouped_cell_indices={"t": np.array([1, 2])})
+    with pytest.raises(IcnvError):
+        ops.subtract_ref_expr_from_obs(obj)
+
+
+def test_argument_validation_happens_before_any_device_work():
+    from infercnv_amd import _lib
+    L = _lib.load()
+    h = ct.c_void_p()
+    bad_chr = _lib.Cfg(10, 4, [0, 5, 9], [[0]])            # chr_start does not end at G
+    assert L.icnv_chain_begin(ct.byref(h), bad_chr.ptr()) == _lib.ERR_ARG
+    assert b"chr_start" in L.icnv_last_error()
+    even = _lib.Cfg(10, 4, [0, 10], [[0]], window_length=100)
+    assert L.icnv_chain_begin(ct.byref(h), even.ptr()) == _lib.ERR_ARG
+    oob = _lib.Cfg(10, 4, [0, 10], [[7]])                  # reference index outside the matrix
+    assert L.icnv_chain_begin(ct.byref(h), oob.ptr()) == _lib.ERR_ARG
+    big = _lib.Cfg(30000, 4, [0, 30000], [[0]])
+    assert L.icnv_chain_begin(ct.byref(h), big.ptr()) == _lib.ERR_UNSUPPORTED
+    ok = _lib.Cfg(10, 4, [0, 4, 10], [[0], [3, 1]])
+    assert L.icnv_chain_begin(ct.byref(h), ok.ptr()) == _lib.OK
+    assert L.icnv_chain_num_rounds(h) == 3                 # steps 8, 12, 22
+    L.icnv_chain_end(h)
+    only_smooth = _lib.Cfg(10, 4, [0, 10], [], stage_mask=_lib.ST_SMOOTH | _lib.ST_CENTER)
+    assert L.icnv_chain_begin(ct.byref(h), only_smooth.ptr()) == _lib.OK
+    assert L.icnv_chain_num_rounds(h) == 0
+    L.icnv_chain_end(h)
+
+
+def test_chr_layout_permutation():
+    from infercnv_amd import GeneOrder, InfercnvObject
+    chrs = np.array(["chr2", "chr1", "chr2", "chr3", "chr1"])
+    obj = InfercnvObject(expr_data=np.zeros((5, 2)), gene_order=GeneOrder(chr=chrs))
+    perm, cs = obj.chr_layout()
+    assert list(chrs[perm]) == ["chr2", "chr2", "chr1", "chr1", "chr3"]   # order of first appearance
+    assert list(cs) == [0, 2, 4, 5]
+    obj2 = InfercnvObject(expr_data=np.zeros((4, 2)), gene_order=GeneOrder(chr=np.array(["a", "a", "b", "c"])))
+    perm2, cs2 = obj2.chr_layout()
+    assert perm2 is None and list(cs2) == [0, 2, 3, 4]
+
+
+def test_synthetic_generator_is_deterministic_and_shardable():
+    import torch
+    from infercnv_amd import synth
+    x, cs = synth.make_matrix_np(1000, 40)
+    assert cs[0] == 0 and cs[-1] == 1000 and len(cs) == 23 and (np.diff(cs) >= 1).all()
+    y, _ = synth.make_matrix_np(1000, 10, cell_offset=20, C_total=40)
+    np.testing.assert_array_equal(y, x[:, 20:30])
+    t, _ = synth.make_matrix_torch(1000, 40, "cpu")
+    assert np.abs(t.numpy().T - x).max() < 1e-13
+    assert list(synth.chr_layout(10000)[:3]) == [0, 1072, 1780]
+    refs, obs = synth.groups(1000)
+    assert sum(map(len, refs)) == 100 and sum(map(len, obs)) == 900
+
+
+def test_shard_helpers():
+    from infercnv_amd import sharded
+    b = [sharded.shard_bounds(10, 3, r) for r in range(3)]
+    assert b == [(0, 4), (4, 7), (7, 10)]
+    loc = sharded.localize_groups([np.array([9, 0, 5, 4]), np.array([1])], 4, 7)
+    assert [list(v) for v in loc] == [[1, 0], []]
+    cuts = sharded.align_to_groups(100, 4, [0, 30, 45, 80, 100])
+    assert cuts == [(0, 30), (30, 45), (45, 80), (80, 100)]
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
+import numpy as np, torch, torch.distributed as dist
+import oracle_np as onp
+from infercnv_amd import sharded, synth
+
+class OracleEngine:
+    """Same four methods as device.ChainPlan, arithmetic by the NumPy oracle (test-only)."""
+    def __init__(self, G, chr_codes, ref_groups_local):
+        self.G, self.chr_codes, self.refs = G, chr_codes, ref_groups_local
+        self.num_rounds = 3
+        self.b1 = self.b2 = self.den = None
+    def _upto(self, x, stage):
+        v = x
+        if stage >= 1: v = onp.subtract_expr(v, self.b1, True); v = onp.apply_max_threshold_bounds(v, 3.0)
+        if stage >= 1: v = onp.center_columns(onp.smooth_by_chromosome(v, self.chr_codes, 101))
+        if stage >= 2: v = onp.invert_log2(onp.subtract_expr(v, self.b2, True))
+        return v
+    def round_partial(self, r, x):
+        v = self._upto(x, r)
+        if r < 2:
+            sums = [v[:, g].sum(axis=1) if len(g) else np.zeros(self.G) for g in self.refs]
+            self.buf = torch.from_numpy(np.concatenate(sums + [np.array([float(len(g)) for g in self.refs])]))
+        else:
+            idx = np.concatenate(self.refs).astype(int)
+            vals = v[:, idx]
+            sd = vals.std(axis=0, ddof=1).sum() if idx.size else 0.0
+            self.buf = torch.tensor([vals.sum(), sd, float(idx.size), float(idx.size * self.G)], dtype=torch.float64)
+        return self.buf
+    def round_finish(self, r):
+        b = self.buf.numpy()
+        if r < 2:
+            n = len(self.refs)
+            means = (b[:self.G * n].reshape(n, self.G) / b[self.G * n:][:, None]).T
+            if r == 0: self.b1 = means
+            else: self.b2 = means
+        else:
+            self.den = (b[0] / b[3], b[1] / b[2] * 1.5)
+    def apply(self, x, out=None, want_pre_denoise=False):
+        pre = self._upto(x, 2)
+        return onp.clear_noise_bounds(pre, *self.den), pre
+
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=2)
+rank = dist.get_rank()
+G, C = 600, 41
+x, cs = synth.make_matrix_np(G, C)
+refs, _ = synth.groups(C, ref_frac=0.3)
+refs = [refs[0][::-1].copy(), refs[1]]                      # unsorted group, spans both shards
+refs[1] = np.concatenate([refs[1], [C - 1]]).astype(np.int32)
+chr_codes = np.repeat(np.arange(len(cs) - 1), np.diff(cs))
+c0, c1 = sharded.shard_bounds(C, 2, rank)
+eng = OracleEngine(G, chr_codes, sharded.localize_groups(refs, c0, c1))
+out, pre = sharded.ShardedChain(eng).run(np.ascontiguousarray(x[:, c0:c1]), want_pre_denoise=True)
+want, want_pre = onp.run_chain(x, chr_codes, refs, return_pre_denoise=True)
+assert np.abs(pre - want_pre[:, c0:c1]).max() < 1e-12, np.abs(pre - want_pre[:, c0:c1]).max()
+assert (np.abs(out - want[:, c0:c1]) > 1e-12).mean() < 1e-3
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_sharded_chain_two_ranks_gloo(tmp_path):
+    """world_size-2 run of the N>1 orchestration (reference rounds + all-reduce) on CPU."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(port), str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
+        assert f"rank {r} ok" in o
