@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path named by BASELINE.json: cells/sec through the fused
+smoothing chain (steps 8,9,10,11,12,14,22) + per-cell i6 HMM Viterbi at
+10 000 genes, cell-sharded over N MI355X (one process per GPU, RCCL).
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over this rank's resident batch of cells:
+3 reference rounds (partial -> all-reduce -> finish), the fused apply pass
+writing the denoised matrix + the HMM input, and the Viterbi writing uint8
+states.  Inputs are synthetic (infercnv_amd/synth.py), generated in HBM before
+the timed region.  Weak scaling: every rank holds --cells cells (default
+50 000 = BASELINE.json configs[1]).
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for the field meanings).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy ceiling
+FP64_VECTOR_PEAK_TF = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+
+
+def cpu_baseline(G, target_seconds=12.0):
+    """The plain-C oracle (oracle/icnv_oracle.c, OpenMP over cells) timed on this
+    host's cores over a bounded sample of the same synthetic workload.  R is not
+    installed in the image, so the reference itself cannot be timed: kind="port"."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_c as oc
+    from infercnv_amd import synth
+    oc.build()
+    cores = os.cpu_count() or 1
+    oc.set_num_threads(cores)
+    means, sd, logPi, logDelta = synth.hmm_params_i6()
+
+    def run(C):
+        x, cs = synth.make_matrix_np(G, C)
+        refs, _ = synth.groups(C)
+        t0 = time.perf_counter()
+        _, pre, _ = oc.smooth_chain(x, cs, refs, want_pre_denoise=True)
+        oc.viterbi_cells(pre, cs, means, sd, logPi, logDelta)
+        return time.perf_counter() - t0
+
+    pilot_c = 256
+    t_pilot = run(pilot_c)
+    C = int(min(20000, max(512, pilot_c * target_seconds / max(t_pilot, 1e-3))))
+    t = run(C)
+    return {"value": C / t, "unit": "cells/s", "cores": oc.num_threads(), "kind": "port",
+            "sample": f"{G} genes x {C} cells of the same synthetic generator, smooth chain + i6 Viterbi, "
+                      f"oracle/icnv_oracle.c with OpenMP over cells, {t:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--genes", type=int, default=10000)
+    ap.add_argument("--cells", type=int, default=50000, help="cells per GPU (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from infercnv_amd import device, sharded, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    device.init(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    G, C_local = args.genes, args.cells
+    C_total = C_local * world
+    c0 = rank * C_local
+    x, chr_start = synth.make_matrix_torch(G, C_local, "cuda", cell_offset=c0, C_total=C_total)
+    refs_global, _ = synth.groups(C_total)
+    refs_local = sharded.localize_groups(refs_global, c0, c0 + C_local)
+    means, sd, logPi, logDelta = synth.hmm_params_i6()
+
+    out = torch.empty_like(x)
+    states = torch.empty((C_local, G), dtype=torch.uint8, device="cuda")
+    plan = device.ChainPlan(G, C_local, chr_start, refs_local)
+    chain = sharded.ShardedChain(plan)
+
+    def step():
+        _, pre = chain.run(x, out=out, want_pre_denoise=True)
+        device.viterbi_cells(pre, chr_start, means, sd, logPi, logDelta, states=states)
+        return pre
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_kernel_timing:
+        device.timing_reset()
+        device.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    device.timing_enable(False)
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = C_total * args.steps / elapsed
+        kernels = {}
+        for k in ("chain_apply", "chain_gene_sums", "chain_cell_stats", "viterbi", "reduce_partials"):
+            ms, n = device.timing_get(k)
+            if n:
+                kernels[k] = {"avg_ms": ms / n, "launches_per_step": n / args.steps, "ms_per_step": ms / args.steps}
+        # algorithmic bytes per launch: chain apply reads 8 B and writes 8 B per gene*cell
+        # (+8 B for the HMM-input copy it also emits here); Viterbi reads 8 B and writes 1 B per gene*cell.
+        alg = {"chain_apply": 2 * 8 * G * C_local, "viterbi": 9 * G * C_local}
+        roof = {}
+        for k, b in alg.items():
+            if k in kernels:
+                gbs = b / (kernels[k]["avg_ms"] * 1e-3) / 1e9
+                roof[k] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": b,
+                           "avg_launch_ms": kernels[k]["avg_ms"]}
+        if "chain_apply" in roof:
+            roof["chain_apply"]["note"] = ("fused smooth pass; also writes the pre-denoise HMM input (+8 B/gene*cell, "
+                                           "not counted in the algorithmic bytes)")
+        if "viterbi" in roof:
+            flops = 500.0 * G * C_local     # ~0.5 kflop fp64 per gene*cell
+            tf = flops / (kernels["viterbi"]["avg_ms"] * 1e-3) / 1e12
+            roof["viterbi"]["note"] = ("fp64 transcendental-bound small-state DP, no MFMA-shaped work; "
+                                       f"~{tf:.1f} TFLOP/s fp64 of {FP64_VECTOR_PEAK_TF} vector peak")
+        dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
+        traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(traffic_file):
+            try:
+                tr = json.load(open(traffic_file))
+                for k in roof:
+                    if k in tr:
+                        roof[k]["traffic"] = tr[k]
+            except Exception:
+                pass
+        res = {
+            "metric": "cells/sec through smooth+i6-HMM, 10k genes", "value": value, "unit": "cells/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"synthetic {G} genes x {C_local} cells per GPU ({C_total} total), fused smooth chain "
+                                   "(steps 8,9,10,11,12,14,22) + per-cell i6 HMM Viterbi, inputs resident in HBM",
+                       "genes": G, "cells_per_gpu": C_local, "cells_total": C_total, "window_length": 101,
+                       "hmm": "i6, t=1e-6", "parallelism": f"cell-shard x{world}, 3 small all-reduces"},
+            "roofline": roof.get(dominant) or (next(iter(roof.values())) if roof else None),
+            "roofline_kernel": dominant,
+            "roofline_by_kernel": roof,
+            "kernels": kernels,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(G)
+        elif not args.no_cpu_baseline:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
