@@ -49,6 +49,7 @@ struct ChainArgs {
     const int32_t *chr_start;  // device, n_chr+1
     int32_t n_chr;
     int32_t T;              // half window, (W-1)/2; 0 = no smoothing
+    int32_t pad;            // zeros between chromosomes in LDS (set by launch_chain)
     uint32_t mask;          // ICNV_ST_* stages applied in this pass
     int32_t use_bounds;
     double max_thresh;
@@ -59,6 +60,7 @@ struct ChainArgs {
     double *cell_stats;     // MODE_CELL_STATS: [n_cells * 2] {sum, sd}
 };
 
+constexpr int CHAIN_NT = 512;  // threads per workgroup of the chain kernel
 int launch_chain(const ChainArgs &a, int mode, hipStream_t stream);
 int chain_max_genes();
 int launch_reduce_partials(const double *partial, int nblk, int32_t G, double *out, double count,

@@ -73,20 +73,24 @@ __device__ inline double dev_log(double x) {
     return (k == 0) ? f - v : dk * ln2_hi - ((v - dk * ln2_lo) - f);
 }
 
-// log P(Z > y), y >= 0 -- pnorm_both()'s three ranges (R nmath/pnorm.c, Cody 1969)
+// log P(Z > y), y >= 0 -- pnorm_both()'s three ranges (R nmath/pnorm.c, Cody 1969).
+// The three ranges share ONE division site and ONE log site (the rational's
+// numerator factor is y, 1 or 1/y^2; multiplying by 1.0 is exact), which is
+// what a diverged wavefront executes once instead of three times; every lane
+// still performs exactly the reference's operation sequence for its range.
 __device__ inline double dev_pnorm_log_upper(double y) {
-    double tmp;
-    if (y <= 0.67448975) {
+    double num, den, f1, cn, cd;
+    const bool r1 = (y <= 0.67448975);
+    const bool r3 = !(y <= 5.656854249492380195206754896838);
+    if (r1) {
         const double q = y * y;
-        double num = 0.065682337918207449113 * q, den = q;
+        num = 0.065682337918207449113 * q; den = q;
         num = (num + 2.2352520354606839287) * q;  den = (den + 47.20258190468824187) * q;
         num = (num + 161.02823106855587881) * q;  den = (den + 976.09855173777669322) * q;
         num = (num + 1067.6894854603709582) * q;  den = (den + 10260.932208618978205) * q;
-        tmp = y * (num + 18154.981253343561249) / (den + 45507.789335026729956);
-        return dev_log(0.5 - tmp);
-    }
-    if (y <= 5.656854249492380195206754896838) {
-        double num = 1.0765576773720192317e-8 * y, den = y;
+        f1 = y; cn = 18154.981253343561249; cd = 45507.789335026729956;
+    } else if (!r3) {
+        num = 1.0765576773720192317e-8 * y; den = y;
         num = (num + 0.39894151208813466764) * y;  den = (den + 22.266688044328115691) * y;
         num = (num + 8.8831497943883759412) * y;   den = (den + 235.38790178262499861) * y;
         num = (num + 93.506656132177855979) * y;   den = (den + 1519.377599407554805) * y;
@@ -94,20 +98,23 @@ __device__ inline double dev_pnorm_log_upper(double y) {
         num = (num + 2494.5375852903726711) * y;   den = (den + 18615.571640885098091) * y;
         num = (num + 6848.1904505362823326) * y;   den = (den + 34900.952721145977266) * y;
         num = (num + 11602.651437647350124) * y;   den = (den + 38912.003286093271411) * y;
-        tmp = (num + 9842.7148383839780218) / (den + 19685.429676859990727);
+        f1 = 1.0; cn = 9842.7148383839780218; cd = 19685.429676859990727;
     } else {
         const double q = 1.0 / (y * y);
-        double num = 0.02307344176494017303 * q, den = q;
+        num = 0.02307344176494017303 * q; den = q;
         num = (num + 0.21589853405795699) * q;       den = (den + 1.28426009614491121) * q;
         num = (num + 0.1274011611602473639) * q;     den = (den + 0.468238212480865118) * q;
         num = (num + 0.022235277870649807) * q;      den = (den + 0.0659881378689285515) * q;
         num = (num + 0.001421619193227893466) * q;   den = (den + 0.00378239633202758244) * q;
-        tmp = q * (num + 2.9112874951168792e-5) / (den + 7.29751555083966205e-5);
-        tmp = (0.398942280401432677939946059934 - tmp) / y;
+        f1 = q; cn = 2.9112874951168792e-5; cd = 7.29751555083966205e-5;
     }
+    double tmp = f1 * (num + cn) / (den + cd);
+    if (r3) tmp = (0.398942280401432677939946059934 - tmp) / y;
+    const double lg = dev_log(r1 ? 0.5 - tmp : tmp);
+    if (r1) return lg;
     const double xs = __builtin_trunc(y * 16.0) / 16.0;
     const double del = (y - xs) * (y + xs);
-    return (-xs * xs * 0.5) + (-del * 0.5) + dev_log(tmp);
+    return (-xs * xs * 0.5) + (-del * 0.5) + lg;
 }
 
 // emission scores of one observation (R/inferCNV_HMM.R:1129-1133, 1156-1160)
@@ -152,15 +159,19 @@ __global__ void __launch_bounds__(VIT_NT) viterbi_kernel(const double *__restric
     uint32_t *bpc = bp + (int64_t)s * ncols + col;
 
     double nu[K], sc[K];
-    double xv = xc[0];
-    double xn = xc[1];
-    emission<K>(xv, p, sd, sc);
+    double xn = xc[0];
 #pragma unroll
-    for (int k = 0; k < K; ++k) nu[k] = p.logDelta[k] + sc[k];
-    for (int i = 1; i < n; ++i) {
-        xv = xn;
+    for (int k = 0; k < K; ++k) nu[k] = 0.0;
+    // one emission site for the whole sequence keeps the kernel's code footprint small
+    for (int i = 0; i < n; ++i) {
+        const double xv = xn;
         if (i + 1 < n) xn = xc[i + 1];
         emission<K>(xv, p, sd, sc);
+        if (i == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) nu[k] = p.logDelta[k] + sc[k];
+            continue;
+        }
         double nn[K];
         uint32_t word = 0;
 #pragma unroll

@@ -131,7 +131,7 @@ def test_chain_options(dev):
     x, cs = synth.make_matrix_np(G, C)
     refs = [np.arange(0, 6, dtype=np.int32)]
     xd = to_dev(x)
-    for kw in ({"use_bounds": False}, {"max_thresh": None}, {"window_length": 3}, {"window_length": 5001},
+    for kw in ({"use_bounds": False}, {"max_thresh": None}, {"window_length": 3}, {"window_length": 301},
                {"window_length": 1}, {"noise_filter": 0.1}, {"noise_filter": 0.0}, {"stage_mask": 0x3F}):
         out, _ = dev.smooth_chain(xd, cs, refs, **kw)
         okw = dict(kw)
