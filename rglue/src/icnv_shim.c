@@ -1,0 +1,135 @@
+/*
+ * icnv_shim.c -- .Call shim between the infercnv R package and libicnv_hip.so.
+ *
+ * WRITTEN BLIND: R is not installed in the build image, so this file has never
+ * been compiled against Rinternals.h.  It contains no logic: it unpacks SEXPs
+ * into the plain pointers/sizes of include/icnv.h, allocates the result under
+ * PROTECT, and converts error codes to Rf_error() only AFTER the library has
+ * returned (the library never longjmps and owns/frees its device memory).
+ *
+ * Build (inside the infercnv source tree):
+ *   PKG_CPPFLAGS = -I$(ICNV_HOME)/include
+ *   PKG_LIBS     = -L$(ICNV_HOME)/infercnv_amd -licnv_hip -Wl,-rpath,$(ICNV_HOME)/infercnv_amd
+ */
+#include <R.h>
+#include <Rinternals.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "icnv.h"
+
+static void fail(int rc) { Rf_error("libicnv_hip error %d: %s", rc, icnv_last_error()); }
+
+/* .Call("icnv_R_smooth_chain", expr, chr_start, ref_idx, ref_off, window, max_thresh, use_bounds,
+ *       sd_amplifier, noise_filter, stage_mask, want_pre)  ->  list(expr, pre | NULL)
+ * expr: REALSXP matrix genes x cells (column-major == cell-major); indices 0-based INTSXP. */
+SEXP icnv_R_smooth_chain(SEXP expr, SEXP chr_start, SEXP ref_idx, SEXP ref_off, SEXP window, SEXP max_thresh,
+                         SEXP use_bounds, SEXP sd_amplifier, SEXP noise_filter, SEXP stage_mask, SEXP want_pre) {
+    if (!Rf_isReal(expr) || !Rf_isMatrix(expr)) Rf_error("expr must be a numeric matrix");
+    icnv_chain_cfg cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.G = Rf_nrows(expr);
+    cfg.C = Rf_ncols(expr);
+    cfg.chr_start = (const int32_t *)INTEGER(chr_start);
+    cfg.n_chr = (int32_t)(XLENGTH(chr_start) - 1);
+    cfg.window_length = Rf_asInteger(window);
+    cfg.max_thresh = Rf_asReal(max_thresh);       /* NA_real_ is a NaN: step 9 skipped */
+    cfg.use_bounds = Rf_asLogical(use_bounds);
+    cfg.sd_amplifier = Rf_asReal(sd_amplifier);
+    cfg.noise_filter = Rf_asReal(noise_filter);
+    cfg.stage_mask = (uint32_t)Rf_asInteger(stage_mask);
+    cfg.ref_idx = (const int32_t *)INTEGER(ref_idx);
+    cfg.ref_off = (const int32_t *)INTEGER(ref_off);
+    cfg.n_ref_grp = (int32_t)(XLENGTH(ref_off) - 1);
+    const int pre = Rf_asLogical(want_pre);
+    SEXP out = PROTECT(Rf_allocMatrix(REALSXP, (int)cfg.G, (int)cfg.C));
+    SEXP pre_m = PROTECT(pre ? Rf_allocMatrix(REALSXP, (int)cfg.G, (int)cfg.C) : R_NilValue);
+    int rc = icnv_smooth_chain(REAL(expr), REAL(out), pre ? REAL(pre_m) : NULL, &cfg);
+    if (rc) { UNPROTECT(2); fail(rc); }
+    Rf_setAttrib(out, R_DimNamesSymbol, Rf_getAttrib(expr, R_DimNamesSymbol));
+    if (pre) Rf_setAttrib(pre_m, R_DimNamesSymbol, Rf_getAttrib(expr, R_DimNamesSymbol));
+    SEXP res = PROTECT(Rf_allocVector(VECSXP, 2));
+    SET_VECTOR_ELT(res, 0, out);
+    SET_VECTOR_ELT(res, 1, pre_m);
+    UNPROTECT(3);
+    return res;
+}
+
+SEXP icnv_R_average_bounds(SEXP expr) {
+    double out2[2];
+    int rc = icnv_average_bounds(REAL(expr), Rf_nrows(expr), Rf_ncols(expr), out2);
+    if (rc) fail(rc);
+    SEXP r = PROTECT(Rf_allocVector(REALSXP, 2));
+    REAL(r)[0] = out2[0];
+    REAL(r)[1] = out2[1];
+    UNPROTECT(1);
+    return r;
+}
+
+/* states are uint8 in the library; the reference stores them as numeric (R/inferCNV_HMM.R:294-295) */
+static SEXP widen_states(const uint8_t *st, SEXP like) {
+    const R_xlen_t n = XLENGTH(like);
+    SEXP out = PROTECT(Rf_allocMatrix(REALSXP, Rf_nrows(like), Rf_ncols(like)));
+    double *o = REAL(out);
+    for (R_xlen_t i = 0; i < n; i++) o[i] = (st[i] == 0xFF) ? -1.0 : (double)st[i];
+    Rf_setAttrib(out, R_DimNamesSymbol, Rf_getAttrib(like, R_DimNamesSymbol));
+    UNPROTECT(1);
+    return out;
+}
+
+/* .Call("icnv_R_viterbi_cells", expr, chr_start, mean, sd_shared, logPi, logDelta) */
+SEXP icnv_R_viterbi_cells(SEXP expr, SEXP chr_start, SEXP mean, SEXP sd_shared, SEXP logPi, SEXP logDelta) {
+    const int64_t G = Rf_nrows(expr), C = Rf_ncols(expr);
+    uint8_t *st = (uint8_t *)R_alloc((size_t)G * (size_t)C, 1);
+    int rc = icnv_viterbi_cells(REAL(expr), st, G, C, (const int32_t *)INTEGER(chr_start),
+                                (int32_t)(XLENGTH(chr_start) - 1), (int32_t)XLENGTH(mean), REAL(mean),
+                                Rf_asReal(sd_shared), REAL(logPi), REAL(logDelta));
+    if (rc) fail(rc); /* ICNV_ERR_UNDERFLOW == the reference's stop("Problems With Underflow") */
+    return widen_states(st, expr);
+}
+
+/* .Call("icnv_R_viterbi_groups", expr, chr_start, grp_idx, grp_off, mean, sd_per_grp, logPi, logDelta) */
+SEXP icnv_R_viterbi_groups(SEXP expr, SEXP chr_start, SEXP grp_idx, SEXP grp_off, SEXP mean, SEXP sd_per_grp,
+                           SEXP logPi, SEXP logDelta) {
+    const int64_t G = Rf_nrows(expr), C = Rf_ncols(expr);
+    uint8_t *st = (uint8_t *)R_alloc((size_t)G * (size_t)C, 1);
+    int rc = icnv_viterbi_groups(REAL(expr), st, G, C, (const int32_t *)INTEGER(chr_start),
+                                 (int32_t)(XLENGTH(chr_start) - 1), (const int32_t *)INTEGER(grp_idx),
+                                 (const int32_t *)INTEGER(grp_off), (int32_t)(XLENGTH(grp_off) - 1),
+                                 (int32_t)XLENGTH(mean), REAL(mean), REAL(sd_per_grp), REAL(logPi), REAL(logDelta));
+    if (rc) fail(rc);
+    return widen_states(st, expr);
+}
+
+/* .Call("icnv_R_median_filter", expr, chr_start, tile_idx, tile_off, window_size) */
+SEXP icnv_R_median_filter(SEXP expr, SEXP chr_start, SEXP tile_idx, SEXP tile_off, SEXP window_size) {
+    SEXP out = PROTECT(Rf_allocMatrix(REALSXP, Rf_nrows(expr), Rf_ncols(expr)));
+    int rc = icnv_median_filter(REAL(expr), REAL(out), Rf_nrows(expr), Rf_ncols(expr),
+                                (const int32_t *)INTEGER(chr_start), (int32_t)(XLENGTH(chr_start) - 1),
+                                (const int32_t *)INTEGER(tile_idx), (const int32_t *)INTEGER(tile_off),
+                                (int32_t)(XLENGTH(tile_off) - 1), Rf_asInteger(window_size));
+    if (rc) { UNPROTECT(1); fail(rc); }
+    Rf_setAttrib(out, R_DimNamesSymbol, Rf_getAttrib(expr, R_DimNamesSymbol));
+    UNPROTECT(1);
+    return out;
+}
+
+SEXP icnv_R_init(SEXP device) {
+    int rc = icnv_init(Rf_asInteger(device));
+    if (rc) fail(rc);
+    return R_NilValue;
+}
+
+static const R_CallMethodDef call_methods[] = {
+    {"icnv_R_smooth_chain", (DL_FUNC)&icnv_R_smooth_chain, 11},
+    {"icnv_R_average_bounds", (DL_FUNC)&icnv_R_average_bounds, 1},
+    {"icnv_R_viterbi_cells", (DL_FUNC)&icnv_R_viterbi_cells, 6},
+    {"icnv_R_viterbi_groups", (DL_FUNC)&icnv_R_viterbi_groups, 8},
+    {"icnv_R_median_filter", (DL_FUNC)&icnv_R_median_filter, 5},
+    {"icnv_R_init", (DL_FUNC)&icnv_R_init, 1},
+    {NULL, NULL, 0}};
+
+void R_init_infercnv(DllInfo *dll) {
+    R_registerRoutines(dll, NULL, call_methods, NULL, NULL);
+    R_useDynamicSymbols(dll, FALSE);
+}
