@@ -49,10 +49,15 @@ def cpu_baseline(G, target_seconds=12.0):
         oc.viterbi_cells(pre, cs, means, sd, logPi, logDelta)
         return time.perf_counter() - t0
 
-    pilot_c = 256
+    # pilot sized so that every thread gets several cells, then scale to ~target_seconds of CPU work
+    pilot_c = max(512, 8 * cores)
+    run(pilot_c)                                   # first call also pays thread start-up / page faults
     t_pilot = run(pilot_c)
-    C = int(min(20000, max(512, pilot_c * target_seconds / max(t_pilot, 1e-3))))
+    C = int(min(60000, max(pilot_c, pilot_c * target_seconds / max(t_pilot, 1e-3))))
     t = run(C)
+    if t < 0.6 * target_seconds and C < 60000:     # the pilot under-estimated the parallel speed: one larger sample
+        C = int(min(60000, C * target_seconds / max(t, 1e-3)))
+        t = run(C)
     return {"value": C / t, "unit": "cells/s", "cores": oc.num_threads(), "kind": "port",
             "sample": f"{G} genes x {C} cells of the same synthetic generator, smooth chain + i6 Viterbi, "
                       f"oracle/icnv_oracle.c with OpenMP over cells, {t:.1f} s"}
@@ -80,11 +85,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if os.environ.get("ICNV_BENCH_ONE_DEVICE"):          # smoke-test the N>1 code path on a single GPU
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device.init(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("ICNV_BENCH_BACKEND", "nccl")   # "gloo" only for the 1-GPU smoke of the N>1 path
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     G, C_local = args.genes, args.cells
     C_total = C_local * world
@@ -156,7 +167,7 @@ def main():
                                        f"~{tf:.1f} TFLOP/s fp64 of {FP64_VECTOR_PEAK_TF} vector peak")
         dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
         traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(traffic_file):
+        if os.path.exists(traffic_file) and G == 10000 and C_local == 50000:   # counters were collected on this shape
             try:
                 tr = json.load(open(traffic_file))
                 for k in roof:

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libicnv_hip.so")
+LIB_PATH = os.environ.get("ICNV_LIB", os.path.join(_HERE, "libicnv_hip.so"))
 
 ST_SUBTRACT_REF_1 = 0x01
 ST_MAX_THRESH = 0x02

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""gpurun_out/pmc/{FETCH_SIZE,WRITE_SIZE}/*_counter_collection.csv -> profiles/pmc_traffic.json (+ a text table).
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports 1/2 of the
+bytes of a wide coalesced streaming read, so it is doubled; the calibration launch (chain kernel with stage_mask 0:
+exactly 4.0 GB read + 4.0 GB written) checks the correction in our own access pattern."""
+import collections, csv, json, os, re, sys
+root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
+def load(path):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if "icnv" in r["Kernel_Name"]:
+            m = re.search(r"::(\w+_kernel(?:<[^>]*>)?)\(", r["Kernel_Name"])
+            agg[m.group(1) if m else r["Kernel_Name"][:60]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+f = {t: load(f"{root}/FETCH_SIZE/{t}_counter_collection.csv") for t in ("copy", "bench")}
+w = {t: load(f"{root}/WRITE_SIZE/{t}_counter_collection.csv") for t in ("copy", "bench")}
+lines = ["kernel  FETCH_SIZE(KiB, raw)  fetch_bytes(x2 corrected)  WRITE_SIZE(KiB)  write_bytes  total_bytes"]
+out = {}
+for t in ("copy", "bench"):
+    for k in sorted(f[t]):
+        fb, wb = f[t][k] * 2 * 1024, w[t].get(k, 0.0) * 1024
+        lines.append(f"{t}:{k}  {f[t][k]:.0f}  {fb:.4g}  {w[t].get(k, 0):.0f}  {wb:.4g}  {fb + wb:.4g}")
+        if t == "bench":
+            if k.startswith("chain_kernel") and k.endswith(", 0, 127>"): out["chain_apply"] = fb + wb
+            if k.startswith("viterbi_kernel"): out["viterbi"] = fb + wb
+        else:
+            out["calibration_copy_4e9_read_4e9_write"] = {"fetch_bytes_corrected": fb, "write_bytes": wb}
+print("\n".join(lines))
+os.makedirs("profiles", exist_ok=True)
+json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
