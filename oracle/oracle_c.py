@@ -56,6 +56,8 @@ def lib():
         L.orc_smooth_chain.restype = ct.c_int
         L.orc_log.argtypes = [dbl]
         L.orc_log.restype = dbl
+        L.orc_log_array.argtypes = [_dp, _dp, i64]
+        L.orc_fma_array.argtypes = [_dp, _dp, _dp, _dp, i64]
         L.orc_pnorm_log_upper.argtypes = [dbl]
         L.orc_pnorm_log_upper.restype = dbl
         L.orc_viterbi_cells.argtypes = [_dp, _bp, i64, i64, _ip, i32, i32, _dp, dbl, _dp, _dp]
@@ -114,8 +116,21 @@ def num_threads():
 
 
 def log(x):
-    L = lib()
-    return np.array([L.orc_log(float(v)) for v in np.ravel(x)]).reshape(np.shape(x))
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    lib().orc_log_array(x.ctypes.data_as(_dp), out.ctypes.data_as(_dp), x.size)
+    return out
+
+
+def fma(a, b, c):
+    """Correctly rounded fused multiply-add (libm), broadcast like NumPy."""
+    a, b, c = np.broadcast_arrays(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64),
+                                  np.asarray(c, dtype=np.float64))
+    a, b, c = (np.ascontiguousarray(v) for v in (a, b, c))
+    out = np.empty(a.shape, dtype=np.float64)
+    lib().orc_fma_array(a.ctypes.data_as(_dp), b.ctypes.data_as(_dp), c.ctypes.data_as(_dp),
+                        out.ctypes.data_as(_dp), out.size)
+    return out
 
 
 def pnorm_log_upper(y):

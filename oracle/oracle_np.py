@@ -289,71 +289,53 @@ _Q = (1.28426009614491121, 0.468238212480865118, 0.0659881378689285515,
 _M_1_SQRT_2PI = 0.398942280401432677939946059934
 _SQRT32 = 5.656854249492380195206754896838
 
-_LN2_HI = 6.93147180369123816490e-01
-_LN2_LO = 1.90821492927058770002e-10
-_LG = (6.666666666666735130e-01, 3.999999999940941908e-01, 2.857142874366239149e-01,
-       2.222219843214978396e-01, 1.818357216161805012e-01, 1.531383769920937332e-01,
-       1.479819860511658591e-01)
+def _fma(a, b, c):
+    """NumPy has no fused multiply-add; the correctly rounded primitive comes from
+    libm through the C oracle's helper (the *algorithm* below stays independent)."""
+    import oracle_c
+    return oracle_c.fma(a, b, c)
 
 
 def icnv_log(x):
-    """Natural log with a FIXED IEEE-754 operation sequence (the classic
-    fdlibm e_log.c scheme: x = 2^k (1+f), s = f/(2+f), log(1+f) = f - hfsq +
-    s (hfsq + R(s^2))).  No FMA, every step a correctly rounded double op, so
-    NumPy, gcc and the HIP kernel agree bit for bit.  R itself calls the
-    platform libm log (<1 ulp, platform dependent) -- see DESIGN.md."""
+    """Natural log with a FIXED operation sequence (DESIGN.md "Arithmetic spec"):
+    table-driven, constants from oracle/gen_log_table.py, explicit correctly
+    rounded fma.  x = 2^k z; r = fma(z, invc, -1) (exact); w = k LN2HI + logc_hi
+    (exact); hi = w + r; lo = ((w - hi) + r) + (k LN2LO + logc_lo);
+    result = hi + fma(r r, B0 + r(B1 + ... + r B6), lo).  <= 0.52 ulp.
+    R itself calls the platform libm log (implementation-defined at this level)."""
+    import icnv_log_table as T
     x = np.asarray(x, dtype=np.float64)
     shp = x.shape
-    x = np.atleast_1d(x).copy()
-    res = np.empty_like(x)
-    bits = x.view(np.int64)
-    hx = (bits >> 32).astype(np.int64)
-    lx = bits & 0xFFFFFFFF
-    k = np.zeros(x.shape, dtype=np.int64)
-    tiny = hx < 0x00100000
-    zero = tiny & (((hx & 0x7FFFFFFF) | lx) == 0)
-    neg = tiny & (hx < 0) & ~zero
-    sub = tiny & ~zero & ~neg
+    x = np.atleast_1d(x).ravel().copy()
+    ix = x.view(np.uint64).copy()
+    special = (ix - np.uint64(0x0010000000000000)) >= np.uint64(0x7FE0000000000000)
+    zero = (ix << np.uint64(1)) == 0
+    pinf = ix == np.uint64(0x7FF0000000000000)
+    bad = ((ix >> np.uint64(63)) != 0) | ((ix & np.uint64(0x7FF0000000000000)) == np.uint64(0x7FF0000000000000))
+    sub = special & ~zero & ~pinf & ~bad
     with np.errstate(all="ignore"):
-        x = np.where(sub, x * 1.80143985094819840000e+16, x)
-    k = np.where(sub, k - 54, k)
-    bits = x.view(np.int64)
-    hx = (bits >> 32).astype(np.int64)
-    lx = bits & 0xFFFFFFFF
-    infnan = hx >= 0x7FF00000
-    k = k + (hx >> 20) - 1023
-    hx = hx & 0x000FFFFF
-    i = (hx + 0x95F64) & 0x100000
-    newhi = hx | (i ^ 0x3FF00000)
-    xn = ((newhi << 32) | lx).astype(np.int64).view(np.float64)
-    k = k + (i >> 20)
-    dk = k.astype(np.float64)
+        xs = np.where(sub, x * 2.0 ** 52, x)
+    ix = np.where(sub, xs.view(np.uint64) - np.uint64(52 << 52), ix)
+    tmp = ix - np.uint64(T.OFF)
+    i = ((tmp >> np.uint64(45)) & np.uint64(127)).astype(np.int64)
+    k = (tmp.view(np.int64) >> 52)
+    z = (ix - (tmp & np.uint64(0xFFF0000000000000))).view(np.float64)
+    tab = np.array(T.TABLE)
+    invc, lchi, lclo = tab[i, 0], tab[i, 1], tab[i, 2]
     with np.errstate(all="ignore"):
-        f = xn - 1.0
-        small = (0x000FFFFF & (2 + hx)) < 3
-        # |f| < 2^-20 branch
-        Rs = f * f * (0.5 - 0.33333333333333333 * f)
-        r_small = np.where(f == 0.0,
-                           np.where(k == 0, 0.0, dk * _LN2_HI + dk * _LN2_LO),
-                           np.where(k == 0, f - Rs, dk * _LN2_HI - ((Rs - dk * _LN2_LO) - f)))
-        s = f / (2.0 + f)
-        z = s * s
-        w = z * z
-        ii = hx - 0x6147A
-        jj = 0x6B851 - hx
-        t1 = w * (_LG[1] + w * (_LG[3] + w * _LG[5]))
-        t2 = z * (_LG[0] + w * (_LG[2] + w * (_LG[4] + w * _LG[6])))
-        R = t2 + t1
-        hfsq = 0.5 * f * f
-        big = (ii | jj) > 0
-        r_big = np.where(k == 0, f - (hfsq - s * (hfsq + R)),
-                         dk * _LN2_HI - ((hfsq - (s * (hfsq + R) + dk * _LN2_LO)) - f))
-        r_mid = np.where(k == 0, f - s * (f - R),
-                         dk * _LN2_HI - ((s * (f - R) - dk * _LN2_LO) - f))
-        res = np.where(small, r_small, np.where(big, r_big, r_mid))
-        res = np.where(infnan, x + x, res)
-        res = np.where(neg, np.nan, res)
-        res = np.where(zero, -np.inf, res)
+        r = _fma(z, invc, -1.0)
+        kd = k.astype(np.float64)
+        w = _fma(kd, T.LN2HI, lchi)
+        hi = w + r
+        lo = ((w - hi) + r) + (kd * T.LN2LO + lclo)
+        r2 = r * r
+        q = _fma(r, T.B[6], T.B[5])
+        for j in (4, 3, 2, 1, 0):
+            q = _fma(r, q, T.B[j])
+        res = hi + _fma(r2, q, lo)
+    res = np.where(zero, -np.inf, res)
+    res = np.where(pinf, np.inf, res)
+    res = np.where(bad & ~pinf, np.nan, res)
     return res.reshape(shp)
 
 

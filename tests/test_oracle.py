@@ -187,14 +187,26 @@ def test_multi_ref_groups_and_no_bounds():
 
 
 def test_log_and_pnorm_restatements_agree_and_are_accurate():
+    from decimal import Decimal, getcontext
     from scipy.special import log_ndtr
     rng = np.random.default_rng(0)
     xs = np.concatenate([np.exp(rng.uniform(-700, 700, 20000)), rng.uniform(0.2, 1.0, 20000),
-                         1 + rng.uniform(-1e-6, 1e-6, 2000), [1.0, 2.0, 0.5, 5e-324, 2.2250738585072014e-308]])
+                         1 + rng.uniform(-1e-6, 1e-6, 2000), 1 + rng.uniform(-0.05, 0.05, 20000),
+                         [1.0, 2.0, 0.5, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308]])
     a, b = onp.icnv_log(xs), oc.log(xs)
-    np.testing.assert_array_equal(a, b)                       # bit-identical restatements
-    assert np.max(np.abs(a - np.log(xs)) / np.maximum(np.abs(np.log(xs)), 1e-300)) < 4.5e-16
-    assert np.isneginf(oc.log(np.array([0.0]))[0]) and np.isnan(oc.log(np.array([-1.0]))[0])
+    np.testing.assert_array_equal(a, b)                       # bit-identical restatements (NumPy vs C)
+    assert np.max(np.abs(a - np.log(xs)) / np.maximum(np.abs(np.log(xs)), 1e-300)) < 2.3e-16
+    spec = oc.log(np.array([0.0, -1.0, np.inf, np.nan, 1.0]))
+    assert np.isneginf(spec[0]) and np.isnan(spec[1]) and np.isposinf(spec[2]) and np.isnan(spec[3]) and spec[4] == 0.0
+    # ulp error against 60-digit logarithms, including the sub-interval boundaries of the table
+    getcontext().prec = 60
+    import icnv_log_table as T
+    edge = np.array([T.OFF + (i << 45) + d for i in range(128) for d in (-1, 0, 1)], dtype=np.uint64).view(np.float64)
+    sample = np.concatenate([xs[::37], edge])
+    got = oc.log(sample)
+    worst = max(abs(Decimal(float(g)) - Decimal(float(x)).ln()) / Decimal(float(np.spacing(abs(g)))) for g, x
+                in zip(got, sample) if g != 0.0)
+    assert worst < Decimal("0.53"), worst
     ys = np.concatenate([np.linspace(0, 40, 40001), rng.uniform(0, 8, 20000), [0.67448975, 5.656854249492380]])
     p, q = onp.pnorm_log_upper(ys), oc.pnorm_log_upper(ys)
     np.testing.assert_array_equal(p, q)
