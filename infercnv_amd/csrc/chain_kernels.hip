@@ -50,14 +50,22 @@ __device__ inline double wave_max(double v) {
     return v;
 }
 
-// sums[g] = sum_b partial[b*G + g] in fixed order; also stores the cell count.
+// sums[g] = sum_b partial[b*G + g] in a fixed order (four interleaved partial sums combined at the
+// end, so the loads pipeline); also stores the cell count.
 __global__ void reduce_partials_kernel(const double *partial, int nblk, int G, double *out, double count,
                                        double *count_out) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < G) {
-        double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * G + g];
-        out[g] = s;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int b = 0;
+        for (; b + 4 <= nblk; b += 4) {
+            s0 += partial[(int64_t)(b + 0) * G + g];
+            s1 += partial[(int64_t)(b + 1) * G + g];
+            s2 += partial[(int64_t)(b + 2) * G + g];
+            s3 += partial[(int64_t)(b + 3) * G + g];
+        }
+        for (; b < nblk; ++b) s0 += partial[(int64_t)b * G + g];
+        out[g] = (s0 + s1) + (s2 + s3);
     }
     if (g == 0 && count_out) *count_out = count;
 }
@@ -155,7 +163,7 @@ int launch_chain(const ChainArgs &a0, int mode, hipStream_t stream) {
 int launch_reduce_partials(const double *partial, int nblk, int32_t G, double *out, double count,
                            double *count_out, hipStream_t stream) {
     KernelTimer kt("reduce_partials", stream);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((G + 255) / 256), dim3(256), 0, stream, partial, nblk, G, out,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((G + 63) / 64), dim3(64), 0, stream, partial, nblk, G, out,
                        count, count_out);
     ICNV_HIP(hipGetLastError());
     return ICNV_OK;
