@@ -26,11 +26,11 @@
 
 namespace icnv {
 
-int launch_chain_l7(const ChainArgs &a, int mode, hipStream_t stream);
-int launch_chain_l23(const ChainArgs &a, int mode, hipStream_t stream);
-int launch_chain_l37(const ChainArgs &a, int mode, hipStream_t stream);
-int launch_chain_w11(const ChainArgs &a, int mode, hipStream_t stream);
-int launch_chain_w19(const ChainArgs &a, int mode, hipStream_t stream);
+// one translation unit per (threads, chunk length) so the variants compile in parallel
+int launch_chain_m7(const ChainArgs &a, int mode, hipStream_t stream);    // 768 threads,  <=  5376 positions
+int launch_chain_m15(const ChainArgs &a, int mode, hipStream_t stream);   // 768 threads,  <= 11520
+int launch_chain_m23(const ChainArgs &a, int mode, hipStream_t stream);   // 768 threads,  <= 17664
+int launch_chain_l37(const ChainArgs &a, int mode, hipStream_t stream);   // 512 threads,  <= 18944
 
 namespace {
 
@@ -140,7 +140,7 @@ __global__ void minmax_cells_kernel(const double *x, int G, int64_t C, double *o
 
 }  // namespace
 
-int chain_max_genes() { return CHAIN_NT * 37; }
+int chain_max_genes() { return 512 * 37; }
 
 int launch_chain(const ChainArgs &a0, int mode, hipStream_t stream) {
     ChainArgs a = a0;
@@ -150,12 +150,11 @@ int launch_chain(const ChainArgs &a0, int mode, hipStream_t stream) {
     a.pad = smooth ? ((a.T + 3) & ~1) : 0;  // even(T+2)
     // padded positions: genes + PAD zeros before every chromosome and after the last
     const int64_t npos = (int64_t)a.G + (int64_t)(a.n_chr + 1) * a.pad;
-    static const int wide = getenv("ICNV_CHAIN_NT1024") ? atoi(getenv("ICNV_CHAIN_NT1024")) : 1;
-    if (wide && npos > 1024 * 3 && npos <= 1024 * 11) return launch_chain_w11(a, mode, stream);
-    if (wide && npos > 1024 * 11 && npos <= 1024 * 19) return launch_chain_w19(a, mode, stream);
-    if (npos <= CHAIN_NT * 7) return launch_chain_l7(a, mode, stream);
-    if (npos <= CHAIN_NT * 23) return launch_chain_l23(a, mode, stream);
-    if (npos <= CHAIN_NT * 37) return launch_chain_l37(a, mode, stream);
+    // 768 threads = 3 wavefronts per SIMD = 168 VGPRs per lane: measured fastest (no spills, 12 waves)
+    if (npos <= 768 * 7) return launch_chain_m7(a, mode, stream);
+    if (npos <= 768 * 15) return launch_chain_m15(a, mode, stream);
+    if (npos <= 768 * 23) return launch_chain_m23(a, mode, stream);
+    if (npos <= 512 * 37) return launch_chain_l37(a, mode, stream);
     ICNV_FAIL(ICNV_ERR_UNSUPPORTED,
               "fused smoothing chain: genes + (n_chr+1)*(window/2+2) padding exceed the LDS-resident limit of 18944");
 }

@@ -2,5 +2,5 @@
 #include "chain_kernel.inc"
 
 namespace icnv {
-int launch_chain_l37(const ChainArgs &a, int mode, hipStream_t stream) { return launch_chain_v<CHAIN_NT, 37>(a, mode, stream); }
+int launch_chain_l37(const ChainArgs &a, int mode, hipStream_t stream) { return launch_chain_v<512, 37>(a, mode, stream); }
 }  // namespace icnv

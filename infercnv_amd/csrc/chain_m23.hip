@@ -1,0 +1,6 @@
+// chain kernel variants with 768 threads (3 wavefronts per SIMD, 168 VGPRs) and chunk length 23
+#include "chain_kernel.inc"
+
+namespace icnv {
+int launch_chain_m23(const ChainArgs &a, int mode, hipStream_t stream) { return launch_chain_v<768, 23>(a, mode, stream); }
+}  // namespace icnv

@@ -60,7 +60,6 @@ struct ChainArgs {
     double *cell_stats;     // MODE_CELL_STATS: [n_cells * 2] {sum, sd}
 };
 
-constexpr int CHAIN_NT = 512;  // threads per workgroup of the chain kernel
 int launch_chain(const ChainArgs &a, int mode, hipStream_t stream);
 int chain_max_genes();
 int launch_reduce_partials(const double *partial, int nblk, int32_t G, double *out, double count,
