@@ -124,6 +124,19 @@ void icnv_chain_end(icnv_chain_t *chain);
 int icnv_average_bounds(const double *expr, int64_t G, int64_t C, double *out2);
 int icnv_average_bounds_dev(const double *expr, int64_t G, int64_t C, double *out2_host, void *stream);
 
+/* ---- ingest: steps 3 and 4 of run() (first "next" row) -------- */
+/* colSums(expr.data) per cell (R/inferCNV_ops.R:3089), device pointers. */
+int icnv_col_sums_dev(const double *expr, int64_t G, int64_t C, double *sums_dev, void *stream);
+/* normalize_counts_by_seq_depth (R/inferCNV_ops.R:3064-3111): x / colSum * factor, and
+ * log2xplus1 (:2756-2769): log2(x + 1); either part can be switched off. */
+int icnv_normalize_log2_dev(const double *expr_in, double *expr_out, int64_t G, int64_t C,
+                            const double *col_sums_dev, double normalize_factor, int32_t do_normalize,
+                            int32_t do_log2, void *stream);
+/* Host buffers; normalize_factor NaN = median(colSums) like the reference's default
+ * (normalize_factor=NA); the factor used is returned through factor_used (nullable). */
+int icnv_normalize_log2(const double *expr_in, double *expr_out, int64_t G, int64_t C,
+                        double normalize_factor, int32_t do_normalize, int32_t do_log2, double *factor_used);
+
 /* ---- HMM ---------------------------------------------------------------- */
 /* Viterbi.dthmm.adj (R/inferCNV_HMM.R:1101-1176) for every (cell, chromosome):
  * predict_CNV_via_HMM_on_indiv_cells (R/inferCNV_HMM.R:284-324) with K = 6 and

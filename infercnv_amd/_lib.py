@@ -70,6 +70,9 @@ PROTOTYPES = {
     "icnv_chain_end": (None, [_vp]),
     "icnv_average_bounds": (ct.c_int, [_vp, _i64, _i64, _dp]),
     "icnv_average_bounds_dev": (ct.c_int, [_vp, _i64, _i64, _dp, _vp]),
+    "icnv_col_sums_dev": (ct.c_int, [_vp, _i64, _i64, _vp, _vp]),
+    "icnv_normalize_log2_dev": (ct.c_int, [_vp, _vp, _i64, _i64, _vp, _dbl, _i32, _i32, _vp]),
+    "icnv_normalize_log2": (ct.c_int, [_vp, _vp, _i64, _i64, _dbl, _i32, _i32, _dp]),
     "icnv_viterbi_cells": (ct.c_int, [_vp, _vp, _i64, _i64, _ip, _i32, _i32, _dp, _dbl, _dp, _dp]),
     "icnv_viterbi_cells_dev": (ct.c_int, [_vp, _vp, _i64, _i64, _ip, _i32, _i32, _dp, _dbl, _dp, _dp, _vp, _vp]),
     "icnv_viterbi_groups": (ct.c_int, [_vp, _vp, _i64, _i64, _ip, _i32, _ip, _ip, _i32, _i32, _dp, _dp, _dp, _dp]),

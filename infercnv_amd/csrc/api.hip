@@ -481,6 +481,56 @@ int icnv_average_bounds(const double *expr, int64_t G, int64_t C, double *out2) 
     return icnv_average_bounds_dev(d.as<double>(), G, C, out2, nullptr);
 }
 
+// ------------------------------------------------------------------ ingest (steps 3-4)
+int icnv_col_sums_dev(const double *expr, int64_t G, int64_t C, double *sums_dev, void *stream) {
+    if (!expr || !sums_dev || G < 1 || C < 0 || G > 0x7fffffff) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    return launch_col_sums(expr, (int32_t)G, C, sums_dev, (hipStream_t)stream);
+}
+
+int icnv_normalize_log2_dev(const double *expr_in, double *expr_out, int64_t G, int64_t C, const double *col_sums_dev,
+                            double normalize_factor, int32_t do_normalize, int32_t do_log2, void *stream) {
+    if (!expr_in || !expr_out || G < 1 || C < 0 || G > 0x7fffffff) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    if (do_normalize && (!col_sums_dev || std::isnan(normalize_factor)))
+        ICNV_FAIL(ICNV_ERR_ARG, "normalisation needs the column sums and a factor");
+    return launch_normalize_log2(expr_in, expr_out, (int32_t)G, C, col_sums_dev, normalize_factor, do_normalize, do_log2,
+                                 (hipStream_t)stream);
+}
+
+static double host_median(std::vector<double> v) {
+    const size_t n = v.size(), h = n / 2;
+    std::nth_element(v.begin(), v.begin() + h, v.end());
+    const double hi = v[h];
+    if (n & 1) return hi;
+    const double lo = *std::max_element(v.begin(), v.begin() + h);
+    return (lo + hi) * 0.5;
+}
+
+int icnv_normalize_log2(const double *expr_in, double *expr_out, int64_t G, int64_t C, double normalize_factor,
+                        int32_t do_normalize, int32_t do_log2, double *factor_used) {
+    if (!expr_in || !expr_out || G < 1 || C < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    DevBuf din, dout, dsum;
+    int rc;
+    const size_t bytes = (size_t)G * (size_t)C * sizeof(double);
+    if ((rc = din.alloc(bytes)) || (rc = dout.alloc(bytes)) || (rc = dsum.alloc((size_t)C * sizeof(double)))) return rc;
+    ICNV_HIP(hipMemcpy(din.p, expr_in, bytes, hipMemcpyHostToDevice));
+    double factor = normalize_factor;
+    if (do_normalize) {
+        if ((rc = icnv_col_sums_dev(din.as<double>(), G, C, dsum.as<double>(), nullptr))) return rc;
+        if (std::isnan(factor)) {   // median(colSums), R/inferCNV_ops.R:3096
+            std::vector<double> cs((size_t)C);
+            ICNV_HIP(hipMemcpy(cs.data(), dsum.p, (size_t)C * sizeof(double), hipMemcpyDeviceToHost));
+            factor = host_median(std::move(cs));
+        }
+        if (std::isnan(factor)) ICNV_FAIL(ICNV_ERR_ARG, "normalize factor not estimated");   // :3105
+    }
+    if (factor_used) *factor_used = factor;
+    if ((rc = icnv_normalize_log2_dev(din.as<double>(), dout.as<double>(), G, C, dsum.as<double>(), factor, do_normalize,
+                                      do_log2, nullptr)))
+        return rc;
+    ICNV_HIP(hipMemcpy(expr_out, dout.p, bytes, hipMemcpyDeviceToHost));
+    return ICNV_OK;
+}
+
 // ------------------------------------------------------------------ HMM
 static int fill_hmm(HmmParams &p, int32_t K, const double *mean, const double *logPi, const double *logDelta) {
     if (K != 3 && K != 6) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "HMM kernels are built for K = 6 (i6) and K = 3 (i3)");

@@ -138,7 +138,57 @@ __global__ void minmax_cells_kernel(const double *x, int G, int64_t C, double *o
     }
 }
 
+// colSums(expr.data) (R/inferCNV_ops.R:3089): one workgroup per cell, fixed-order reduction
+__global__ void col_sums_kernel(const double *x, int G, int64_t C, double *out) {
+    __shared__ double red[4];
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        const double *col = x + c * (int64_t)G;
+        double s = 0.0;
+        for (int g = threadIdx.x; g < G; g += blockDim.x) s += col[g];
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) out[c] = (red[0] + red[1]) + (red[2] + red[3]);
+        __syncthreads();
+    }
+}
+
+// .normalize_data_matrix_by_seq_depth (R/inferCNV_ops.R:3082-3111): x / colSum * factor, then
+// log2xplus1 (:2756-2769): log2(x + 1).  Operation order as in R (divide, multiply, add, log2).
+__global__ void normalize_log2_kernel(const double *in, double *out, int G, int64_t C, const double *col_sums,
+                                      double factor, int do_norm, int do_log) {
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        const double *src = in + c * (int64_t)G;
+        double *dst = out + c * (int64_t)G;
+        const double cs = do_norm ? col_sums[c] : 1.0;
+        for (int g = threadIdx.x; g < G; g += blockDim.x) {
+            double v = src[g];
+            if (do_norm) v = v / cs * factor;
+            if (do_log) v = log2(v + 1.0);
+            dst[g] = v;
+        }
+    }
+}
+
 }  // namespace
+
+int launch_col_sums(const double *x, int32_t G, int64_t C, double *out, hipStream_t stream) {
+    if (C <= 0) return ICNV_OK;
+    KernelTimer kt("col_sums", stream);
+    hipLaunchKernelGGL(col_sums_kernel, dim3((unsigned)(C < 8192 ? C : 8192)), dim3(256), 0, stream, x, G, C, out);
+    ICNV_HIP(hipGetLastError());
+    return ICNV_OK;
+}
+
+int launch_normalize_log2(const double *in, double *out, int32_t G, int64_t C, const double *col_sums, double factor,
+                          int do_norm, int do_log, hipStream_t stream) {
+    if (C <= 0) return ICNV_OK;
+    KernelTimer kt("normalize_log2", stream);
+    hipLaunchKernelGGL(normalize_log2_kernel, dim3((unsigned)(C < 8192 ? C : 8192)), dim3(256), 0, stream, in, out, G, C,
+                       col_sums, factor, do_norm, do_log);
+    ICNV_HIP(hipGetLastError());
+    return ICNV_OK;
+}
 
 int chain_max_genes() { return 512 * 37; }
 

@@ -70,6 +70,9 @@ int launch_reduce_cell_stats(const double *cell_stats, int32_t n_cells, int32_t 
                              hipStream_t stream);
 int launch_denoise_from_stats(const double *stats4, double sd_amplifier, double noise_filter,
                               double *mu_s, hipStream_t stream);
+int launch_col_sums(const double *x, int32_t G, int64_t C, double *out, hipStream_t stream);
+int launch_normalize_log2(const double *in, double *out, int32_t G, int64_t C, const double *col_sums, double factor,
+                          int do_norm, int do_log, hipStream_t stream);
 int launch_minmax_cells(const double *x, int32_t G, int64_t C, double *out2_dev, hipStream_t stream);
 
 // ---- HMM ------------------------------------------------------------------

@@ -128,6 +128,35 @@ def average_bounds(x):
     return out[0], out[1]
 
 
+# ------------------------------------------------------------------ ingest (steps 3-4)
+def col_sums(x):
+    """colSums per cell (R/inferCNV_ops.R:3089) -> float64 (C,) tensor."""
+    L = _lib.load()
+    C, G = _check_matrix(x)
+    out = torch.empty(C, dtype=torch.float64, device=x.device)
+    check(L.icnv_col_sums_dev(_ptr(x), G, C, _ptr(out), _stream()))
+    return out
+
+
+def normalize_log2(x, col_sums_t=None, normalize_factor=None, do_normalize=True, do_log2=True, out=None):
+    """normalize_counts_by_seq_depth + log2xplus1 (R/inferCNV_ops.R:3064-3111, 2756-2769).  With
+    normalize_factor=None the factor is median(colSums) of THIS matrix; a cell-sharded caller
+    all-gathers the column sums and passes the global median instead."""
+    L = _lib.load()
+    C, G = _check_matrix(x)
+    if do_normalize and col_sums_t is None:
+        col_sums_t = col_sums(x)
+    if do_normalize and normalize_factor is None:
+        srt = torch.sort(col_sums_t).values
+        n = srt.numel()
+        normalize_factor = float(srt[n // 2]) if n % 2 else float((srt[n // 2 - 1] + srt[n // 2]) * 0.5)
+    if out is None:
+        out = torch.empty_like(x)
+    check(L.icnv_normalize_log2_dev(_ptr(x), _ptr(out), G, C, _ptr(col_sums_t), float(normalize_factor or 0.0),
+                                    int(do_normalize), int(do_log2), _stream()))
+    return out
+
+
 # ------------------------------------------------------------------ HMM
 def viterbi_cells(x, chr_start, means, sd_shared, logPi, logDelta, states=None):
     """predict_CNV_via_HMM_on_indiv_cells (R/inferCNV_HMM.R:284-324) / i3 variant

@@ -51,6 +51,30 @@ def _with_expr(obj, expr, hspike=None):
     return new
 
 
+# ------------------------------------------------------------------ steps 3 / 4 (ingest)
+def _normalize_log2(infercnv_obj, normalize_factor, do_norm, do_log):
+    L = _lib.load()
+    x = _as_f(infercnv_obj.expr_data)
+    out = np.empty_like(x, order="F")
+    used = ct.c_double()
+    nf = float("nan") if normalize_factor is None or (isinstance(normalize_factor, float) and math.isnan(normalize_factor)) \
+        else float(normalize_factor)
+    check(L.icnv_normalize_log2(x.ctypes.data_as(ct.c_void_p), out.ctypes.data_as(ct.c_void_p), x.shape[0], x.shape[1],
+                                nf, int(do_norm), int(do_log), ct.byref(used)))
+    return out
+
+
+def normalize_counts_by_seq_depth(infercnv_obj: InfercnvObject, normalize_factor=None) -> InfercnvObject:
+    """R/inferCNV_ops.R:3064-3111 (normalize_factor=NA -> median library size).  No hspike mirror in the reference."""
+    return _with_expr(infercnv_obj, _normalize_log2(infercnv_obj, normalize_factor, True, False))
+
+
+def log2xplus1(infercnv_obj: InfercnvObject) -> InfercnvObject:
+    """R/inferCNV_ops.R:2756-2769."""
+    hs = log2xplus1(infercnv_obj.hspike) if infercnv_obj.hspike is not None else None
+    return _with_expr(infercnv_obj, _normalize_log2(infercnv_obj, None, False, True), hs)
+
+
 # ------------------------------------------------------------------ step 8 / 12
 def subtract_ref_expr_from_obs(infercnv_obj: InfercnvObject, inv_log=False, use_bounds=True) -> InfercnvObject:
     """R/inferCNV_ops.R:1678-1702.  `inv_log=TRUE` (not used by run()) is not

@@ -105,6 +105,39 @@ static double r_median_scratch(double *a, int64_t n) {
 }
 
 /* ------------------------------------------------------------------ */
+/* steps 3-4: normalize_counts_by_seq_depth + log2xplus1               */
+/* (R/inferCNV_ops.R:3064-3111, 2756-2769)                             */
+/* ------------------------------------------------------------------ */
+/* in place; normalize_factor NaN -> median(colSums).  Returns the factor used. */
+double orc_normalize_log2(double *x, int64_t G, int64_t C, double normalize_factor, int32_t do_norm, int32_t do_log) {
+    double factor = normalize_factor;
+    double *cs = (double *)malloc(sizeof(double) * (C > 0 ? C : 1));
+    if (do_norm) {
+        for (int64_t c = 0; c < C; c++) { /* colSums: long double accumulation like R */
+            ld_t s = 0;
+            for (int64_t g = 0; g < G; g++) s += x[g + G * c];
+            cs[c] = (double)s;
+        }
+        if (isnan(factor)) {
+            double *tmp = (double *)malloc(sizeof(double) * C);
+            memcpy(tmp, cs, sizeof(double) * C);
+            factor = r_median_scratch(tmp, C);
+            free(tmp);
+        }
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < C; c++)
+        for (int64_t g = 0; g < G; g++) {
+            double v = x[g + G * c];
+            if (do_norm) v = v / cs[c] * factor;
+            if (do_log) v = log2(v + 1.0);
+            x[g + G * c] = v;
+        }
+    free(cs);
+    return factor;
+}
+
+/* ------------------------------------------------------------------ */
 /* A.1 reference subtraction  (R/inferCNV_ops.R:1678-1786)             */
 /* ------------------------------------------------------------------ */
 /* means[g + G*r] = mean over cells of ref group r (R/inferCNV_ops.R:1708-1735). */

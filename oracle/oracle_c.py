@@ -41,6 +41,8 @@ def lib():
         i64, i32, dbl = ct.c_int64, ct.c_int32, ct.c_double
         L.orc_num_threads.restype = ct.c_int
         L.orc_set_num_threads.argtypes = [ct.c_int]
+        L.orc_normalize_log2.argtypes = [_dp, i64, i64, dbl, i32, i32]
+        L.orc_normalize_log2.restype = dbl
         L.orc_ref_group_means.argtypes = [_dp, i64, i64, _ip, _ip, i32, i32, _dp]
         L.orc_ref_group_means.restype = ct.c_int
         L.orc_subtract_ref.argtypes = [_dp, i64, i64, _dp, i32, i32]
@@ -136,6 +138,15 @@ def fma(a, b, c):
 def pnorm_log_upper(y):
     L = lib()
     return np.array([L.orc_pnorm_log_upper(float(v)) for v in np.ravel(y)]).reshape(np.shape(y))
+
+
+def normalize_log2(expr, normalize_factor=None, do_norm=True, do_log=True):
+    """Steps 3-4 -> (matrix, factor used)."""
+    x = np.array(expr, dtype=np.float64, order="F", copy=True)
+    f = lib().orc_normalize_log2(x.ctypes.data_as(_dp), x.shape[0], x.shape[1],
+                                 float("nan") if normalize_factor is None else float(normalize_factor),
+                                 int(do_norm), int(do_log))
+    return x, f
 
 
 def ref_group_means(expr, ref_groups, inv_log=False):

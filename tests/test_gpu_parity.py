@@ -395,3 +395,77 @@ def test_full_size_properties(dev, C):
     # (5) checksum of checksums is reproducible run to run (deterministic reductions)
     out3, _ = dev.smooth_chain(x, cs, refs)
     assert torch.equal(out3, out)
+
+
+# ------------------------------------------------------------------ ingest (steps 3-4) and the whole replay from counts
+def test_ingest_and_full_replay_from_counts(dev, example):
+    """@count.data -> steps 3,4 (normalise by depth, log2(x+1)) -> chain -> @expr.data, all on the HIP path."""
+    from infercnv_amd import GeneOrder, InfercnvObject, ops
+    counts = example["count_data"].astype(np.float64)
+    levels = example["chr_levels"][example["chr_codes"]]
+    obj = InfercnvObject(expr_data=counts, gene_order=GeneOrder(chr=levels),
+                         reference_grouped_cell_indices={"normal": example["ref_normal"]},
+                         observation_grouped_cell_indices={"tumor": example["obs_tumor"]})
+    o3 = ops.normalize_counts_by_seq_depth(obj)
+    want3 = onp.normalize_counts_by_seq_depth(counts)
+    assert np.abs(o3.expr_data - want3).max() < 1e-9 * np.abs(want3).max()
+    o4 = ops.log2xplus1(o3)
+    assert np.abs(o4.expr_data - example["log"]).max() < 1e-12
+    final = ops.hip_smooth_chain(o4)
+    assert (np.abs(final.expr_data - example["expr_data"]) > 1e-10).mean() < 1e-4
+    # device-resident flavour with an explicit factor
+    xd = to_dev(counts)
+    cs = dev.col_sums(xd).cpu().numpy()
+    assert np.abs(cs - counts.sum(axis=0)).max() < 1e-6
+    y = dev.normalize_log2(xd, normalize_factor=1e5)
+    want, _ = oc.normalize_log2(counts, 1e5)
+    assert np.abs(to_host(y) - want).max() < 1e-12
+
+
+# ------------------------------------------------------------------ BASELINE.json configs 4 and 5 (scaled to one GPU)
+def test_config4_i3_subclusters_properties(dev):
+    """i3 HMM at subcluster level (500-cell subclusters): every member of a subcluster carries the subcluster's
+    trace, and the trace equals the oracle's Viterbi on the GPU's own group means (identical inputs)."""
+    from infercnv_amd import synth
+    G, C = 10000, 20000
+    x, cs = synth.make_matrix_torch(G, C, "cuda")
+    refs, _ = synth.groups(C)
+    out, pre = dev.smooth_chain(x, cs, refs, want_pre_denoise=True)
+    ref_idx = np.concatenate(refs)
+    mu, sigma = dev.cells_mean_sd(pre, ref_idx)
+    delta_m = abs(-1.6448536269514722 * sigma)
+    m3 = np.array([mu - delta_m, mu, mu + delta_m])
+    Pi, dl = onp.get_HMM_i3(1e-6)
+    groups = [np.arange(s, min(s + 500, C), dtype=np.int32) for s in range(0, C, 500)]
+    st, bad = dev.viterbi_groups(pre, cs, groups, m3, [sigma] * len(groups), np.log(Pi), np.log(dl))
+    assert int(bad.item()) == 0
+    gm = dev.group_means(pre, groups)
+    torch.cuda.synchronize()
+    st_h = st.cpu().numpy()
+    for q in (0, 7, len(groups) - 1):
+        want, _ = oc.viterbi_cells(gm[q].cpu().numpy().reshape(-1, 1), cs, m3, sigma, np.log(Pi), np.log(dl))
+        members = groups[q]
+        assert (st_h[members] == want[:, 0][None, :]).all()
+    assert set(np.unique(st_h)) <= {1, 2, 3}
+
+
+def test_config5_median_filter_properties(dev):
+    """2-D median denoise: constants are fixed points; the filter commutes with exact scalings and negation; tiles are
+    independent (filtering a tile alone gives the same values)."""
+    from infercnv_amd import synth
+    G, C = 10000, 1500
+    x, cs = synth.make_matrix_torch(G, C, "cuda")
+    tiles = [np.arange(s, min(s + 500, C), dtype=np.int32) for s in range(0, C, 500)]
+    y = dev.median_filter(x, cs, tiles, 7)
+    assert torch.equal(dev.median_filter(x * 4.0, cs, tiles, 7), y * 4.0)      # power-of-two scaling is exact
+    assert torch.equal(dev.median_filter(-x, cs, tiles, 7), -y)                # order statistics mirror exactly
+    const = torch.full_like(x, 1.25)
+    assert torch.equal(dev.median_filter(const, cs, tiles, 7), const)
+    sub = x[500:1000].contiguous()
+    ysub = dev.median_filter(sub, cs, [np.arange(500, dtype=np.int32)], 7)
+    assert torch.equal(ysub, y[500:1000])
+    # spot parity against the oracle on one chromosome of one tile
+    k = 20                                                       # chr21: 108 genes
+    xs = x[:500, cs[k]:cs[k + 1]].cpu().numpy().T
+    want = oc.median_filter(xs, np.array([0, xs.shape[0]], dtype=np.int32), [np.arange(500, dtype=np.int32)], 7)
+    np.testing.assert_array_equal(y[:500, cs[k]:cs[k + 1]].cpu().numpy().T, want)
