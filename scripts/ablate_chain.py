@@ -14,6 +14,8 @@ masks = [("copy(0x00)", 0x00), ("st8", 0x01), ("st9", 0x02), ("st10 smooth", 0x0
          ("st14 exp2", 0x20), ("st8-10", 0x07), ("st8-11", 0x0F), ("st8-14", 0x3F), ("all", 0x7F)]
 if len(sys.argv) > 2 and sys.argv[2] == "copyonly":
     masks = masks[:1]
+if len(sys.argv) > 2 and sys.argv[2] == "allonly":
+    masks = masks[-1:]
 for name, m in masks:
     plan = device.ChainPlan(G, C, cs, refs, stage_mask=m)
     for r in range(plan.num_rounds):
