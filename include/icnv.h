@@ -179,6 +179,17 @@ int icnv_viterbi_groups_dev(const double *expr, uint8_t *states, int64_t G, int6
 int icnv_group_means_dev(const double *expr, int64_t G, int64_t C, const int32_t *grp_idx,
                          const int32_t *grp_off, int32_t n_grp, double *out, void *stream);
 
+/* .get_state_consensus (R/inferCNV_HMM.R:977-987): per gene the most frequent state among each group's
+ * cells (ties -> smallest state, -1/0xFF first, as table()+order() do).  consensus (nullable): uint8
+ * [g + G*q].  states_out (nullable, may alias states): every member cell receives its group's consensus
+ * -- the overwrite that predict_CNV_via_HMM_on_tumor_subclusters_per_chr (R/inferCNV_HMM.R:473-483) and
+ * get_predicted_CNV_regions (:706-764) are built on (second "next" row). */
+int icnv_state_consensus(const uint8_t *states, int64_t G, int64_t C, const int32_t *grp_idx,
+                         const int32_t *grp_off, int32_t n_grp, uint8_t *consensus, uint8_t *states_out);
+int icnv_state_consensus_dev(const uint8_t *states, int64_t G, int64_t C, const int32_t *grp_idx,
+                             const int32_t *grp_off, int32_t n_grp, uint8_t *consensus,
+                             uint8_t *states_out, void *stream);
+
 /* assign_HMM_states_to_proxy_expr_vals (R/inferCNV_HMM.R:1191-1206; K = 6:
  * {0,0.5,1,1.5,2,3}) and i3HMM_assign_... (R/inferCNV_i3HMM.R:405-417; K = 3:
  * {0.5,1,1.5}).  n = G*C elements. */

@@ -79,6 +79,8 @@ PROTOTYPES = {
     "icnv_viterbi_groups_dev": (ct.c_int, [_vp, _vp, _i64, _i64, _ip, _i32, _ip, _ip, _i32, _i32, _dp, _dp, _dp, _dp,
                                            _vp, _vp]),
     "icnv_group_means_dev": (ct.c_int, [_vp, _i64, _i64, _ip, _ip, _i32, _vp, _vp]),
+    "icnv_state_consensus": (ct.c_int, [_vp, _i64, _i64, _ip, _ip, _i32, _vp, _vp]),
+    "icnv_state_consensus_dev": (ct.c_int, [_vp, _i64, _i64, _ip, _ip, _i32, _vp, _vp, _vp]),
     "icnv_states_to_proxy": (ct.c_int, [_vp, _vp, _i64, _i32]),
     "icnv_states_to_proxy_dev": (ct.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "icnv_cells_mean_sd_dev": (ct.c_int, [_vp, _i64, _i64, _ip, _i64, _dp, _vp]),

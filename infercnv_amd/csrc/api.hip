@@ -681,6 +681,53 @@ int icnv_viterbi_groups(const double *expr, uint8_t *states, int64_t G, int64_t 
     return ICNV_OK;
 }
 
+int icnv_state_consensus_dev(const uint8_t *states, int64_t G, int64_t C, const int32_t *grp_idx,
+                             const int32_t *grp_off, int32_t n_grp, uint8_t *consensus, uint8_t *states_out,
+                             void *stream) {
+    if (!states || G < 1 || C < 0 || G > 0x7fffffff || (!consensus && !states_out)) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    int rc = validate_groups(grp_idx, grp_off, n_grp, C, "groups");
+    if (rc) return rc;
+    if (n_grp > 65535) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "more than 65535 groups");
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf d_idx, d_off, d_cons, d_map;
+    if ((rc = upload(d_idx, grp_idx, n_grp ? (size_t)grp_off[n_grp] : 0, s))) return rc;
+    if ((rc = upload(d_off, grp_off, (size_t)n_grp + 1, s))) return rc;
+    uint8_t *cons = consensus;
+    if (!cons) {
+        if ((rc = d_cons.alloc((size_t)G * std::max(n_grp, 1)))) return rc;
+        cons = d_cons.as<uint8_t>();
+    }
+    if ((rc = launch_state_consensus(states, (int32_t)G, d_idx.as<int32_t>(), d_off.as<int32_t>(), n_grp, cons, s))) return rc;
+    if (states_out) {   // every member cell gets its group's consensus; cells in no group keep their states
+        std::vector<int32_t> cell_to_grp((size_t)std::max<int64_t>(C, 1), -1);
+        for (int q = 0; q < n_grp; ++q)
+            for (int i = grp_off[q]; i < grp_off[q + 1]; ++i) cell_to_grp[grp_idx[i]] = q;
+        if ((rc = upload(d_map, cell_to_grp.data(), (size_t)C, s))) return rc;
+        if (states_out != states)
+            ICNV_HIP(hipMemcpyAsync(states_out, states, (size_t)G * C, hipMemcpyDeviceToDevice, s));
+        if ((rc = launch_broadcast_states_keep(cons, (int32_t)G, C, d_map.as<int32_t>(), states_out, s))) return rc;
+    }
+    return ICNV_OK;
+}
+
+int icnv_state_consensus(const uint8_t *states, int64_t G, int64_t C, const int32_t *grp_idx, const int32_t *grp_off,
+                         int32_t n_grp, uint8_t *consensus, uint8_t *states_out) {
+    if (!states) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
+    DevBuf ds, dc, dout;
+    int rc;
+    const size_t n = (size_t)G * (size_t)C;
+    if ((rc = ds.alloc(std::max<size_t>(n, 1)))) return rc;
+    if (consensus && (rc = dc.alloc((size_t)G * std::max(n_grp, 1)))) return rc;
+    if (states_out && (rc = dout.alloc(std::max<size_t>(n, 1)))) return rc;
+    ICNV_HIP(hipMemcpy(ds.p, states, n, hipMemcpyHostToDevice));
+    rc = icnv_state_consensus_dev(ds.as<uint8_t>(), G, C, grp_idx, grp_off, n_grp, consensus ? dc.as<uint8_t>() : nullptr,
+                                  states_out ? dout.as<uint8_t>() : nullptr, nullptr);
+    if (rc) return rc;
+    if (consensus) ICNV_HIP(hipMemcpy(consensus, dc.p, (size_t)G * n_grp, hipMemcpyDeviceToHost));
+    if (states_out) ICNV_HIP(hipMemcpy(states_out, dout.p, n, hipMemcpyDeviceToHost));
+    return ICNV_OK;
+}
+
 int icnv_states_to_proxy_dev(const uint8_t *states, double *out, int64_t n, int32_t K, void *stream) {
     if (!states || !out || n < 0 || (K != 3 && K != 6)) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
     return launch_states_to_proxy(states, out, n, K, (hipStream_t)stream);

@@ -93,6 +93,10 @@ int launch_group_means_ws(const double *x, int32_t G, const int32_t *grp_idx_dev
                           int32_t n_grp, int nsplit, double *part, double *out, hipStream_t stream);
 int launch_broadcast_states(const uint8_t *grp_states, int32_t G, int64_t C, const int32_t *cell_to_grp_dev,
                             uint8_t *states, hipStream_t stream);
+int launch_state_consensus(const uint8_t *states, int32_t G, const int32_t *grp_idx_dev, const int32_t *grp_off_dev,
+                           int32_t n_grp, uint8_t *out, hipStream_t stream);
+int launch_broadcast_states_keep(const uint8_t *grp_states, int32_t G, int64_t C, const int32_t *cell_to_grp_dev,
+                                 uint8_t *states, hipStream_t stream);
 int launch_states_to_proxy(const uint8_t *states, double *out, int64_t n, int32_t K, hipStream_t stream);
 
 // ---- median filter --------------------------------------------------------

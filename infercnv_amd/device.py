@@ -208,6 +208,20 @@ def group_means(x, groups):
     return out
 
 
+def state_consensus(states, groups, overwrite=False):
+    """.get_state_consensus (R/inferCNV_HMM.R:977-987) per group -> (n_groups, G) uint8; with
+    overwrite=True also returns the state matrix with every member cell set to its group's consensus."""
+    L = _lib.load()
+    C, G = _check_matrix(states, torch.uint8)
+    idx, off = pack_groups(groups)
+    idx, ip = i32(idx)
+    off, op = i32(off)
+    cons = torch.empty((len(groups), G), dtype=torch.uint8, device=states.device)
+    out = torch.empty_like(states) if overwrite else None
+    check(L.icnv_state_consensus_dev(_ptr(states), G, C, ip, op, len(groups), _ptr(cons), _ptr(out), _stream()))
+    return (cons, out) if overwrite else cons
+
+
 def states_to_proxy(states, K):
     """assign_HMM_states_to_proxy_expr_vals (R/inferCNV_HMM.R:1191-1206) / i3 (R/inferCNV_i3HMM.R:405-417)."""
     L = _lib.load()

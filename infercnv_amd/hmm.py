@@ -186,22 +186,22 @@ def predict_CNV_via_HMM_on_tumor_subclusters(infercnv_obj, cnv_mean_sd, cnv_leve
                               cnv_level_to_mean_sd_fit, t)
 
 
-def predict_CNV_via_HMM_on_tumor_subclusters_per_chr(infercnv_obj, cnv_mean_sd, cnv_level_to_mean_sd_fit=None,
-                                                     t=1e-6):
-    """R/inferCNV_HMM.R:412-487: subclusters are defined per chromosome
-    (tumor_subclusters$subclusters[[chr]][[group]][[name]]); one device call per
-    chromosome.  (The reference's region-consensus post-processing :473-483 is
-    report-side and not part of the hot path.)"""
-    if infercnv_obj.tumor_subclusters is None:
+def predict_CNV_via_HMM_on_tumor_subclusters_per_chr(infercnv_obj, subclusters_per_chr, cnv_mean_sd,
+                                                     cnv_level_to_mean_sd_fit=None, t=1e-6):
+    """R/inferCNV_HMM.R:412-487: `subclusters_per_chr[chr]` lists the cell index vectors of the subclusters
+    defined on that chromosome; one device call per chromosome, then (:473-483) every cell of each GLOBAL
+    subcluster (infercnv_obj.tumor_subclusters) receives that subcluster's per-gene consensus state."""
+    if subclusters_per_chr is None:
         return predict_CNV_via_HMM_on_whole_tumor_samples(infercnv_obj, True, cnv_mean_sd, cnv_level_to_mean_sd_fit, t)
+    from .cnv_regions import overwrite_with_consensus
     hmm = _get_HMM(cnv_mean_sd, t)
     chrs = np.asarray(infercnv_obj.gene_order.chr)
     out = np.full(infercnv_obj.expr_data.shape, -1.0)
-    for chr_name, per_chr in infercnv_obj.tumor_subclusters["subclusters"].items():
+    for chr_name, groups in subclusters_per_chr.items():
         rows = np.nonzero(chrs == chr_name)[0]
         if rows.size == 0:
             continue
-        groups = [np.asarray(idx, dtype=np.int32) for grp in per_chr.values() for idx in grp.values()]
+        groups = [np.asarray(g, dtype=np.int32) for g in (groups.values() if isinstance(groups, dict) else groups)]
         x = np.asfortranarray(infercnv_obj.expr_data[rows], dtype=np.float64)
         sd = [_group_sd(len(g), cnv_mean_sd, cnv_level_to_mean_sd_fit) for g in groups]
         st = _viterbi_groups(x, np.array([0, rows.size], dtype=np.int32), groups,
@@ -211,6 +211,8 @@ def predict_CNV_via_HMM_on_tumor_subclusters_per_chr(infercnv_obj, cnv_mean_sd, 
         out[rows] = st
     new = infercnv_obj.copy()
     new.expr_data = out
+    if infercnv_obj.tumor_subclusters is not None:   # get_predicted_CNV_regions(by="subcluster") consensus overwrite
+        new = overwrite_with_consensus(new, _flatten_subclusters(infercnv_obj))
     return new
 
 

@@ -32,6 +32,16 @@ class InfercnvObject:
     tumor_subclusters: Optional[dict] = None                # {"subclusters": {group: {name: idx}}}
     options: dict = field(default_factory=dict)
     hspike: Optional["InfercnvObject"] = None               # R slot `.hspike`
+    gene_names: Optional[np.ndarray] = None                 # rownames(expr.data)
+    cell_names: Optional[np.ndarray] = None                 # colnames(expr.data)
+
+    def genes(self):
+        return self.gene_names if self.gene_names is not None else np.array(
+            [f"gene_{i + 1}" for i in range(self.expr_data.shape[0])])
+
+    def cells(self):
+        return self.cell_names if self.cell_names is not None else np.array(
+            [f"cell_{i + 1}" for i in range(self.expr_data.shape[1])])
 
     # ---- helpers mirroring R/inferCNV.R ------------------------------------
     def has_reference_cells(self) -> bool:

@@ -556,3 +556,45 @@ def apply_median_filtering(expr, chr_codes, tiles, window_size=7):
             t = np.asarray(t, dtype=np.int64)
             out[np.ix_(idx, t)] = median_filter(expr[np.ix_(idx, t)], window_size)
     return out
+
+
+# --------------------------------------------------------------------------
+# CNV region consensus (SURVEY 8f #2)
+# --------------------------------------------------------------------------
+def state_consensus(states, groups):
+    """.get_state_consensus (R/inferCNV_HMM.R:977-987): per gene the most frequent state among a group's
+    cells; table() orders states ascending and order(decreasing=TRUE)[1] keeps the first maximum."""
+    states = np.asarray(states)
+    out = np.zeros((states.shape[0], len(groups)))
+    for gi, g in enumerate(groups):
+        sub = states[:, np.asarray(g, dtype=np.int64)]
+        for r in range(states.shape[0]):
+            vals, cnt = np.unique(sub[r], return_counts=True)      # ascending values
+            out[r, gi] = vals[np.argmax(cnt)]                      # first maximum
+    return out
+
+
+def define_cnv_gene_regions(state_consensus_vec, chrs, counter):
+    """.define_cnv_gene_regions (R/inferCNV_HMM.R:1005-1057) as the plain loop the reference runs:
+    returns [(region name, state, [0-based gene indices])] and the advanced counter."""
+    regions = []
+    seen = []
+    for c in chrs:
+        if c not in seen:
+            seen.append(c)
+    for c in seen:
+        gene_idx = [i for i, cc in enumerate(chrs) if cc == c]
+        if len(gene_idx) < 2:
+            continue
+        prev = state_consensus_vec[gene_idx[0]]
+        counter += 1
+        regions.append(["%s-region_%d" % (c, counter), prev, [gene_idx[0]]])
+        for i in gene_idx[1:]:
+            st = state_consensus_vec[i]
+            if st != prev:
+                counter += 1
+                regions.append(["%s-region_%d" % (c, counter), st, [i]])
+            else:
+                regions[-1][2].append(i)
+            prev = st
+    return regions, counter

@@ -469,3 +469,110 @@ def test_config5_median_filter_properties(dev):
     xs = x[:500, cs[k]:cs[k + 1]].cpu().numpy().T
     want = oc.median_filter(xs, np.array([0, xs.shape[0]], dtype=np.int32), [np.arange(500, dtype=np.int32)], 7)
     np.testing.assert_array_equal(y[:500, cs[k]:cs[k + 1]].cpu().numpy().T, want)
+
+
+# ------------------------------------------------------------------ state consensus + CNV region reports (8f #2)
+def test_state_consensus_bit_exact(dev):
+    rng = np.random.default_rng(21)
+    G, C = 1500, 131
+    st = rng.integers(1, 7, size=(G, C)).astype(np.uint8)
+    st[rng.random((G, C)) < 0.05] = 255                           # the reference's -1 "untouched" entries
+    st[:40, :] = np.where(rng.random((40, C)) < 0.5, 3, 4)        # many exact ties
+    perm = rng.permutation(C)
+    groups = [perm[:1], perm[1:3], perm[3:60], perm[60:124]]      # sizes 1, 2, odd, even; 7 cells in no group
+    want = onp.state_consensus(np.where(st == 255, -1, st).astype(np.float64), groups)
+    d_st = torch.from_numpy(np.ascontiguousarray(st.T)).cuda()
+    cons, over = dev.state_consensus(d_st, groups, overwrite=True)
+    got = cons.cpu().numpy().T.astype(np.float64)
+    got[got == 255] = -1
+    assert np.array_equal(got, want)
+    over = over.cpu().numpy().T
+    for gi, g in enumerate(groups):
+        assert np.array_equal(over[:, g], np.repeat(cons.cpu().numpy()[gi][:, None], len(g), axis=1))
+    rest = perm[124:]
+    assert np.array_equal(over[:, rest], st[:, rest])             # non-member cells keep their states
+
+
+def test_cnv_region_reports_on_reference_states(dev, example, golden_dir, tmp_path):
+    """get_predicted_CNV_regions / generate_cnv_region_reports on the reference's own HMM_states object
+    (data/HMM_states.rda, mirrored in tests/golden/hmm_states_example.npz) against the loop restatement."""
+    from infercnv_amd import cnv_regions
+    from infercnv_amd.infercnv_object import GeneOrder, InfercnvObject
+    hs = np.load(os.path.join(golden_dir, "hmm_states_example.npz"))["HMM_states"].astype(np.float64)
+    chr_names = example["chr_levels"][example["chr_codes"] - example["chr_codes"].min()]
+    obj = InfercnvObject(expr_data=hs, gene_order=GeneOrder(chr_names, example["gene_start"], example["gene_stop"]),
+                         reference_grouped_cell_indices={"normal": example["ref_normal"]},
+                         observation_grouped_cell_indices={"tumor": example["obs_tumor"]},
+                         tumor_subclusters={"subclusters": {"normal": {"normal_s1": example["ref_normal"]},
+                                                            "tumor": {"tumor_s1": example["obs_tumor"][:6],
+                                                                      "tumor_s2": example["obs_tumor"][6:]}}})
+    for by in ("consensus", "subcluster", "cell"):
+        res = cnv_regions.get_predicted_CNV_regions(obj, by)
+        counter = 0
+        assert len(res) == {"consensus": 2, "subcluster": 3, "cell": 20}[by]
+        for entry in res:
+            idx = np.array([int(c.split("_")[1]) - 1 for c in entry["cells"]])
+            cons = onp.state_consensus(hs, [idx])[:, 0]
+            want, counter = onp.define_cnv_gene_regions(cons, list(chr_names), counter)
+            assert [rn for rn, _ in entry["gene_regions"]] == [w[0] for w in want]
+            for (rn, r), w in zip(entry["gene_regions"], want):
+                assert r["state"] == w[1] and r["gene"].tolist() == w[2]
+            for (rn, state, c, s, e), w in zip(entry["cnv_ranges"], want):
+                assert s == example["gene_start"][w[2]].min() and e == example["gene_stop"][w[2]].max()
+    assert res[0]["cell_group_name"] == "cell_%d" % (example["ref_normal"][0] + 1)
+    regions = cnv_regions.generate_cnv_region_reports(obj, "HMM_pred", str(tmp_path), ignore_neutral_state=3,
+                                                      by="subcluster")
+    lines = open(tmp_path / "HMM_pred.pred_cnv_regions.dat").read().splitlines()
+    assert lines[0] == "cell_group_name\tcnv_name\tstate\tchr\tstart\tend"
+    n_non_neutral = sum(1 for x in regions for r in x["cnv_ranges"] if r[1] != 3)
+    assert len(lines) == 1 + n_non_neutral and all(l.split("\t")[2] != "3" for l in lines[1:])
+    assert lines[1].split("\t")[0] in ("normal.normal_s1", "tumor.tumor_s1", "tumor.tumor_s2")
+    genes = open(tmp_path / "HMM_pred.pred_cnv_genes.dat").read().splitlines()
+    assert genes[0] == "cell_group_name\tgene_region_name\tstate\tgene\tchr\tstart\tend"
+    assert len(genes) == 1 + sum(len(r["gene"]) for x in regions for _, r in x["gene_regions"] if r["state"] != 3)
+    assert open(tmp_path / "HMM_pred.cell_groupings").read().splitlines()[0] == "cell_group_name\tcell"
+    used = open(tmp_path / "HMM_pred.genes_used.dat").read().splitlines()
+    assert used[0] == "chr\tstart\tstop" and len(used) == 1 + hs.shape[0]
+    # consensus overwrite (R/inferCNV_HMM.R:473-483): every subcluster becomes constant per gene
+    new = cnv_regions.overwrite_with_consensus(obj, [example["obs_tumor"][:6], example["obs_tumor"][6:]])
+    want = onp.state_consensus(hs, [example["obs_tumor"][:6]])[:, 0]
+    assert np.array_equal(new.expr_data[:, example["obs_tumor"][:6]], np.repeat(want[:, None], 6, axis=1))
+    assert np.array_equal(new.expr_data[:, example["ref_normal"]], hs[:, example["ref_normal"]])
+
+
+def test_per_chr_subcluster_predictor_with_consensus(dev):
+    """predict_CNV_via_HMM_on_tumor_subclusters_per_chr (R/inferCNV_HMM.R:412-487): per-chromosome
+    subclusters, then the global subclusters' consensus overwrite."""
+    from infercnv_amd import hmm, synth
+    from infercnv_amd.infercnv_object import GeneOrder, InfercnvObject
+    rng = np.random.default_rng(5)
+    G, C = 900, 40
+    chrs = np.array(["chr1"] * 400 + ["chr2"] * 300 + ["chr3"] * 200)
+    x = 1.0 + 0.1 * rng.standard_normal((G, C))
+    x[100:250, 20:] += 0.5
+    x[450:600, :10] -= 0.45
+    cms = {k: {"mean": m, "sd": 0.08} for k, m in zip(hmm.CNV_LEVELS, (0.01, 0.5, 1.0, 1.5, 2.0, 3.0))}
+    sub = {"subclusters": {"all": {"s1": np.arange(0, 20), "s2": np.arange(20, 40)}}}
+    per_chr = {"chr1": [np.arange(0, 20), np.arange(20, 40)],
+               "chr2": [np.arange(0, 10), np.arange(10, 25), np.arange(25, 40)],
+               "chr3": [np.arange(0, 40)]}
+    obj = InfercnvObject(expr_data=x, gene_order=GeneOrder(chrs),
+                         observation_grouped_cell_indices={"all": np.arange(C)}, tumor_subclusters=sub)
+    got = hmm.predict_CNV_via_HMM_on_tumor_subclusters_per_chr(obj, per_chr, cms).expr_data
+    # oracle: Viterbi of each (chr, subcluster) mean profile (the GPU's own group means -> identical inputs),
+    # then the per-gene consensus of each global subcluster
+    h = hmm._get_HMM(cms, 1e-6)
+    means, logPi, logDelta = h["state_emission_params"]["mean"], np.log(h["state_transitions"]), np.log(h["delta"])
+    raw = np.full((G, C), -1.0)
+    for c, groups in per_chr.items():
+        rows = np.nonzero(chrs == c)[0]
+        gm = dev.group_means(to_dev(x[rows]), groups).cpu().numpy().T
+        assert np.abs(gm - oc.group_means(np.ascontiguousarray(x[rows]), groups)).max() < 1e-14
+        for q, g in enumerate(groups):
+            st, _ = oc.viterbi_cells(gm[:, q:q + 1], np.array([0, rows.size], dtype=np.int32), means, 0.08, logPi, logDelta)
+            raw[np.ix_(rows, g)] = st.astype(np.float64)
+    want = raw.copy()
+    for g in (np.arange(0, 20), np.arange(20, 40)):
+        want[:, g] = onp.state_consensus(raw, [g])
+    assert np.array_equal(got, want)
+    assert (got[100:250, 20:] == 4).mean() > 0.9 and (got[450:600, :10] == 2).mean() > 0.0

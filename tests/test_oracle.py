@@ -313,3 +313,26 @@ def test_i3_params_c_vs_numpy(example, example_log):
     mu2, sigma2 = oc.mean_sd_of_cells(example_log, example["ref_normal"])
     assert abs(mu - mu2) < 1e-14 and abs(sigma - sigma2) < 1e-14
     assert abs(delta - 1.6448536269514722 * sigma) < 1e-12
+
+
+def test_state_consensus_ties_and_invalid():
+    """.get_state_consensus (R/inferCNV_HMM.R:977-987): table() sorts the states ascending and
+    order(decreasing=TRUE)[1] keeps the first maximum -> ties resolve to the smallest state, -1 first."""
+    st = np.array([[3, 3, 4, 4],        # tie 3/4 -> 3
+                   [-1, 2, 2, -1],      # tie -1/2 -> -1
+                   [6, 6, 6, 1],
+                   [1, 2, 3, 4],        # all tied -> 1
+                   [5, 2, 5, 2]], dtype=np.float64)
+    got = onp.state_consensus(st, [np.arange(4), np.array([2, 3])])
+    assert got[:, 0].tolist() == [3, -1, 6, 1, 2]
+    assert got[:, 1].tolist() == [4, -1, 1, 3, 2]
+
+
+def test_define_cnv_gene_regions_loop():
+    chrs = ["chr1"] * 5 + ["chrX"] + ["chr2"] * 3
+    cons = [3, 3, 4, 4, 3, 6, 2, 2, 2]
+    regions, counter = onp.define_cnv_gene_regions(cons, chrs, 10)
+    assert [(r[0], r[1], r[2]) for r in regions] == [
+        ("chr1-region_11", 3, [0, 1]), ("chr1-region_12", 4, [2, 3]), ("chr1-region_13", 3, [4]),
+        ("chr2-region_14", 2, [6, 7, 8])]          # chrX has a single gene: skipped (:1013)
+    assert counter == 14
