@@ -480,7 +480,9 @@ def test_state_consensus_bit_exact(dev):
     st[:40, :] = np.where(rng.random((40, C)) < 0.5, 3, 4)        # many exact ties
     perm = rng.permutation(C)
     groups = [perm[:1], perm[1:3], perm[3:60], perm[60:124]]      # sizes 1, 2, odd, even; 7 cells in no group
-    want = onp.state_consensus(np.where(st == 255, -1, st).astype(np.float64), groups)
+    sf = st.astype(np.float64)
+    sf[st == 255] = -1.0
+    want = onp.state_consensus(sf, groups)
     d_st = torch.from_numpy(np.ascontiguousarray(st.T)).cuda()
     cons, over = dev.state_consensus(d_st, groups, overwrite=True)
     got = cons.cpu().numpy().T.astype(np.float64)
