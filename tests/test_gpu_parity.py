@@ -217,6 +217,26 @@ def test_viterbi_adversarial_near_ties_bit_exact(dev):
     np.testing.assert_array_equal(to_host(st), want)
 
 
+def test_viterbi_extreme_operands_bit_exact(dev):
+    """Observations / parameters outside the range where the kernel's lean division is proven identical to
+    IEEE division (|x| >= 2^40, subnormals, a zero state mean, a huge sd) take the plain IEEE path."""
+    from infercnv_amd import synth
+    means, sd, logPi, logDelta = synth.hmm_params_i6()
+    rng = np.random.default_rng(17)
+    G, C = 600, 128
+    cs = np.array([0, 250, 600], dtype=np.int32)
+    x = rng.normal(1.0, 0.3, size=(G, C))
+    odd = rng.random((G, C)) < 0.03
+    x[odd] = rng.choice([2.0 ** 40, -2.0 ** 40, 1e13, 1e150, -1e200, 1e-310, -4e-320, 0.0, 1e300], size=int(odd.sum()))
+    t = 1e-2                                   # a soft transition matrix keeps the scores finite longer
+    Pi, delta = onp.get_HMM_i6(t)
+    for mm, s_ in ((means, sd), (np.array([0.0, 0.5, 1.0, 1.5, 2.0, 3.0]), sd), (means, 2.0 ** 45), (means, 2.0 ** -41)):
+        st, bad = dev.viterbi_cells(to_dev(x), cs, mm, s_, np.log(Pi), np.log(delta))
+        want, wbad = oc.viterbi_cells(x, cs, mm, s_, np.log(Pi), np.log(delta))
+        np.testing.assert_array_equal(to_host(st), want)
+        assert int(bad.item()) == wbad
+
+
 def test_viterbi_i3_bit_exact(dev):
     pre, cs = _hmm_input(3000, 100, seed=3)
     refs = np.arange(10, dtype=np.int32)
