@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include "icnv_internal.h"
+#include <algorithm>
 
 namespace icnv {
 
@@ -192,21 +193,63 @@ int launch_normalize_log2(const double *in, double *out, int32_t G, int64_t C, c
 
 int chain_max_genes() { return 512 * 37; }
 
+// Geometry of the LDS-resident cell vector: threads x chunk length, chosen by the padded position count.
+// 768 threads = 3 wavefronts per SIMD = 168 VGPRs per lane: measured fastest (no spills, 12 waves).
+struct ChainGeom { int nt, lmax, pad; };
+static bool chain_geom(int64_t G, int n_chr, int T, ChainGeom &g) {
+    g.pad = T >= 1 ? ((T + 3) & ~1) : 0;  // even(T+2)
+    // padded positions: genes + PAD zeros before every chromosome and after the last
+    const int64_t npos = G + (int64_t)(n_chr + 1) * g.pad;
+    if (npos <= 768 * 7) { g.nt = 768; g.lmax = 7; return true; }
+    if (npos <= 768 * 15) { g.nt = 768; g.lmax = 15; return true; }
+    if (npos <= 768 * 23) { g.nt = 768; g.lmax = 23; return true; }
+    if (npos <= 512 * 37) { g.nt = 512; g.lmax = 37; return true; }
+    return false;
+}
+
+int chain_build_inv_table(const int32_t *chr_start, int32_t n_chr, int32_t G, int32_t T, std::vector<double> &tab) {
+    ChainGeom g;
+    tab.clear();
+    if (T < 1) return ICNV_OK;
+    if (!chain_geom(G, n_chr, T, g))
+        ICNV_FAIL(ICNV_ERR_UNSUPPORTED,
+                  "fused smoothing chain: genes + (n_chr+1)*(window/2+2) padding exceed the LDS-resident limit of 18944");
+    tab.assign((size_t)g.nt * (g.lmax + 1), 0.0);
+    const int64_t full = (int64_t)(T + 1) * (T + 1);
+    for (int k = 0; k < n_chr; ++k) {
+        const int n = chr_start[k + 1] - chr_start[k];
+        const int64_t base = (int64_t)chr_start[k] + (int64_t)(k + 1) * g.pad;
+        for (int i = 0; i < n; ++i) {
+            double inv;
+            if (n <= 1) {
+                inv = 1.0 / (double)(T + 1);  // single-gene chromosome: untouched (R/inferCNV_ops.R:2417); A = (T+1) x
+            } else {
+                const int64_t rl = std::max(T - i, 0), rr = std::max(T - (n - 1 - i), 0);
+                inv = 1.0 / (double)(full - rl * (rl + 1) / 2 - rr * (rr + 1) / 2);
+            }
+            const int64_t p = base + i;
+            const int64_t t = p / g.lmax, q = p % g.lmax;
+            tab[(size_t)(((q >> 1) * g.nt + t) * 2 + (q & 1))] = inv;
+        }
+    }
+    return ICNV_OK;
+}
+
 int launch_chain(const ChainArgs &a0, int mode, hipStream_t stream) {
     ChainArgs a = a0;
     if (a.n_chr > 510) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "more than 510 chromosomes/contigs");
     const bool smooth = (a.mask & ICNV_ST_SMOOTH) && a.T >= 1;
     if (!smooth) a.T = 0;
-    a.pad = smooth ? ((a.T + 3) & ~1) : 0;  // even(T+2)
-    // padded positions: genes + PAD zeros before every chromosome and after the last
-    const int64_t npos = (int64_t)a.G + (int64_t)(a.n_chr + 1) * a.pad;
-    // 768 threads = 3 wavefronts per SIMD = 168 VGPRs per lane: measured fastest (no spills, 12 waves)
-    if (npos <= 768 * 7) return launch_chain_m7(a, mode, stream);
-    if (npos <= 768 * 15) return launch_chain_m15(a, mode, stream);
-    if (npos <= 768 * 23) return launch_chain_m23(a, mode, stream);
-    if (npos <= 512 * 37) return launch_chain_l37(a, mode, stream);
-    ICNV_FAIL(ICNV_ERR_UNSUPPORTED,
-              "fused smoothing chain: genes + (n_chr+1)*(window/2+2) padding exceed the LDS-resident limit of 18944");
+    ChainGeom g;
+    if (!chain_geom(a.G, a.n_chr, a.T, g))
+        ICNV_FAIL(ICNV_ERR_UNSUPPORTED,
+                  "fused smoothing chain: genes + (n_chr+1)*(window/2+2) padding exceed the LDS-resident limit of 18944");
+    if (smooth && !a.inv_pos) ICNV_FAIL(ICNV_ERR_ARG, "smoothing launch without its normalisation table");
+    a.pad = g.pad;
+    if (g.lmax == 7) return launch_chain_m7(a, mode, stream);
+    if (g.lmax == 15) return launch_chain_m15(a, mode, stream);
+    if (g.lmax == 23) return launch_chain_m23(a, mode, stream);
+    return launch_chain_l37(a, mode, stream);
 }
 
 int launch_reduce_partials(const double *partial, int nblk, int32_t G, double *out, double count,

@@ -1,6 +1,7 @@
 // Internal declarations shared by the HIP translation units of libicnv_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <stdint.h>
 
 #include <string>
@@ -56,12 +57,16 @@ struct ChainArgs {
     const double *b1;       // [2*G] lo | hi  (step 8)
     const double *b2;       // [2*G] lo | hi  (step 12)
     const double *denoise;  // [2] mu, s
+    const double *inv_pos;  // smoothing: 1/denominator per padded LDS position (chain_build_inv_table)
     double *partial;        // MODE_GENE_SUMS: [gridDim.x * G]
     double *cell_stats;     // MODE_CELL_STATS: [n_cells * 2] {sum, sd}
 };
 
 int launch_chain(const ChainArgs &a, int mode, hipStream_t stream);
 int chain_max_genes();
+// Host: per-position normalisation table of the smoothing stage for this geometry, in the kernel's
+// [(LMAX+1)/2][NT] double2 layout (R/inferCNV_ops.R:2410-2440: pyramid weights renormalised at chromosome edges).
+int chain_build_inv_table(const int32_t *chr_start, int32_t n_chr, int32_t G, int32_t T, std::vector<double> &tab);
 int launch_reduce_partials(const double *partial, int nblk, int32_t G, double *out, double count,
                            double *count_out, hipStream_t stream);
 int launch_bounds_from_sums(const double *sums_counts, int32_t G, int32_t n_grp, int32_t use_bounds,
