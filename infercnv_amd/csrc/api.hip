@@ -181,8 +181,10 @@ struct icnv_chain {
     std::vector<int> round_stage;  // ICNV_ST_* bit of each reference round
     int T = 0;
     uint32_t mask = 0;
-    DevBuf d_chr, d_ref, d_b1, d_b2, d_den, d_partial, d_sums, d_cellstats, d_stats, d_inv;
-    std::vector<double> inv_tab;   // host copy of the smoothing normalisation table (kept alive for the async upload)
+    DevBuf d_chr, d_ref, d_b1, d_b2, d_den, d_partial, d_sums, d_cellstats, d_stats, d_inv, d_inv_codes, d_inv_dict;
+    std::vector<double> inv_tab, inv_dict;
+    std::vector<uint32_t> inv_codes;
+    bool inv_coded = false;   // host copy of the smoothing normalisation table (kept alive for the async upload)
     bool uploaded = false;
 };
 
@@ -298,8 +300,12 @@ static int chain_upload(icnv_chain *ch, hipStream_t s) {
     if ((rc = ch->d_cellstats.alloc(std::max<size_t>(ch->ref_idx.size(), 1) * 2 * sizeof(double)))) return rc;
     if ((rc = ch->d_stats.alloc(4 * sizeof(double)))) return rc;
     if (ch->T >= 1) {
-        if ((rc = chain_build_inv_table(ch->chr_start.data(), ch->cfg.n_chr, (int32_t)G, ch->T, ch->inv_tab))) return rc;
+        if ((rc = chain_build_inv_table(ch->chr_start.data(), ch->cfg.n_chr, (int32_t)G, ch->T, ch->inv_tab, ch->inv_codes,
+                                        ch->inv_dict, ch->inv_coded)))
+            return rc;
         if ((rc = upload(ch->d_inv, ch->inv_tab.data(), ch->inv_tab.size(), s))) return rc;
+        if ((rc = upload(ch->d_inv_codes, ch->inv_codes.data(), ch->inv_codes.size(), s))) return rc;
+        if ((rc = upload(ch->d_inv_dict, ch->inv_dict.data(), ch->inv_dict.size(), s))) return rc;
     }
     ch->uploaded = true;
     return ICNV_OK;
@@ -319,6 +325,9 @@ static ChainArgs chain_args(icnv_chain *ch, const double *in) {
     a.b2 = ch->d_b2.as<double>();
     a.denoise = ch->d_den.as<double>();
     a.inv_pos = ch->T >= 1 ? ch->d_inv.as<double>() : nullptr;
+    a.inv_codes = ch->T >= 1 ? ch->d_inv_codes.as<uint32_t>() : nullptr;
+    a.inv_dict = ch->T >= 1 ? ch->d_inv_dict.as<double>() : nullptr;
+    a.inv_coded = ch->inv_coded ? 1 : 0;
     a.partial = ch->d_partial.as<double>();
     a.cell_stats = ch->d_cellstats.as<double>();
     return a;

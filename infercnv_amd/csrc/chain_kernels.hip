@@ -24,6 +24,7 @@
 
 #include "icnv_internal.h"
 #include <algorithm>
+#include <map>
 
 namespace icnv {
 
@@ -32,6 +33,7 @@ int launch_chain_m7(const ChainArgs &a, int mode, hipStream_t stream);    // 768
 int launch_chain_m15(const ChainArgs &a, int mode, hipStream_t stream);   // 768 threads,  <= 11520
 int launch_chain_m23(const ChainArgs &a, int mode, hipStream_t stream);   // 768 threads,  <= 17664
 int launch_chain_l37(const ChainArgs &a, int mode, hipStream_t stream);   // 512 threads,  <= 18944
+int launch_chain_l23(const ChainArgs &a, int mode, hipStream_t stream);   // 512 threads,  <= 11776 (experiment)
 
 namespace {
 
@@ -201,15 +203,20 @@ static bool chain_geom(int64_t G, int n_chr, int T, ChainGeom &g) {
     // padded positions: genes + PAD zeros before every chromosome and after the last
     const int64_t npos = G + (int64_t)(n_chr + 1) * g.pad;
     if (npos <= 768 * 7) { g.nt = 768; g.lmax = 7; return true; }
+    if (getenv("ICNV_CHAIN_512") && npos > 768 * 7 && npos <= 512 * 23) { g.nt = 512; g.lmax = 23; return true; }
     if (npos <= 768 * 15) { g.nt = 768; g.lmax = 15; return true; }
     if (npos <= 768 * 23) { g.nt = 768; g.lmax = 23; return true; }
     if (npos <= 512 * 37) { g.nt = 512; g.lmax = 37; return true; }
     return false;
 }
 
-int chain_build_inv_table(const int32_t *chr_start, int32_t n_chr, int32_t G, int32_t T, std::vector<double> &tab) {
+int chain_build_inv_table(const int32_t *chr_start, int32_t n_chr, int32_t G, int32_t T, std::vector<double> &tab,
+                          std::vector<uint32_t> &codes, std::vector<double> &dict, bool &coded) {
     ChainGeom g;
+    coded = true;
     tab.clear();
+    codes.clear();
+    dict.clear();
     if (T < 1) return ICNV_OK;
     if (!chain_geom(G, n_chr, T, g))
         ICNV_FAIL(ICNV_ERR_UNSUPPORTED,
@@ -232,6 +239,30 @@ int chain_build_inv_table(const int32_t *chr_start, int32_t n_chr, int32_t G, in
             tab[(size_t)(((q >> 1) * g.nt + t) * 2 + (q & 1))] = inv;
         }
     }
+    // byte-coded form: dictionary of the distinct values (entry 0 = padding), one code per position.  Plans
+    // with more than 254 distinct values (many very short contigs of different lengths) are not coded.
+    dict.assign(256, 0.0);
+    codes.assign((size_t)g.nt * ((g.lmax + 3) / 4), 0u);
+    std::map<double, int64_t> freq;
+    for (double v : tab)
+        if (v != 0.0) ++freq[v];
+    std::vector<std::pair<int64_t, double>> order;
+    for (auto &kv : freq) order.emplace_back(-kv.second, kv.first);
+    std::sort(order.begin(), order.end());
+    std::map<double, uint32_t> code_of;
+    for (size_t i = 0; i < order.size() && i < 254; ++i) {
+        code_of[order[i].second] = (uint32_t)i + 1;
+        dict[i + 1] = order[i].second;
+    }
+    for (int64_t p = 0; p < (int64_t)g.nt * g.lmax; ++p) {
+        const int64_t t = p / g.lmax, q = p % g.lmax;
+        const double inv = tab[(size_t)(((q >> 1) * g.nt + t) * 2 + (q & 1))];
+        if (inv == 0.0) continue;
+        auto it = code_of.find(inv);
+        if (it == code_of.end()) { coded = false; continue; }
+        const uint32_t code = it->second;
+        codes[(size_t)((q >> 2) * g.nt + t)] |= code << (8 * (q & 3));
+    }
     return ICNV_OK;
 }
 
@@ -244,10 +275,11 @@ int launch_chain(const ChainArgs &a0, int mode, hipStream_t stream) {
     if (!chain_geom(a.G, a.n_chr, a.T, g))
         ICNV_FAIL(ICNV_ERR_UNSUPPORTED,
                   "fused smoothing chain: genes + (n_chr+1)*(window/2+2) padding exceed the LDS-resident limit of 18944");
-    if (smooth && !a.inv_pos) ICNV_FAIL(ICNV_ERR_ARG, "smoothing launch without its normalisation table");
+    if (smooth && !(a.inv_pos && a.inv_codes && a.inv_dict)) ICNV_FAIL(ICNV_ERR_ARG, "smoothing launch without its normalisation table");
     a.pad = g.pad;
     if (g.lmax == 7) return launch_chain_m7(a, mode, stream);
     if (g.lmax == 15) return launch_chain_m15(a, mode, stream);
+    if (g.lmax == 23 && g.nt == 512) return launch_chain_l23(a, mode, stream);
     if (g.lmax == 23) return launch_chain_m23(a, mode, stream);
     return launch_chain_l37(a, mode, stream);
 }

@@ -58,6 +58,9 @@ struct ChainArgs {
     const double *b2;       // [2*G] lo | hi  (step 12)
     const double *denoise;  // [2] mu, s
     const double *inv_pos;  // smoothing: 1/denominator per padded LDS position (chain_build_inv_table)
+    const uint32_t *inv_codes;  // one byte per position: index into inv_dict; [(LMAX+3)/4][NT]
+    int32_t inv_coded;          // 1: every distinct value has a code (else the generic kernels read inv_pos)
+    const double *inv_dict;     // [256] distinct 1/denominator values, entry 0 = 0.0 (padding)
     double *partial;        // MODE_GENE_SUMS: [gridDim.x * G]
     double *cell_stats;     // MODE_CELL_STATS: [n_cells * 2] {sum, sd}
 };
@@ -66,7 +69,8 @@ int launch_chain(const ChainArgs &a, int mode, hipStream_t stream);
 int chain_max_genes();
 // Host: per-position normalisation table of the smoothing stage for this geometry, in the kernel's
 // [(LMAX+1)/2][NT] double2 layout (R/inferCNV_ops.R:2410-2440: pyramid weights renormalised at chromosome edges).
-int chain_build_inv_table(const int32_t *chr_start, int32_t n_chr, int32_t G, int32_t T, std::vector<double> &tab);
+int chain_build_inv_table(const int32_t *chr_start, int32_t n_chr, int32_t G, int32_t T, std::vector<double> &tab,
+                          std::vector<uint32_t> &codes, std::vector<double> &dict, bool &coded);
 int launch_reduce_partials(const double *partial, int nblk, int32_t G, double *out, double count,
                            double *count_out, hipStream_t stream);
 int launch_bounds_from_sums(const double *sums_counts, int32_t G, int32_t n_grp, int32_t use_bounds,
