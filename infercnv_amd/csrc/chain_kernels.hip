@@ -275,6 +275,8 @@ int launch_chain(const ChainArgs &a0, int mode, hipStream_t stream) {
     if (!chain_geom(a.G, a.n_chr, a.T, g))
         ICNV_FAIL(ICNV_ERR_UNSUPPORTED,
                   "fused smoothing chain: genes + (n_chr+1)*(window/2+2) padding exceed the LDS-resident limit of 18944");
+    if (smooth && a.T / g.lmax > 64)   // CS_GUARD of chain_kernel.inc
+        ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "smoothing window too long for the fused chain kernel (half window / chunk length > 64)");
     if (smooth && !(a.inv_pos && a.inv_codes && a.inv_dict)) ICNV_FAIL(ICNV_ERR_ARG, "smoothing launch without its normalisation table");
     a.pad = g.pad;
     if (g.lmax == 7) return launch_chain_m7(a, mode, stream);
