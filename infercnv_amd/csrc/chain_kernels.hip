@@ -32,8 +32,7 @@ namespace icnv {
 int launch_chain_m7(const ChainArgs &a, int mode, hipStream_t stream);    // 768 threads,  <=  5376 positions
 int launch_chain_m15(const ChainArgs &a, int mode, hipStream_t stream);   // 768 threads,  <= 11520
 int launch_chain_m23(const ChainArgs &a, int mode, hipStream_t stream);   // 768 threads,  <= 17664
-int launch_chain_l37(const ChainArgs &a, int mode, hipStream_t stream);   // 512 threads,  <= 18944
-int launch_chain_l23(const ChainArgs &a, int mode, hipStream_t stream);   // 512 threads,  <= 11776 (experiment)
+int launch_chain_l35(const ChainArgs &a, int mode, hipStream_t stream);   // 512 threads,  <= 17920
 
 namespace {
 
@@ -193,7 +192,7 @@ int launch_normalize_log2(const double *in, double *out, int32_t G, int64_t C, c
     return ICNV_OK;
 }
 
-int chain_max_genes() { return 512 * 37; }
+int chain_max_genes() { return 512 * 35; }
 
 // Geometry of the LDS-resident cell vector: threads x chunk length, chosen by the padded position count.
 // 768 threads = 3 wavefronts per SIMD = 168 VGPRs per lane: measured fastest (no spills, 12 waves).
@@ -203,10 +202,9 @@ static bool chain_geom(int64_t G, int n_chr, int T, ChainGeom &g) {
     // padded positions: genes + PAD zeros before every chromosome and after the last
     const int64_t npos = G + (int64_t)(n_chr + 1) * g.pad;
     if (npos <= 768 * 7) { g.nt = 768; g.lmax = 7; return true; }
-    if (getenv("ICNV_CHAIN_512") && npos > 768 * 7 && npos <= 512 * 23) { g.nt = 512; g.lmax = 23; return true; }
     if (npos <= 768 * 15) { g.nt = 768; g.lmax = 15; return true; }
     if (npos <= 768 * 23) { g.nt = 768; g.lmax = 23; return true; }
-    if (npos <= 512 * 37) { g.nt = 512; g.lmax = 37; return true; }
+    if (npos <= 512 * 35) { g.nt = 512; g.lmax = 35; return true; }
     return false;
 }
 
@@ -220,7 +218,7 @@ int chain_build_inv_table(const int32_t *chr_start, int32_t n_chr, int32_t G, in
     if (T < 1) return ICNV_OK;
     if (!chain_geom(G, n_chr, T, g))
         ICNV_FAIL(ICNV_ERR_UNSUPPORTED,
-                  "fused smoothing chain: genes + (n_chr+1)*(window/2+2) padding exceed the LDS-resident limit of 18944");
+                  "fused smoothing chain: genes + (n_chr+1)*(window/2+2) padding exceed the LDS-resident limit of 17920 positions");
     tab.assign((size_t)g.nt * (g.lmax + 1), 0.0);
     const int64_t full = (int64_t)(T + 1) * (T + 1);
     for (int k = 0; k < n_chr; ++k) {
@@ -274,16 +272,15 @@ int launch_chain(const ChainArgs &a0, int mode, hipStream_t stream) {
     ChainGeom g;
     if (!chain_geom(a.G, a.n_chr, a.T, g))
         ICNV_FAIL(ICNV_ERR_UNSUPPORTED,
-                  "fused smoothing chain: genes + (n_chr+1)*(window/2+2) padding exceed the LDS-resident limit of 18944");
+                  "fused smoothing chain: genes + (n_chr+1)*(window/2+2) padding exceed the LDS-resident limit of 17920 positions");
     if (smooth && a.T / g.lmax > 64)   // CS_GUARD of chain_kernel.inc
         ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "smoothing window too long for the fused chain kernel (half window / chunk length > 64)");
     if (smooth && !(a.inv_pos && a.inv_codes && a.inv_dict)) ICNV_FAIL(ICNV_ERR_ARG, "smoothing launch without its normalisation table");
     a.pad = g.pad;
     if (g.lmax == 7) return launch_chain_m7(a, mode, stream);
     if (g.lmax == 15) return launch_chain_m15(a, mode, stream);
-    if (g.lmax == 23 && g.nt == 512) return launch_chain_l23(a, mode, stream);
     if (g.lmax == 23) return launch_chain_m23(a, mode, stream);
-    return launch_chain_l37(a, mode, stream);
+    return launch_chain_l35(a, mode, stream);
 }
 
 int launch_reduce_partials(const double *partial, int nblk, int32_t G, double *out, double count,

@@ -72,7 +72,9 @@ def test_chain_reproduces_reference_golden_object(dev, example):
     assert np.abs(to_host(pre) - ref_pre).max() < 1e-12
 
 
-@pytest.mark.parametrize("G,C,nref", [(10000, 160, 2), (4613, 70, 1), (9999, 67, 3), (301, 33, 2), (37, 9, 1)])
+# the gene counts exercise every kernel geometry: 768 x 7 / 15 / 23 and 512 x 37 positions, even and odd G
+@pytest.mark.parametrize("G,C,nref", [(10000, 160, 2), (4613, 70, 1), (9999, 67, 3), (301, 33, 2), (37, 9, 1),
+                                      (3000, 40, 2), (15000, 48, 2), (14999, 21, 1), (16600, 36, 2), (16501, 19, 1)])
 def test_chain_fused_vs_oracle(dev, G, C, nref):
     from infercnv_amd import synth
     x, cs = synth.make_matrix_np(G, C)
