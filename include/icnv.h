@@ -179,6 +179,26 @@ int icnv_viterbi_groups_dev(const double *expr, uint8_t *states, int64_t G, int6
 int icnv_group_means_dev(const double *expr, int64_t G, int64_t C, const int32_t *grp_idx,
                          const int32_t *grp_off, int32_t n_grp, double *out, void *stream);
 
+/* Gene filters of the ingest (first "next" row).  icnv_gene_stats: per gene the sum over all cells
+ * and the number of cells with expr > 0 -- what require_above_min_mean_expr_cutoff (rowMeans(expr) < cutoff,
+ * R/inferCNV_ops.R:2128-2163) and require_above_min_cells_ref (sum(x > 0 & !is.na(x)) >= min_cells, :2182-2213)
+ * decide on; a cell-sharded caller all-reduces both vectors.  icnv_select_genes: remove_genes on the matrix,
+ * expr_out[j + G_out*c] = expr_in[keep_idx[j] + G_in*c] (0-based, any order). */
+int icnv_gene_stats(const double *expr, int64_t G, int64_t C, double *gene_sums, int32_t *gene_nnz);
+int icnv_gene_stats_dev(const double *expr, int64_t G, int64_t C, double *gene_sums, int32_t *gene_nnz, void *stream);
+int icnv_select_genes(const double *expr_in, int64_t G_in, int64_t C, const int32_t *keep_idx, int64_t G_out,
+                      double *expr_out);
+int icnv_select_genes_dev(const double *expr_in, int64_t G_in, int64_t C, const int32_t *keep_idx, int64_t G_out,
+                          double *expr_out, void *stream);
+
+/* mean() and sd() over the block expr[gene_idx, cell_idx] (gene_idx NULL = all genes): the per-CNV-level emission
+ * statistics of get_spike_dists (R/inferCNV_HMM.R:15-99; SURVEY.md 8f, third "next" row).  out2 = {mean, sd} on the
+ * host; index lists are host arrays, 0-based. */
+int icnv_block_mean_sd(const double *expr, int64_t G, int64_t C, const int32_t *gene_idx, int64_t n_genes,
+                       const int32_t *cell_idx, int64_t n_cells, double *out2);
+int icnv_block_mean_sd_dev(const double *expr, int64_t G, int64_t C, const int32_t *gene_idx, int64_t n_genes,
+                           const int32_t *cell_idx, int64_t n_cells, double *out2_host, void *stream);
+
 /* .get_state_consensus (R/inferCNV_HMM.R:977-987): per gene the most frequent state among each group's
  * cells (ties -> smallest state, -1/0xFF first, as table()+order() do).  consensus (nullable): uint8
  * [g + G*q].  states_out (nullable, may alias states): every member cell receives its group's consensus

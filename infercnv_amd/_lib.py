@@ -79,6 +79,12 @@ PROTOTYPES = {
     "icnv_viterbi_groups_dev": (ct.c_int, [_vp, _vp, _i64, _i64, _ip, _i32, _ip, _ip, _i32, _i32, _dp, _dp, _dp, _dp,
                                            _vp, _vp]),
     "icnv_group_means_dev": (ct.c_int, [_vp, _i64, _i64, _ip, _ip, _i32, _vp, _vp]),
+    "icnv_gene_stats": (ct.c_int, [_vp, _i64, _i64, _vp, _vp]),
+    "icnv_gene_stats_dev": (ct.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "icnv_select_genes": (ct.c_int, [_vp, _i64, _i64, _ip, _i64, _vp]),
+    "icnv_select_genes_dev": (ct.c_int, [_vp, _i64, _i64, _ip, _i64, _vp, _vp]),
+    "icnv_block_mean_sd": (ct.c_int, [_vp, _i64, _i64, _ip, _i64, _ip, _i64, _dp]),
+    "icnv_block_mean_sd_dev": (ct.c_int, [_vp, _i64, _i64, _ip, _i64, _ip, _i64, _dp, _vp]),
     "icnv_state_consensus": (ct.c_int, [_vp, _i64, _i64, _ip, _ip, _i32, _vp, _vp]),
     "icnv_state_consensus_dev": (ct.c_int, [_vp, _i64, _i64, _ip, _ip, _i32, _vp, _vp, _vp]),
     "icnv_states_to_proxy": (ct.c_int, [_vp, _vp, _i64, _i32]),

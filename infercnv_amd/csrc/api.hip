@@ -546,6 +546,113 @@ int icnv_normalize_log2(const double *expr_in, double *expr_out, int64_t G, int6
     return ICNV_OK;
 }
 
+// ------------------------------------------------------------------ gene filters / block statistics
+int icnv_gene_stats_dev(const double *expr, int64_t G, int64_t C, double *gene_sums, int32_t *gene_nnz, void *stream) {
+    if (!expr || !gene_sums || !gene_nnz || G < 1 || C < 0 || G > 0x7fffffff) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 0) {
+        ICNV_HIP(hipMemsetAsync(gene_sums, 0, (size_t)G * sizeof(double), s));
+        ICNV_HIP(hipMemsetAsync(gene_nnz, 0, (size_t)G * sizeof(int32_t), s));
+        return ICNV_OK;
+    }
+    const int ns = gene_stats_nsplit((int32_t)G, C);
+    DevBuf ps, pn;
+    int rc;
+    if ((rc = ps.alloc((size_t)ns * G * sizeof(double))) || (rc = pn.alloc((size_t)ns * G * sizeof(int32_t)))) return rc;
+    if ((rc = launch_gene_stats(expr, (int32_t)G, C, ns, ps.as<double>(), pn.as<int32_t>(), gene_sums, gene_nnz, s))) return rc;
+    ICNV_HIP(hipStreamSynchronize(s));   // the partial buffers go back to the pool
+    return ICNV_OK;
+}
+
+int icnv_gene_stats(const double *expr, int64_t G, int64_t C, double *gene_sums, int32_t *gene_nnz) {
+    if (!expr || !gene_sums || !gene_nnz || G < 1 || C < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    DevBuf din, ds, dn;
+    int rc;
+    const size_t bytes = (size_t)G * (size_t)C * sizeof(double);
+    if ((rc = din.alloc(bytes)) || (rc = ds.alloc((size_t)G * sizeof(double))) || (rc = dn.alloc((size_t)G * sizeof(int32_t))))
+        return rc;
+    ICNV_HIP(hipMemcpy(din.p, expr, bytes, hipMemcpyHostToDevice));
+    if ((rc = icnv_gene_stats_dev(din.as<double>(), G, C, ds.as<double>(), dn.as<int32_t>(), nullptr))) return rc;
+    ICNV_HIP(hipMemcpy(gene_sums, ds.p, (size_t)G * sizeof(double), hipMemcpyDeviceToHost));
+    ICNV_HIP(hipMemcpy(gene_nnz, dn.p, (size_t)G * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return ICNV_OK;
+}
+
+static int validate_index_list(const int32_t *idx, int64_t n, int64_t limit, const char *what) {
+    if (n < 0 || (n > 0 && !idx)) ICNV_FAIL(ICNV_ERR_ARG, std::string("bad ") + what);
+    for (int64_t i = 0; i < n; ++i)
+        if (idx[i] < 0 || idx[i] >= limit) ICNV_FAIL(ICNV_ERR_ARG, std::string(what) + " index out of range");
+    return ICNV_OK;
+}
+
+int icnv_select_genes_dev(const double *expr_in, int64_t G_in, int64_t C, const int32_t *keep_idx, int64_t G_out,
+                          double *expr_out, void *stream) {
+    if (!expr_in || !expr_out || G_in < 1 || C < 0 || G_out < 0 || G_in > 0x7fffffff) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    int rc = validate_index_list(keep_idx, G_out, G_in, "gene");
+    if (rc) return rc;
+    if (G_out == 0 || C == 0) return ICNV_OK;
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf dk;
+    if ((rc = upload(dk, keep_idx, (size_t)G_out, s))) return rc;
+    if ((rc = launch_select_genes(expr_in, (int32_t)G_in, C, dk.as<int32_t>(), (int32_t)G_out, expr_out, s))) return rc;
+    ICNV_HIP(hipStreamSynchronize(s));
+    return ICNV_OK;
+}
+
+int icnv_select_genes(const double *expr_in, int64_t G_in, int64_t C, const int32_t *keep_idx, int64_t G_out,
+                      double *expr_out) {
+    if (!expr_in || !expr_out || G_in < 1 || C < 1 || G_out < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    DevBuf din, dout;
+    int rc;
+    if ((rc = din.alloc((size_t)G_in * C * sizeof(double))) || (rc = dout.alloc((size_t)G_out * C * sizeof(double)))) return rc;
+    ICNV_HIP(hipMemcpy(din.p, expr_in, (size_t)G_in * C * sizeof(double), hipMemcpyHostToDevice));
+    if ((rc = icnv_select_genes_dev(din.as<double>(), G_in, C, keep_idx, G_out, dout.as<double>(), nullptr))) return rc;
+    ICNV_HIP(hipMemcpy(expr_out, dout.p, (size_t)G_out * C * sizeof(double), hipMemcpyDeviceToHost));
+    return ICNV_OK;
+}
+
+int icnv_block_mean_sd_dev(const double *expr, int64_t G, int64_t C, const int32_t *gene_idx, int64_t n_genes,
+                           const int32_t *cell_idx, int64_t n_cells, double *out2_host, void *stream) {
+    if (!expr || !out2_host || G < 1 || G > 0x7fffffff || n_cells < 1 || n_cells > 0x7fffffff || !cell_idx)
+        ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    if (!gene_idx) n_genes = G;   // all genes
+    if (n_genes < 1) ICNV_FAIL(ICNV_ERR_ARG, "empty gene list");
+    int rc = validate_index_list(cell_idx, n_cells, C, "cell");
+    if (rc) return rc;
+    if (gene_idx && (rc = validate_index_list(gene_idx, n_genes, G, "gene"))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf dg, dc, dp;
+    if (gene_idx && (rc = upload(dg, gene_idx, (size_t)n_genes, s))) return rc;
+    if ((rc = upload(dc, cell_idx, (size_t)n_cells, s))) return rc;
+    if ((rc = dp.alloc((size_t)n_cells * sizeof(double)))) return rc;
+    std::vector<double> part((size_t)n_cells);
+    const long double N = (long double)n_cells * (long double)n_genes;
+    long double acc[2] = {0, 0};
+    double mean = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {   // R's mean() then sd(): two passes over the block
+        if ((rc = launch_block_cell_reduce(pass, expr, (int32_t)G, gene_idx ? dg.as<int32_t>() : nullptr, (int32_t)n_genes,
+                                           dc.as<int32_t>(), (int32_t)n_cells, mean, dp.as<double>(), s)))
+            return rc;
+        ICNV_HIP(hipMemcpyAsync(part.data(), dp.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        ICNV_HIP(hipStreamSynchronize(s));
+        for (double v : part) acc[pass] += v;
+        if (pass == 0) mean = (double)(acc[0] / N);
+    }
+    out2_host[0] = mean;
+    out2_host[1] = N > 1 ? std::sqrt((double)(acc[1] / (N - 1))) : NAN;
+    return ICNV_OK;
+}
+
+int icnv_block_mean_sd(const double *expr, int64_t G, int64_t C, const int32_t *gene_idx, int64_t n_genes,
+                       const int32_t *cell_idx, int64_t n_cells, double *out2) {
+    if (!expr || G < 1 || C < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    DevBuf din;
+    int rc;
+    if ((rc = din.alloc((size_t)G * C * sizeof(double)))) return rc;
+    ICNV_HIP(hipMemcpy(din.p, expr, (size_t)G * C * sizeof(double), hipMemcpyHostToDevice));
+    return icnv_block_mean_sd_dev(din.as<double>(), G, C, gene_idx, n_genes, cell_idx, n_cells, out2, nullptr);
+}
+
 // ------------------------------------------------------------------ HMM
 static int fill_hmm(HmmParams &p, int32_t K, const double *mean, const double *logPi, const double *logDelta) {
     if (K != 3 && K != 6) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "HMM kernels are built for K = 6 (i6) and K = 3 (i3)");

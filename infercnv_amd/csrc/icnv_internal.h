@@ -79,6 +79,14 @@ int launch_reduce_cell_stats(const double *cell_stats, int32_t n_cells, int32_t 
                              hipStream_t stream);
 int launch_denoise_from_stats(const double *stats4, double sd_amplifier, double noise_filter,
                               double *mu_s, hipStream_t stream);
+// ---- gene filters / block statistics (stats_kernels.hip) ----
+int gene_stats_nsplit(int32_t G, int64_t C);
+int launch_gene_stats(const double *x, int32_t G, int64_t C, int nsplit, double *part_sum, int32_t *part_nnz, double *sums,
+                      int32_t *nnz, hipStream_t stream);
+int launch_select_genes(const double *in, int32_t G_in, int64_t C, const int32_t *keep_dev, int32_t G_out, double *out,
+                        hipStream_t stream);
+int launch_block_cell_reduce(int pass, const double *x, int32_t G, const int32_t *gene_idx_dev, int32_t n_genes,
+                             const int32_t *cell_idx_dev, int32_t n_cells, double mean, double *out, hipStream_t stream);
 int launch_col_sums(const double *x, int32_t G, int64_t C, double *out, hipStream_t stream);
 int launch_normalize_log2(const double *in, double *out, int32_t G, int64_t C, const double *col_sums, double factor,
                           int do_norm, int do_log, hipStream_t stream);

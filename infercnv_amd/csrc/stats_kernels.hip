@@ -1,0 +1,124 @@
+// Gene filters of the ingest (steps 2: require_above_min_mean_expr_cutoff / require_above_min_cells_ref,
+// R/inferCNV_ops.R:2128-2213), row selection (remove_genes) and the mean / sd of a gene x cell block
+// (get_spike_dists, R/inferCNV_HMM.R:15-99) for gfx950.  All HBM-bound streaming work.
+#include "icnv_internal.h"
+
+namespace icnv {
+
+namespace {
+
+constexpr int GS_TILE = 256;   // genes per block (coalesced along the gene axis of the cell-major matrix)
+
+// part_sum[sp*G + g] = sum over the sp-th slice of cells of x[g, c];  part_nnz likewise counts x > 0 (NaN is not > 0,
+// which is R's `x > 0 & !is.na(x)`).  Fixed slice order => deterministic.
+__global__ void gene_stats_partial_kernel(const double *__restrict__ x, int G, int64_t C, int nsplit,
+                                          double *__restrict__ part_sum, int32_t *__restrict__ part_nnz) {
+    const int g = blockIdx.x * GS_TILE + threadIdx.x;
+    const int sp = blockIdx.y;
+    if (g >= G) return;
+    const int64_t per = (C + nsplit - 1) / nsplit;
+    const int64_t lo = sp * per;
+    int64_t hi = lo + per;
+    if (hi > C) hi = C;
+    double s = 0.0;
+    int32_t n = 0;
+    for (int64_t c = lo; c < hi; ++c) {
+        const double v = __builtin_nontemporal_load(x + c * (int64_t)G + g);
+        s += v;
+        n += (v > 0.0) ? 1 : 0;
+    }
+    part_sum[(int64_t)sp * G + g] = s;
+    part_nnz[(int64_t)sp * G + g] = n;
+}
+__global__ void gene_stats_finish_kernel(const double *__restrict__ part_sum, const int32_t *__restrict__ part_nnz, int G,
+                                         int nsplit, double *__restrict__ sums, int32_t *__restrict__ nnz) {
+    const int g = blockIdx.x * GS_TILE + threadIdx.x;
+    if (g >= G) return;
+    double s = 0.0;
+    int32_t n = 0;
+    for (int sp = 0; sp < nsplit; ++sp) {
+        s += part_sum[(int64_t)sp * G + g];
+        n += part_nnz[(int64_t)sp * G + g];
+    }
+    sums[g] = s;
+    nnz[g] = n;
+}
+
+// out[j, c] = in[keep[j], c]  (remove_genes: rows dropped, cell-major layout => a per-cell gather)
+__global__ void select_genes_kernel(const double *__restrict__ in, int G_in, int64_t C, const int32_t *__restrict__ keep,
+                                    int G_out, double *__restrict__ out) {
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        const double *src = in + c * (int64_t)G_in;
+        double *dst = out + c * (int64_t)G_out;
+        for (int j = threadIdx.x; j < G_out; j += blockDim.x) dst[j] = src[keep[j]];
+    }
+}
+
+// per listed cell: sum (PASS 0) or sum of squared deviations from `mean` (PASS 1) over the listed genes
+template <int PASS>
+__global__ void block_cell_reduce_kernel(const double *__restrict__ x, int G, const int32_t *__restrict__ gene_idx,
+                                         int n_genes, const int32_t *__restrict__ cell_idx, double mean,
+                                         double *__restrict__ out) {
+    __shared__ double red[256 / 64];
+    const double *src = x + (int64_t)cell_idx[blockIdx.x] * G;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < n_genes; j += 256) {
+        const double v = src[gene_idx ? gene_idx[j] : j];
+        if (PASS == 0) s += v;
+        else { const double d = v - mean; s += d * d; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+}  // namespace
+
+int gene_stats_nsplit(int32_t G, int64_t C) {
+    const int tiles = (G + GS_TILE - 1) / GS_TILE;
+    int64_t ns = (4096 + tiles - 1) / tiles;   // enough blocks to fill 256 CUs several times over
+    if (ns > C) ns = C;
+    if (ns < 1) ns = 1;
+    if (ns > 1024) ns = 1024;
+    return (int)ns;
+}
+
+int launch_gene_stats(const double *x, int32_t G, int64_t C, int nsplit, double *part_sum, int32_t *part_nnz, double *sums,
+                      int32_t *nnz, hipStream_t stream) {
+    if (C <= 0) return ICNV_OK;
+    KernelTimer kt("gene_stats", stream);
+    const int tiles = (G + GS_TILE - 1) / GS_TILE;
+    hipLaunchKernelGGL(gene_stats_partial_kernel, dim3(tiles, nsplit), dim3(GS_TILE), 0, stream, x, G, C, nsplit, part_sum,
+                       part_nnz);
+    hipLaunchKernelGGL(gene_stats_finish_kernel, dim3(tiles), dim3(GS_TILE), 0, stream, part_sum, part_nnz, G, nsplit, sums,
+                       nnz);
+    ICNV_HIP(hipGetLastError());
+    return ICNV_OK;
+}
+
+int launch_select_genes(const double *in, int32_t G_in, int64_t C, const int32_t *keep_dev, int32_t G_out, double *out,
+                        hipStream_t stream) {
+    if (C <= 0 || G_out <= 0) return ICNV_OK;
+    KernelTimer kt("select_genes", stream);
+    hipLaunchKernelGGL(select_genes_kernel, dim3((unsigned)(C < 8192 ? C : 8192)), dim3(256), 0, stream, in, G_in, C,
+                       keep_dev, G_out, out);
+    ICNV_HIP(hipGetLastError());
+    return ICNV_OK;
+}
+
+int launch_block_cell_reduce(int pass, const double *x, int32_t G, const int32_t *gene_idx_dev, int32_t n_genes,
+                             const int32_t *cell_idx_dev, int32_t n_cells, double mean, double *out, hipStream_t stream) {
+    if (n_cells <= 0) return ICNV_OK;
+    if (pass == 0)
+        hipLaunchKernelGGL(block_cell_reduce_kernel<0>, dim3(n_cells), dim3(256), 0, stream, x, G, gene_idx_dev, n_genes,
+                           cell_idx_dev, mean, out);
+    else
+        hipLaunchKernelGGL(block_cell_reduce_kernel<1>, dim3(n_cells), dim3(256), 0, stream, x, G, gene_idx_dev, n_genes,
+                           cell_idx_dev, mean, out);
+    ICNV_HIP(hipGetLastError());
+    return ICNV_OK;
+}
+
+}  // namespace icnv

@@ -45,6 +45,38 @@ def determine_mean_delta_via_Z(sigma, p):
     return abs(statistics.NormalDist(0.0, sigma).inv_cdf(p))
 
 
+HSPIKE_CHR_INFO = (("chrA", 1), ("chr_0", 0.01), ("chr_B", 1), ("chr_0pt5", 0.5), ("chr_C", 1), ("chr_1pt5", 1.5),
+                   ("chr_D", 1), ("chr_2pt0", 2.0), ("chr_E", 1), ("chr_3pt0", 3), ("chr_F", 1))
+"""(name, cnv) of the fake chromosomes of the hidden spike-in (.get_hspike_chr_info, R/inferCNV_hidden_spike.R:170-215)."""
+
+
+def get_spike_dists(hspike_obj: InfercnvObject, chr_info=HSPIKE_CHR_INFO):
+    """get_spike_dists (R/inferCNV_HMM.R:15-99): per CNV level the mean and sd of the residual expression of the
+    spiked (observation) cells over the genes of that level's fake chromosomes -- one block reduction on the
+    device per level.  Returns {"cnv:1": {"mean":, "sd":}, ...} in order of first appearance."""
+    if hspike_obj is None:
+        raise ValueError("get_spike_dists(hspike_obj): Error, hspike obj is null")
+    L = _lib.load()
+    x = np.asfortranarray(hspike_obj.expr_data, dtype=np.float64)
+    G, C = x.shape
+    cells = np.concatenate([np.asarray(v, dtype=np.int32) for v in hspike_obj.observation_grouped_cell_indices.values()])
+    chrs = np.asarray(hspike_obj.gene_order.chr)
+    genes_by_cnv = {}
+    for name, cnv in chr_info:
+        key = "cnv:%g" % cnv
+        genes_by_cnv.setdefault(key, []).append(np.nonzero(chrs == name)[0])
+    out = {}
+    for key, parts in genes_by_cnv.items():
+        gi, gp = i32(np.concatenate(parts))
+        if gi.size == 0:
+            continue
+        ci, cp = i32(cells)
+        buf = (ct.c_double * 2)()
+        check(L.icnv_block_mean_sd(x.ctypes.data_as(ct.c_void_p), G, C, gp, gi.size, cp, ci.size, buf))
+        out[key] = {"mean": buf[0], "sd": buf[1]}
+    return out
+
+
 def _log(a):
     with np.errstate(divide="ignore"):
         return np.log(np.asarray(a, dtype=np.float64))

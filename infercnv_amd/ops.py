@@ -51,6 +51,65 @@ def _with_expr(obj, expr, hspike=None):
     return new
 
 
+# ------------------------------------------------------------------ step 2 (gene filters)
+def _gene_stats(infercnv_obj):
+    """(rowSums(expr), per-gene number of cells with expr > 0) from the HIP path."""
+    L = _lib.load()
+    x = _as_f(infercnv_obj.expr_data)
+    G, C = x.shape
+    sums = np.empty(G, dtype=np.float64)
+    nnz = np.empty(G, dtype=np.int32)
+    check(L.icnv_gene_stats(x.ctypes.data_as(ct.c_void_p), G, C, sums.ctypes.data_as(ct.c_void_p),
+                            nnz.ctypes.data_as(ct.c_void_p)))
+    return sums, nnz
+
+
+def remove_genes(infercnv_obj: InfercnvObject, gene_indices_to_remove) -> InfercnvObject:
+    """remove_genes (R/inferCNV.R:445-457): drops the rows (0-based here) from expr.data (on the device),
+    count.data and gene_order."""
+    L = _lib.load()
+    x = _as_f(infercnv_obj.expr_data)
+    G, C = x.shape
+    drop = np.zeros(G, dtype=bool)
+    drop[np.asarray(gene_indices_to_remove, dtype=np.int64)] = True
+    keep = np.nonzero(~drop)[0].astype(np.int32)
+    if keep.size == 0:
+        raise ValueError("all genes removed")
+    out = np.empty((keep.size, C), dtype=np.float64, order="F")
+    check(L.icnv_select_genes(x.ctypes.data_as(ct.c_void_p), G, C, keep.ctypes.data_as(ct.POINTER(ct.c_int32)), keep.size,
+                              out.ctypes.data_as(ct.c_void_p)))
+    new = infercnv_obj.copy()
+    new.expr_data = out
+    if infercnv_obj.count_data is not None:
+        new.count_data = np.asarray(infercnv_obj.count_data)[keep]
+    go = infercnv_obj.gene_order
+    new.gene_order = type(go)(np.asarray(go.chr)[keep], None if go.start is None else np.asarray(go.start)[keep],
+                              None if go.stop is None else np.asarray(go.stop)[keep])
+    if infercnv_obj.gene_names is not None:
+        new.gene_names = np.asarray(infercnv_obj.gene_names)[keep]
+    new.validate()
+    return new
+
+
+def require_above_min_mean_expr_cutoff(infercnv_obj: InfercnvObject, min_mean_expr_cutoff) -> InfercnvObject:
+    """R/inferCNV_ops.R:2128-2163: removes genes with rowMeans(expr.data) < cutoff."""
+    sums, _ = _gene_stats(infercnv_obj)
+    indices = np.nonzero(sums / infercnv_obj.expr_data.shape[1] < min_mean_expr_cutoff)[0]
+    return remove_genes(infercnv_obj, indices) if indices.size else infercnv_obj
+
+
+def require_above_min_cells_ref(infercnv_obj: InfercnvObject, min_cells_per_gene) -> InfercnvObject:
+    """R/inferCNV_ops.R:2182-2213: keeps genes expressed (> 0, not NA) in at least min_cells_per_gene cells;
+    stops when no gene passes (the reference's stop(998))."""
+    _, nnz = _gene_stats(infercnv_obj)
+    passed = nnz >= min_cells_per_gene
+    if passed.all():
+        return infercnv_obj
+    if not passed.any():
+        raise RuntimeError("All genes removed! Must revisit your data..., cannot continue here.")
+    return remove_genes(infercnv_obj, np.nonzero(~passed)[0])
+
+
 # ------------------------------------------------------------------ steps 3 / 4 (ingest)
 def _normalize_log2(infercnv_obj, normalize_factor, do_norm, do_log):
     L = _lib.load()

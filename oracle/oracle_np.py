@@ -598,3 +598,23 @@ def define_cnv_gene_regions(state_consensus_vec, chrs, counter):
                 regions[-1][2].append(i)
             prev = st
     return regions, counter
+
+
+# --------------------------------------------------------------------------
+# gene filters (step 2) and spike-in emission statistics (SURVEY 8f #1, #3)
+# --------------------------------------------------------------------------
+def below_min_mean_expr_cutoff(expr, min_mean_expr):
+    """.below_min_mean_expr_cutoff (R/inferCNV_ops.R:2154-2163): which(rowMeans(expr) < cutoff), 0-based."""
+    return np.nonzero(r_sum(expr, axis=1) / expr.shape[1] < min_mean_expr)[0]
+
+
+def genes_passing_min_cells(expr, min_cells_per_gene):
+    """require_above_min_cells_ref (R/inferCNV_ops.R:2182-2184): sum(x > 0 & !is.na(x)) >= min_cells, 0-based."""
+    with np.errstate(invalid="ignore"):
+        return np.nonzero((np.asarray(expr) > 0).sum(axis=1) >= min_cells_per_gene)[0]
+
+
+def gene_expr_mean_sd(expr, gene_idx, cell_idx):
+    """.get_gene_expr_mean_sd_by_cnv (R/inferCNV_HMM.R:84-99): mean() and sd() of c(expr[genes, cells])."""
+    v = np.asarray(expr, dtype=np.float64)[np.ix_(np.asarray(gene_idx), np.asarray(cell_idx))].ravel(order="F")
+    return float(r_mean(v)), float(r_sd(v.reshape(-1, 1), axis=0)[0])

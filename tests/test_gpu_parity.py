@@ -600,3 +600,69 @@ def test_per_chr_subcluster_predictor_with_consensus(dev):
         want[:, g] = onp.state_consensus(raw, [g])
     assert np.array_equal(got, want)
     assert (got[100:250, 20:] == 4).mean() > 0.9 and (got[450:600, :10] == 2).mean() > 0.0
+
+
+# ------------------------------------------------------------------ gene filters + spike-in statistics (8f #1, #3)
+def test_gene_filters_and_row_selection(dev, example):
+    """Step 2 on the reference's bundled raw counts: require_above_min_mean_expr_cutoff / require_above_min_cells_ref
+    decide exactly as R does (integer counts: the fp64 row sums are exact), remove_genes gathers the rows."""
+    from infercnv_amd import ops
+    from infercnv_amd.infercnv_object import GeneOrder, InfercnvObject
+    counts = example["count_data"].astype(np.float64)
+    rng = np.random.default_rng(2)
+    counts[rng.random(counts.shape[0]) < 0.2] *= 0.0                  # silence some genes entirely
+    counts[rng.random(counts.shape) < 0.5] = 0.0
+    obj = InfercnvObject(expr_data=counts, count_data=counts.copy(), gene_order=GeneOrder(example["chr_codes"], example["gene_start"],
+                                                                                       example["gene_stop"]),
+                         reference_grouped_cell_indices={"normal": example["ref_normal"]},
+                         observation_grouped_cell_indices={"tumor": example["obs_tumor"]})
+    sums, nnz = ops._gene_stats(obj)
+    assert np.array_equal(sums, counts.sum(axis=1)) and np.array_equal(nnz, (counts > 0).sum(axis=1))
+    for cutoff in (0.1, 1.0, 2.5):
+        got = ops.require_above_min_mean_expr_cutoff(obj, cutoff)
+        drop = onp.below_min_mean_expr_cutoff(counts, cutoff)
+        keep = np.setdiff1d(np.arange(counts.shape[0]), drop)
+        assert 0 < drop.size < counts.shape[0]
+        assert np.array_equal(got.expr_data, counts[keep]) and np.array_equal(got.gene_order.start, example["gene_start"][keep])
+    got = ops.require_above_min_cells_ref(obj, 3)
+    assert np.array_equal(got.expr_data, counts[onp.genes_passing_min_cells(counts, 3)])
+    with pytest.raises(RuntimeError):
+        ops.require_above_min_cells_ref(obj, 10 ** 6)
+    # device-resident flavour on a larger matrix, NaN entries are "not expressed"
+    x = rng.poisson(0.7, size=(5000, 700)).astype(np.float64)
+    x[rng.random(x.shape) < 0.01] = np.nan
+    L = __import__("infercnv_amd")._lib.load()
+    import ctypes as ct
+    d = to_dev(x)
+    s_d = torch.empty(5000, dtype=torch.float64, device="cuda")
+    n_d = torch.empty(5000, dtype=torch.int32, device="cuda")
+    rc = L.icnv_gene_stats_dev(ct.c_void_p(d.data_ptr()), 5000, 700, ct.c_void_p(s_d.data_ptr()), ct.c_void_p(n_d.data_ptr()), None)
+    assert rc == 0
+    assert np.array_equal(n_d.cpu().numpy(), onp.genes_passing_min_cells(x, 0).size * 0 + (x > 0).sum(axis=1))
+    ok = ~np.isnan(x).any(axis=1)
+    assert np.abs(s_d.cpu().numpy()[ok] - x[ok].sum(axis=1)).max() == 0.0
+
+
+def test_get_spike_dists_block_statistics(dev):
+    """get_spike_dists (R/inferCNV_HMM.R:15-99) on a synthetic hidden spike-in object."""
+    from infercnv_amd import hmm
+    from infercnv_amd.infercnv_object import GeneOrder, InfercnvObject
+    rng = np.random.default_rng(8)
+    sizes = [40, 35, 40, 30, 40, 45, 40, 25, 40, 50, 90]
+    chrs = np.concatenate([[name] * n for (name, _), n in zip(hmm.HSPIKE_CHR_INFO, sizes)])
+    level = np.concatenate([[cnv] * n for (_, cnv), n in zip(hmm.HSPIKE_CHR_INFO, sizes)])
+    C = 60
+    x = rng.normal(1.0, 0.1, size=(chrs.size, C))
+    x[:, 30:] *= level[:, None]                                        # spiked cells
+    obj = InfercnvObject(expr_data=x, gene_order=GeneOrder(chrs),
+                         reference_grouped_cell_indices={"simnormal": np.arange(0, 30)},
+                         observation_grouped_cell_indices={"spike_a": np.arange(30, 50), "spike_b": np.arange(50, 60)})
+    got = hmm.get_spike_dists(obj)
+    assert list(got) == ["cnv:1", "cnv:0.01", "cnv:0.5", "cnv:1.5", "cnv:2", "cnv:3"]
+    for key, v in got.items():
+        cnv = float(key.split(":")[1])
+        m, s = onp.gene_expr_mean_sd(x, np.nonzero(level == cnv)[0], np.arange(30, 60))
+        assert abs(v["mean"] - m) < 1e-14 and abs(v["sd"] - s) < 1e-14
+    # the result feeds the i6 predictor directly
+    st = hmm.predict_CNV_via_HMM_on_indiv_cells(obj, got).expr_data
+    assert (st[level == 3][:, 30:] == 6).mean() > 0.9 and (st[level == 1][:, :30] == 3).mean() > 0.9

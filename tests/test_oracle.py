@@ -336,3 +336,13 @@ def test_define_cnv_gene_regions_loop():
         ("chr1-region_11", 3, [0, 1]), ("chr1-region_12", 4, [2, 3]), ("chr1-region_13", 3, [4]),
         ("chr2-region_14", 2, [6, 7, 8])]          # chrX has a single gene: skipped (:1013)
     assert counter == 14
+
+
+def test_gene_filter_restatements():
+    """R/inferCNV_ops.R:2154-2163, 2182-2184 on a hand-checkable matrix."""
+    x = np.array([[0, 0, 0, 0], [1, 0, 0, 0], [2, 2, 2, 2], [0, 1, np.nan, 1], [0.3, 0.1, 0.0, 0.0]], dtype=np.float64)
+    assert onp.below_min_mean_expr_cutoff(np.nan_to_num(x), 0.1).tolist() == [0]        # 0.1 is not < 0.1 (row 4 mean)
+    assert onp.below_min_mean_expr_cutoff(np.nan_to_num(x), 0.26).tolist() == [0, 1, 4]
+    assert onp.genes_passing_min_cells(x, 2).tolist() == [2, 3, 4]                       # NA is not counted
+    m, s = onp.gene_expr_mean_sd(np.arange(12.0).reshape(3, 4), [0, 2], [1, 3])          # values 1, 9, 3, 11
+    assert m == 6.0 and abs(s - np.std([1, 9, 3, 11], ddof=1)) < 1e-15
