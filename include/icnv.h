@@ -156,6 +156,27 @@ int icnv_viterbi_cells_dev(const double *expr, uint8_t *states, int64_t G, int64
                            double sd_shared, const double *logPi, const double *logDelta,
                            int32_t *n_underflow_dev, void *stream);
 
+/* Certified fast path of the per-cell Viterbi (DESIGN.md "Certified fast Viterbi").  With a shared sd and the
+ * transition structure of .get_HMM / .i3HMM_get_HMM (R/inferCNV_HMM.R:230-265, R/inferCNV_i3HMM.R:99-156: one
+ * off-diagonal and one diagonal probability) icnv_viterbi_cells[_dev] computes the emission scores from a
+ * verified polynomial table, tests every arg-max decision against a certified error band and recomputes the
+ * flagged sequences with the exact kernel: the states are those of the exact kernel, bit for bit.
+ *   icnv_viterbi_set_mode   0 = auto (default), 1 = exact kernel only
+ *   icnv_viterbi_last_stats out4 = {path of the last call (0 exact / 1 fast), sequences, flagged sequences of
+ *                           the last column batch, table intervals}; synchronises with the last call
+ *   icnv_hmm_emission_table host-only: the table for (K, mean, sd); meta8 = {n_intervals, x_lo, x_hi, eps_tab,
+ *                           s_max, degree, n_segments, eps_spec}; seg_out [n_seg*4] = {lo, 1/width, base, n-1};
+ *                           coef_out [n_intervals*K*(degree+1)] (nullable)
+ *   icnv_hmm_emission_scores host-only: which = 0 the exact scores of R/inferCNV_HMM.R:1129-1133 in 80-bit
+ *                           arithmetic, which = 1 the table's scores through the kernel's double operations
+ *                           (ok_out[i] = 0 and NaN where x[i] is outside the table's domain); out [n*K] */
+int icnv_viterbi_set_mode(int mode);
+int icnv_viterbi_last_stats(int64_t *out4);
+int icnv_hmm_emission_table(int32_t K, const double *mean, double sd, double *meta8, double *seg_out, double *coef_out,
+                            int64_t coef_cap);
+int icnv_hmm_emission_scores(int32_t K, const double *mean, double sd, const double *x, int64_t n, int32_t which,
+                             double *out, uint8_t *ok_out);
+
 /* predict_CNV_via_HMM_on_tumor_subclusters / _whole_tumor_samples
  * (R/inferCNV_HMM.R:345-408, 509-567) and the i3 variants
  * (R/inferCNV_i3HMM.R:249-389): Viterbi on rowMeans over each group's cells

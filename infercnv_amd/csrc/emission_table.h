@@ -1,0 +1,56 @@
+// Emission-score table of the certified fast Viterbi path (viterbi_fast.hip).
+//
+// The reference's emission scores (R/inferCNV_HMM.R:1129-1133, 1156-1160)
+//     lp_k = log P(Z > |x - mean_k| / sd),  e_k = 1 / (-lp_k),  s_k = log(e_k / sum_j e_j)
+// are K smooth functions of the single observation x between consecutive state means (|x - mean_k|
+// kinks at every mean).  The table holds, for every interval of a partition of [x_lo, x_hi] whose
+// cut points include the means, one degree-DEG polynomial per state in the normalised position
+// tn in [-0.5, 0.5] inside the interval.  It is built on the host in 80-bit long double from the
+// mathematically exact functions (erfcl / logl) and verified against them through the very double
+// operations the kernel executes; eps_tab is the certified bound the kernel's margin test uses.
+//
+// Host-only, no HIP types: compiled by g++ and also exported through the C ABI
+// (icnv_hmm_emission_table) so that the CPU tests can check the bound independently.
+#pragma once
+#include <stdint.h>
+#include <vector>
+
+namespace icnv {
+
+constexpr int EMIS_DEG = 5;          // polynomial degree
+constexpr int EMIS_MAX_SEG = 8;      // K + 1 segments, K <= 6 (one spare)
+
+struct EmisSegment {                 // 32 bytes, one per segment, read by the kernel with one 16-B + one 8-B LDS load
+    double lo;                       // lower end of the segment
+    double inv_w;                    // 1 / interval width inside the segment
+    int32_t base;                    // index of the segment's first interval
+    int32_t n_m1;                    // number of intervals - 1
+    int32_t pad[2];
+};
+
+struct EmisTable {
+    int K = 0;
+    int n_seg = 0;                   // K + 1
+    int n_int = 0;                   // total intervals
+    double x_lo = 0, x_hi = 0;       // covered domain; observations outside take the exact path
+    double eps_tab = 0;              // certified bound on |table score - exact score| over the domain
+    double s_max = 0;                // max |score| over the domain (bounds the magnitude of the DP values)
+    double width_sigma = 0;          // target interval width in units of sd
+    EmisSegment seg[EMIS_MAX_SEG];
+    std::vector<double> coef;        // [n_int][K][EMIS_DEG + 1], c0 first
+};
+
+// Build the table for K states with strictly increasing means and a shared sd.  max_intervals is the
+// LDS budget.  Returns 0 on success; non-zero (with a reason in *why) when the parameters are not
+// eligible (unsorted means, non-finite values, accuracy target not met): callers then use the exact kernel.
+int build_emission_table(int K, const double *mean, double sd, int max_intervals, EmisTable &out, const char **why);
+
+// The exact scores in long double (the function the table approximates); used by the build's own
+// verification and exported for the tests.
+void emission_scores_exact(int K, const double *mean, double sd, double x, double *s_out);
+
+// The kernel's evaluation of the table restated on the host with the same double operations
+// (explicit fma, same order).  Returns false when x is outside the domain / not finite.
+bool emission_table_eval(const EmisTable &t, const double *mean, double x, double *s_out);
+
+}  // namespace icnv

@@ -105,6 +105,40 @@ int launch_viterbi(const double *x, uint8_t *states, int32_t G, int64_t n_seq_co
                    const double *sd_per_col_dev, double sd_shared, uint32_t *bp_scratch, int32_t *n_underflow,
                    hipStream_t stream);
 size_t viterbi_scratch_bytes(int32_t G, int64_t n_cols);
+
+// certified fast path (viterbi_fast.hip): table-driven scores + decision-margin test, flagged sequences redone exactly
+struct EmisTable;
+struct FastViterbiArgs {
+    const double *x;
+    uint8_t *states;
+    int32_t G;
+    int64_t ncols;
+    const int32_t *chr_start;   // device
+    const int32_t *chr_order;   // device, longest chromosome first
+    int32_t n_chr;
+    const double *table;        // device image (viterbi_fast_table_image)
+    int32_t n_int;
+    double mean[8];
+    double logDelta[8];
+    double a, b;                // log off-diagonal / diagonal transition probability
+    double x_lo, x_hi;          // table domain
+    double eps;                 // eps_tab + eps_spec
+    double b0, s_step;          // |value| bound of the recurrence: B = b0 + (n + 1) s_step
+    uint16_t *bp;               // [G][ncols]
+    int32_t *task_counter;      // zeroed before the launch
+    int32_t *flag_count;        // zeroed before the launch
+    int32_t *flag_list;         // [2 * n_chr * ncols] (chromosome, column) pairs
+};
+size_t viterbi_fast_scratch_bytes(int32_t G, int64_t n_cols);
+size_t viterbi_fast_lds_bytes(int K, int n_int);
+int viterbi_fast_max_intervals(int K);
+void viterbi_fast_table_image(const EmisTable &t, std::vector<double> &img);
+int launch_viterbi_fast(const FastViterbiArgs &a, int K, hipStream_t stream);
+int viterbi_redo_slots();
+size_t viterbi_redo_scratch_bytes(int32_t max_chr_len);
+int launch_viterbi_redo(const double *x, uint8_t *states, int32_t G, const int32_t *chr_start_dev, const HmmParams &p,
+                        double sd_shared, const int32_t *flag_count_dev, const int32_t *flag_list_dev,
+                        uint32_t *bp_redo, int32_t *n_underflow, hipStream_t stream);
 int group_means_nsplit(int32_t G, int32_t n_grp);
 int launch_group_means_ws(const double *x, int32_t G, const int32_t *grp_idx_dev, const int32_t *grp_off_dev,
                           int32_t n_grp, int nsplit, double *part, double *out, hipStream_t stream);

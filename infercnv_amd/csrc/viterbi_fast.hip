@@ -1,0 +1,220 @@
+// Certified fast path of the per-cell HMM Viterbi (Viterbi.dthmm.adj, R/inferCNV_HMM.R:1101-1176).
+//
+// The exact kernel (viterbi_kernels.hip) spends ~1.1 k fp64 instructions per gene and wavefront on
+// the reference's emission arithmetic (K x [Cody's pnorm + log + two divisions + log]).  Its OUTPUT
+// is discrete: the arg-max decisions of the max-plus recurrence.  This kernel computes the same
+// decisions from scores that are within a CERTIFIED distance eps of the exact kernel's scores
+//   - emission scores: K polynomials per observation from the table of emission_table.{h,cpp}
+//     (built in 80-bit arithmetic from the exact functions, verified through these very double
+//     operations; eps_tab), plus the distance of the exact kernel's own arithmetic from the exact
+//     functions (eps_spec);
+//   - the recurrence itself in the same double operations (add, max, add),
+// and tests every decision it takes against the accumulated error bound: with
+//   E_i <= (i + 1) * (eps + 4 u B)   (u = 2^-53, B >= any |value| of the recurrence)
+// bounding |nu_fast - nu_exact| after gene i, a decision whose winner leads by more than 2 E_i is
+// the decision the exact arithmetic takes (max is 1-Lipschitz).  A sequence with any decision inside
+// the band (or an observation outside the table's domain, or a non-finite one) is FLAGGED and
+// recomputed by the exact kernel (viterbi_redo_kernel) -- so the states are those of the exact
+// kernel, bit for bit, always; the fast path only decides how many sequences take the slow road
+// (~1e-4 of them on real-valued data).  DESIGN.md "Certified fast Viterbi" has the derivation.
+//
+// Requires the transition matrix of .get_HMM / .i3HMM_get_HMM (R/inferCNV_HMM.R:230-265,
+// R/inferCNV_i3HMM.R:99-156): one off-diagonal value a = log t and one diagonal value b, b > a.
+// Then  max_j (nu_j + logPi[j,k]) = max(nu_k + b, max_{j != k} nu_j + a), and because the best
+// predecessor overall (i1) beats every other off-diagonal candidate, row k needs only the
+// comparison  nu_k + b  vs  nu_i1 + a  (row i1 keeps itself: b - a is far outside the band):
+// 2 K + 5 (K - 1) operations instead of 4 K^2.  Back-pointers shrink to K bits + i1 (uint16).
+//
+// Mapping: persistent workgroups of 16 wavefronts (the table fills most of the CU's LDS), every
+// wavefront pulls (chromosome, 64-column block) tasks, longest chromosomes first, one lane per
+// sequence as in the exact kernel.
+#include <algorithm>
+#include <cstring>
+
+#include "icnv_internal.h"
+#include "emission_table.h"
+#include "viterbi_trace.h"
+
+#pragma clang fp contract(off)
+
+namespace icnv {
+
+namespace {
+
+constexpr int FAST_NT = 1024;
+constexpr int NCF = EMIS_DEG + 1;
+constexpr int SEG_DOUBLES = EMIS_MAX_SEG * 4;   // segment records at the start of the LDS image
+
+template <int K>
+__global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbiArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double tab[];
+    {
+        const int n_dbl = SEG_DOUBLES + A.n_int * K * NCF;
+        const double2 *src = reinterpret_cast<const double2 *>(A.table);
+        double2 *dst = reinterpret_cast<double2 *>(tab);
+        for (int i = threadIdx.x; i < n_dbl / 2; i += FAST_NT) dst[i] = src[i];
+    }
+    __syncthreads();
+    const double *coef = tab + SEG_DOUBLES;
+    const int lane = threadIdx.x & 63;
+    const int64_t ncg = (A.ncols + 63) >> 6;
+    const int64_t n_tasks = ncg * A.n_chr;
+
+    for (;;) {
+        int task = 0;
+        if (lane == 0) task = atomicAdd(A.task_counter, 1);
+        task = __builtin_amdgcn_readfirstlane(task);
+        if (task >= n_tasks) break;
+        const int chr = A.chr_order[task / ncg];
+        const int64_t col = (task % ncg) * 64 + lane;
+        if (col >= A.ncols) continue;
+        const int s0 = A.chr_start[chr];
+        const int n = A.chr_start[chr + 1] - s0;
+        const double *xc = A.x + col * (int64_t)A.G + s0;
+        uint8_t *st = A.states + col * (int64_t)A.G + s0;
+        if (n < 2) {  // R/inferCNV_HMM.R:1104-1107
+            if (n == 1) st[0] = 3;
+            continue;
+        }
+        uint16_t *bpc = A.bp + (int64_t)s0 * A.ncols + col;
+        // decision band of this task: 4 (n + 1) (eps + 4 u B), B = |logDelta|max + |a| + (n + 1)(s_max + |b|)
+        const double np1 = (double)(n + 1);
+        const double B = A.b0 + np1 * A.s_step;
+        const double thr = 4.0 * np1 * (A.eps + 0x1p-51 * B);
+
+        double nu[K], sc[K];
+        bool flag = false;
+        double xn = xc[0];
+        for (int i = 0; i < n; ++i) {
+            const double xv = xn;
+            if (i + 1 < n) xn = xc[i + 1];
+            const bool ok = (xv >= A.x_lo) && (xv <= A.x_hi);   // false for NaN
+            flag |= !ok;
+            const double xs = ok ? xv : A.mean[0];
+            int seg = 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) seg += (xs >= A.mean[k]) ? 1 : 0;
+            const double2 sg = *reinterpret_cast<const double2 *>(tab + 4 * seg);           // lo, inv_w
+            const int2 sn = *reinterpret_cast<const int2 *>(tab + 4 * seg + 2);             // base, n - 1
+            const double u = (xs - sg.x) * sg.y;
+            int fi = (int)u;
+            fi = fi > sn.y ? sn.y : fi;
+            const double tn = (u - (double)fi) - 0.5;
+            const double *c = coef + (sn.x + fi) * (K * NCF);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const double2 c01 = *reinterpret_cast<const double2 *>(c + k * NCF);
+                const double2 c23 = *reinterpret_cast<const double2 *>(c + k * NCF + 2);
+                const double2 c45 = *reinterpret_cast<const double2 *>(c + k * NCF + 4);
+                double p = __builtin_fma(c45.y, tn, c45.x);
+                p = __builtin_fma(p, tn, c23.y);
+                p = __builtin_fma(p, tn, c23.x);
+                p = __builtin_fma(p, tn, c01.y);
+                sc[k] = __builtin_fma(p, tn, c01.x);
+            }
+            if (i == 0) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) nu[k] = A.logDelta[k] + sc[k];
+                continue;
+            }
+            double m1 = nu[0], m2 = -__builtin_inf();
+            uint32_t i1 = 0;
+#pragma unroll
+            for (int k = 1; k < K; ++k) {
+                const double v = nu[k];
+                m2 = __builtin_fmax(m2, __builtin_fmin(m1, v));
+                i1 = (v > m1) ? (uint32_t)k : i1;
+                m1 = __builtin_fmax(m1, v);
+            }
+            flag |= !(m1 - m2 > thr);
+            const double off = m1 + A.a;
+            uint32_t word = i1 << 6;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const double d = nu[k] + A.b;
+                flag |= !(__builtin_fabs(d - off) > thr);
+                word |= (d >= off) ? (1u << k) : 0u;
+                nu[k] = __builtin_fmax(d, off) + sc[k];
+            }
+            bpc[(int64_t)i * A.ncols] = (uint16_t)word;
+        }
+        // last row: R's which.max
+        double m1 = nu[0], m2 = -__builtin_inf();
+        int cur = 0;
+#pragma unroll
+        for (int k = 1; k < K; ++k) {
+            const double v = nu[k];
+            m2 = __builtin_fmax(m2, __builtin_fmin(m1, v));
+            cur = (v > m1) ? k : cur;
+            m1 = __builtin_fmax(m1, v);
+        }
+        flag |= !(m1 - m2 > thr);
+        if (flag) {
+            const int e = atomicAdd(A.flag_count, 1);
+            A.flag_list[2 * (int64_t)e] = chr;
+            A.flag_list[2 * (int64_t)e + 1] = (int32_t)col;
+        }
+        const int64_t nc = A.ncols;
+        viterbi_traceback(
+            st, n, cur, [&](int i) { return (uint32_t)bpc[(int64_t)i * nc]; },
+            [](uint32_t w, int c) { return ((w >> c) & 1u) ? c : (int)((w >> 6) & 7u); });
+    }
+}
+
+}  // namespace
+
+size_t viterbi_fast_scratch_bytes(int32_t G, int64_t n_cols) { return (size_t)G * (size_t)n_cols * sizeof(uint16_t); }
+size_t viterbi_fast_lds_bytes(int K, int n_int) { return ((size_t)SEG_DOUBLES + (size_t)n_int * K * NCF) * sizeof(double); }
+int viterbi_fast_max_intervals(int K) {
+    // leave 8 KiB of the 160 KiB for the runtime; 16-B granularity
+    return (int)((152 * 1024 - SEG_DOUBLES * sizeof(double)) / ((size_t)K * NCF * sizeof(double)));
+}
+
+// Device image of the table: EMIS_MAX_SEG segment records (lo, inv_w, {base, n-1}, pad) then the coefficients.
+void viterbi_fast_table_image(const EmisTable &t, std::vector<double> &img) {
+    img.assign(SEG_DOUBLES + t.coef.size(), 0.0);
+    for (int s = 0; s < t.n_seg; ++s) {
+        img[4 * s] = t.seg[s].lo;
+        img[4 * s + 1] = t.seg[s].inv_w;
+        int32_t bn[2] = {t.seg[s].base, t.seg[s].n_m1};
+        std::memcpy(&img[4 * s + 2], bn, sizeof(bn));
+    }
+    std::copy(t.coef.begin(), t.coef.end(), img.begin() + SEG_DOUBLES);
+    if (img.size() & 1) img.push_back(0.0);   // the kernel copies 16 bytes at a time
+}
+
+int launch_viterbi_fast(const FastViterbiArgs &a, int K, hipStream_t stream) {
+    if (a.ncols <= 0 || a.n_chr <= 0) return ICNV_OK;
+    const size_t lds = (viterbi_fast_lds_bytes(K, a.n_int) + 15) & ~(size_t)15;
+    if (lds > 160 * 1024) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "emission table does not fit the LDS");
+    const int64_t ncg = (a.ncols + 63) / 64;
+    const int64_t tasks = ncg * a.n_chr;
+    if (tasks > 0x7fffff00) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "too many Viterbi tasks for one launch");
+    int grid = num_cus();
+    const int64_t need = (tasks + FAST_NT / 64 - 1) / (FAST_NT / 64);
+    if (grid > need) grid = (int)need;
+    KernelTimer kt("viterbi", stream);
+    if (K == 6) {
+        static bool set6 = false;
+        if (!set6) {
+            ICNV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_fast_kernel<6>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            set6 = true;
+        }
+        hipLaunchKernelGGL(viterbi_fast_kernel<6>, dim3(grid), dim3(FAST_NT), lds, stream, a);
+    } else if (K == 3) {
+        static bool set3 = false;
+        if (!set3) {
+            ICNV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_fast_kernel<3>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            set3 = true;
+        }
+        hipLaunchKernelGGL(viterbi_fast_kernel<3>, dim3(grid), dim3(FAST_NT), lds, stream, a);
+    } else {
+        ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "fast Viterbi is built for K = 6 and K = 3");
+    }
+    ICNV_HIP(hipGetLastError());
+    return ICNV_OK;
+}
+
+}  // namespace icnv

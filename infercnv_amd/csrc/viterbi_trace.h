@@ -1,0 +1,47 @@
+// Traceback shared by the exact and the certified-fast Viterbi kernels: walks one sequence from its
+// last gene to its first, emitting the 1-based state of every gene (uint8), eight consecutive genes
+// per 8-byte store where the alignment allows.  The back-pointer words of eight genes are requested
+// before they are consumed (their addresses do not depend on the state being traced), so the walk
+// is not one exposed memory latency per gene.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace icnv {
+
+// load(i)  -> raw back-pointer word of gene i (1 <= i < n)
+// step(w, cur) -> predecessor state (0-based) of state `cur` given gene i's word
+template <class Load, class Step>
+__device__ inline void viterbi_traceback(uint8_t *st, int n, int cur, Load load, Step step) {
+    const uint64_t base = (uint64_t)(uintptr_t)st;
+    const uint64_t last = base + (uint64_t)(n - 1);
+    uint64_t word = 0;
+    int i = n - 1;
+    while (i >= 0) {
+        uint32_t W[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) W[j] = (i - j > 0) ? load(i - j) : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int g = i - j;
+            if (g < 0) break;
+            const uint64_t addr = base + (uint64_t)g;
+            const int b = (int)(addr & 7);
+            word |= (uint64_t)(cur + 1) << (8 * b);
+            if (b == 0 || g == 0) {
+                const uint64_t w0 = addr - (uint64_t)b;
+                const int hi = (int)((last - w0) < 7 ? (last - w0) : 7);
+                if (b == 0 && hi == 7) {
+                    *reinterpret_cast<uint64_t *>(st + g) = word;
+                } else {
+                    for (int bb = b; bb <= hi; ++bb) *reinterpret_cast<uint8_t *>(w0 + bb) = (uint8_t)(word >> (8 * bb));
+                }
+                word = 0;
+            }
+            if (g > 0) cur = step(W[j], cur);
+        }
+        i -= 8;
+    }
+}
+
+}  // namespace icnv

@@ -175,6 +175,19 @@ def viterbi_cells(x, chr_start, means, sd_shared, logPi, logDelta, states=None):
     return states, bad
 
 
+def viterbi_set_mode(mode):
+    """0 = auto (certified fast path when the parameters are eligible), 1 = exact kernel only."""
+    check(_lib.load().icnv_viterbi_set_mode(int(mode)))
+
+
+def viterbi_last_stats():
+    """{path, sequences, flagged, table_intervals} of the last per-cell Viterbi call (synchronises with it)."""
+    buf = (ct.c_int64 * 4)()
+    check(_lib.load().icnv_viterbi_last_stats(buf))
+    return {"path": "fast" if buf[0] == 1 else "exact", "sequences": int(buf[1]), "flagged": int(buf[2]),
+            "table_intervals": int(buf[3])}
+
+
 def viterbi_groups(x, chr_start, groups, means, sd_shared_per_group, logPi, logDelta, states=None):
     """predict_CNV_via_HMM_on_tumor_subclusters / _whole_tumor_samples
     (R/inferCNV_HMM.R:345-408, 509-567; i3: R/inferCNV_i3HMM.R:249-389)."""

@@ -193,6 +193,36 @@ def test_viterbi_cells_i6_bit_exact(dev, G, C):
     assert len(np.unique(want)) >= 3
 
 
+def test_viterbi_fast_path_equals_exact_kernel_and_oracle(dev):
+    """The certified fast path (table scores + decision-margin test + exact redo of flagged sequences) must
+    return the exact kernel's states bit for bit -- on ordinary data (few flags) and on data with foreign
+    values (outside the table's domain, NaN: those sequences are flagged and redone)."""
+    from infercnv_amd import synth
+    pre, cs = _hmm_input(10000, 1061, seed=21)
+    means, sd, logPi, logDelta = synth.hmm_params_i6()
+    rng = np.random.default_rng(3)
+    foreign = pre.copy()
+    gi, ci = rng.integers(0, pre.shape[0], 300), rng.integers(0, pre.shape[1], 300)
+    foreign[gi, ci] = rng.choice([np.nan, 1e6, -5.0, 40.0, np.inf], size=300)
+    try:
+        for x, min_flagged in ((pre, 0), (foreign, 250)):
+            xd = to_dev(x)
+            dev.viterbi_set_mode(0)
+            st_fast, bad = dev.viterbi_cells(xd, cs, means, sd, logPi, logDelta)
+            stats = dev.viterbi_last_stats()
+            assert stats["path"] == "fast" and stats["sequences"] == 22 * 1061 and stats["table_intervals"] > 100
+            assert min_flagged <= stats["flagged"] <= max(2 * min_flagged, 0.01 * stats["sequences"])
+            dev.viterbi_set_mode(1)
+            st_exact, bad1 = dev.viterbi_cells(xd, cs, means, sd, logPi, logDelta)
+            assert dev.viterbi_last_stats()["path"] == "exact"
+            assert torch.equal(st_fast, st_exact) and int(bad.item()) == int(bad1.item())
+            if x is pre:
+                want, _ = oc.viterbi_cells(pre, cs, means, sd, logPi, logDelta)
+                np.testing.assert_array_equal(to_host(st_fast), want)
+    finally:
+        dev.viterbi_set_mode(0)
+
+
 def test_viterbi_adversarial_near_ties_bit_exact(dev):
     """Inputs sitting on emission-branch boundaries and state mid-points, 1-gene and 2-gene chromosomes."""
     from infercnv_amd import synth

@@ -1,0 +1,200 @@
+"""CPU tests of the certified fast Viterbi path's host side (no GPU, no kernel):
+
+  * the emission-score table built by libicnv_hip.so (host code, 80-bit arithmetic) against
+    independent 40-digit evaluations of the reference's emission formula
+    (R/inferCNV_HMM.R:1129-1133) -- the certified eps_tab must hold;
+  * eps_spec: the exact kernel's arithmetic (restated in oracle_np.emission_scores) against the
+    same 40-digit values -- the budgeted 5e-14 must hold with a wide margin;
+  * the certified recurrence itself, restated in NumPy from viterbi_fast.hip, against the oracle's
+    exact Viterbi: every sequence the margin test does NOT flag must carry the oracle's states,
+    also when the band is inflated a million-fold (many flags) and on inputs built to tie.
+"""
+import ctypes as ct
+
+import numpy as np
+import pytest
+
+import oracle_c as oc
+import oracle_np as onp
+from infercnv_amd import _lib, synth
+
+
+def _table_meta(K, means, sd):
+    L = _lib.load()
+    m, mp_ = _lib.f64(means)
+    meta, seg = np.zeros(8), np.zeros(32)
+    _lib.check(L.icnv_hmm_emission_table(K, mp_, float(sd), meta.ctypes.data_as(_lib._dp), seg.ctypes.data_as(_lib._dp),
+                                         None, 0))
+    return dict(n_int=int(meta[0]), x_lo=meta[1], x_hi=meta[2], eps_tab=meta[3], s_max=meta[4], deg=int(meta[5]),
+                n_seg=int(meta[6]), eps_spec=meta[7], seg=seg.reshape(8, 4))
+
+
+def _scores(K, means, sd, x, which):
+    L = _lib.load()
+    m, mp_ = _lib.f64(means)
+    xa, xp = _lib.f64(np.ravel(x))
+    out = np.zeros((xa.size, K))
+    ok = np.zeros(xa.size, dtype=np.uint8)
+    _lib.check(L.icnv_hmm_emission_scores(K, mp_, float(sd), xp, xa.size, which, out.ctypes.data_as(_lib._dp),
+                                          ok.ctypes.data_as(ct.c_void_p)))
+    return out.reshape(np.shape(x) + (K,)), ok.reshape(np.shape(x)).astype(bool)
+
+
+def _mp_scores(means, sd, xs):
+    mp = pytest.importorskip("mpmath")
+    mp.mp.dps = 40
+    out = []
+    for x in xs:
+        e = [-1 / mp.log(mp.erfc(abs(mp.mpf(float(x)) - mp.mpf(float(m))) / mp.mpf(float(sd)) / mp.sqrt(2)) / 2)
+             for m in means]
+        tot = sum(e)
+        out.append([mp.log(v / tot) for v in e])
+    return out
+
+
+PARAMS = {
+    "i6": lambda: synth.hmm_params_i6()[:2],
+    "i3": lambda: (np.array([1.0 - 1.6448536269514722 * 0.09, 1.0, 1.0 + 1.6448536269514722 * 0.09]), 0.09),
+}
+
+
+@pytest.mark.parametrize("which", ["i6", "i3"])
+def test_emission_table_meets_its_certified_bound(which):
+    means, sd = PARAMS[which]()
+    K = len(means)
+    t = _table_meta(K, means, sd)
+    assert t["eps_tab"] <= 2e-12 and t["n_int"] * K * (t["deg"] + 1) * 8 <= 152 * 1024
+    assert t["x_lo"] < means[0] - 5 * sd and t["x_hi"] > means[-1] + 5 * sd
+    rng = np.random.default_rng(11)
+    # interval edges, the state means (kinks), their neighbours, and random points
+    edges = []
+    for s in range(t["n_seg"]):
+        lo, inv_w, base, n_m1 = t["seg"][s]
+        edges += [lo + j / inv_w for j in rng.integers(0, int(n_m1) + 2, size=12)]
+    xs = np.concatenate([np.array(edges), means, np.nextafter(means, -np.inf), np.nextafter(means, np.inf),
+                         rng.uniform(t["x_lo"], t["x_hi"], 150), rng.normal(means[K // 2], 2 * sd, 150)])
+    xs = xs[(xs >= t["x_lo"]) & (xs <= t["x_hi"])]
+    tab, ok = _scores(K, means, sd, xs, 1)
+    ex80, _ = _scores(K, means, sd, xs, 0)
+    assert ok.all()
+    want = _mp_scores(means, sd, xs)
+    err_tab = max(abs(float(tab[i, k] - want[i][k])) for i in range(len(xs)) for k in range(K))
+    err_80 = max(abs(float(ex80[i, k] - want[i][k])) for i in range(len(xs)) for k in range(K))
+    assert err_80 < 2e-15            # the builder's 80-bit reference agrees with 40 digits (rounded to double)
+    assert err_tab <= t["eps_tab"]   # the certificate
+    # outside the domain / non-finite: not evaluated
+    _, ok2 = _scores(K, means, sd, np.array([t["x_lo"] - 1.0, t["x_hi"] + 1.0, np.nan, np.inf]), 1)
+    assert not ok2.any()
+
+
+def test_emission_spec_vs_exact():
+    """eps_spec: the exact kernel's emission arithmetic vs the mathematically exact scores."""
+    means, sd = PARAMS["i6"]()
+    t = _table_meta(6, means, sd)
+    rng = np.random.default_rng(12)
+    xs = np.concatenate([rng.uniform(t["x_lo"], t["x_hi"], 100000), rng.normal(1.0, 0.2, 100000), means])
+    spec = onp.emission_scores(xs, means, sd)
+    ex80, _ = _scores(6, means, sd, xs, 0)
+    assert np.abs(spec - ex80).max() < 4e-15 < t["eps_spec"] / 10
+    sub = xs[:300]
+    want = _mp_scores(means, sd, sub)
+    assert max(abs(float(spec[i, k] - want[i][k])) for i in range(len(sub)) for k in range(6)) < 4e-15
+
+
+def certified_viterbi_np(x, means, sd, logPi, logDelta, band_scale=1.0):
+    """NumPy restatement of viterbi_fast.hip for the sequences (columns) of one chromosome x (n, S).
+    Returns (states 1-based (n, S), flagged (S,))."""
+    K = len(means)
+    n, S = x.shape
+    t = _table_meta(K, means, sd)
+    eps = t["eps_tab"] + t["eps_spec"]
+    a, b = logPi[1, 0], logPi[0, 0]
+    ok = (x >= t["x_lo"]) & (x <= t["x_hi"])
+    sc, _ = _scores(K, means, sd, np.where(ok, x, means[0]), 1)
+    flag = ~ok.all(axis=0)
+    np1 = n + 1.0
+    B = (np.abs(logDelta[np.isfinite(logDelta)]).max() + abs(a)) + np1 * (t["s_max"] + abs(b))
+    thr = band_scale * 4.0 * np1 * (eps + 2.0 ** -51 * B)
+    nu = logDelta[None, :] + sc[0]
+    bp = np.zeros((n, S), dtype=np.int64)
+
+    def top2(v):
+        srt = np.sort(v, axis=1)
+        return srt[:, -1], srt[:, -2], np.argmax(v, axis=1)
+
+    with np.errstate(invalid="ignore"):
+        for i in range(1, n):
+            m1, m2, i1 = top2(nu)
+            flag |= ~(m1 - m2 > thr)
+            off = m1 + a
+            d = nu + b
+            flag |= (~(np.abs(d - off[:, None]) > thr)).any(axis=1)
+            bp[i] = (i1 << 6) | ((d >= off[:, None]) * (1 << np.arange(K))[None, :]).sum(axis=1)
+            nu = np.maximum(d, off[:, None]) + sc[i]
+        m1, m2, cur = top2(nu)
+        flag |= ~(m1 - m2 > thr)
+    st = np.zeros((n, S), dtype=np.uint8)
+    for i in range(n - 1, -1, -1):
+        st[i] = cur + 1
+        if i > 0:
+            cur = np.where((bp[i] >> cur) & 1, cur, (bp[i] >> 6) & 7)
+    return st, flag
+
+
+def _check(pre, cs, means, sd, logPi, logDelta, band_scale=1.0):
+    want, _ = oc.viterbi_cells(pre, cs, means, sd, logPi, logDelta)
+    n_seq = n_flag = 0
+    for k in range(len(cs) - 1):
+        seg = pre[cs[k]:cs[k + 1]]
+        if seg.shape[0] < 2:
+            continue
+        st, flag = certified_viterbi_np(seg, np.asarray(means), sd, logPi, logDelta, band_scale)
+        good = ~flag
+        np.testing.assert_array_equal(st[:, good], want[cs[k]:cs[k + 1]][:, good])
+        n_seq += seg.shape[1]
+        n_flag += int(flag.sum())
+    return n_seq, n_flag, want
+
+
+def test_certified_recurrence_matches_oracle_on_unflagged_sequences():
+    G, C = 2400, 160
+    x, cs = synth.make_matrix_np(G, C)
+    refs, _ = synth.groups(C)
+    _, pre, _ = oc.smooth_chain(x, cs, refs, want_pre_denoise=True)
+    means, sd, logPi, logDelta = synth.hmm_params_i6()
+    n_seq, n_flag, want = _check(pre, cs, means, sd, logPi, logDelta)
+    assert len(np.unique(want)) >= 4
+    assert n_flag <= 0.01 * n_seq                  # real-valued data: (almost) nothing is flagged
+    # a band a million times wider flags many sequences; the others must still be right
+    n_seq, n_flag2, _ = _check(pre, cs, means, sd, logPi, logDelta, band_scale=1e6)
+    assert n_flag2 > n_flag
+    # softer transition matrices (more state switches)
+    for t in (1e-2, 0.1):
+        Pi, delta = onp.get_HMM_i6(t)
+        _check(pre[:, :48], cs, means, sd, np.log(Pi), np.log(delta))
+
+
+def test_certified_recurrence_flags_ties_and_foreign_values():
+    means, sd, logPi, logDelta = synth.hmm_params_i6()
+    rng = np.random.default_rng(5)
+    sizes = [2, 3, 300, 64]
+    G, C = sum(sizes), 96
+    cs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    mids = (means[:-1] + means[1:]) / 2
+    pool = np.concatenate([means, mids, means + 0.67448975 * sd, [0.0, 1.0, 10.0, -3.0, 1e-300]])
+    x = rng.choice(pool, size=(G, C)) + rng.choice([0.0, 1e-16, -1e-16, 1e-12], size=(G, C))
+    x[:, :32] = rng.normal(1.0, 0.15, size=(G, 32))
+    x[5, 3] = np.nan
+    x[40, 4] = 1e6
+    n_seq, n_flag, _ = _check(x, cs, means, sd, logPi, logDelta)
+    assert n_flag >= 2
+
+
+def test_i3_certified_recurrence():
+    means, sd = PARAMS["i3"]()
+    G, C = 1500, 64
+    x, cs = synth.make_matrix_np(G, C)
+    refs, _ = synth.groups(C)
+    _, pre, _ = oc.smooth_chain(x, cs, refs, want_pre_denoise=True)
+    Pi, delta = onp.get_HMM_i3(1e-6)
+    _check(pre, cs, means, sd, np.log(Pi), np.log(delta))
