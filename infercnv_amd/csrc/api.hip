@@ -807,6 +807,9 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
         fa.b = b;
         fa.x_lo = g_fast.tab.x_lo;
         fa.x_hi = g_fast.tab.x_hi;
+        fa.cell_lo = g_fast.tab.cell_lo;
+        fa.inv_wc = g_fast.tab.inv_wc;
+        fa.n_cells_m1 = g_fast.tab.n_cells - 1;
         fa.eps = g_fast.tab.eps_tab + EPS_SPEC;
         fa.b0 = dmax + std::fabs(a);
         fa.s_step = g_fast.tab.s_max + std::fabs(b);

@@ -67,8 +67,10 @@ void emission_scores_exact(int K, const double *mean, double sd, double x, doubl
 
 bool emission_table_eval(const EmisTable &t, const double *mean, double x, double *s_out) {
     if (!(x >= t.x_lo && x <= t.x_hi)) return false;
-    int s = 0;
-    for (int k = 0; k < t.K; ++k) s += (x >= mean[k]) ? 1 : 0;
+    (void)mean;
+    int ci = (int)((x - t.cell_lo) * t.inv_wc);
+    if (ci > t.n_cells - 1) ci = t.n_cells - 1;
+    const int s = t.cell[ci].seg_below + ((x >= t.cell[ci].boundary) ? 1 : 0);
     const EmisSegment &sg = t.seg[s];
     const double u = (x - sg.lo) * sg.inv_w;
     int fi = (int)u;   // u >= 0: truncation == floor
@@ -144,6 +146,30 @@ int build_emission_table(int K, const double *mean, double sd, int max_intervals
     out.x_hi = (double)((long double)out.seg[K].lo + (long double)n_of[K] / (long double)out.seg[K].inv_w);
     out.x_hi = std::nextafter(out.x_hi, mean[K - 1]);
     out.coef.assign((size_t)out.n_int * K * NC, 0.0);
+    {   // segment lookup cells
+        double gap = mean[1] - mean[0];
+        for (int k = 2; k < K; ++k) gap = std::fmin(gap, mean[k] - mean[k - 1]);
+        out.cell_lo = out.seg[0].lo;
+        const double width = out.x_hi - out.cell_lo;
+        int nc = (int)std::ceil(width / (0.75 * gap)) + 1;
+        if (nc < 1) nc = 1;
+        if (nc > EMIS_MAX_CELLS) { *why = "state means too close together for the segment lookup"; return 1; }
+        out.n_cells = nc;
+        out.inv_wc = (double)nc / width;
+        for (int c = 0; c < nc; ++c) { out.cell[c].boundary = INFINITY; out.cell[c].seg_below = 0; out.cell[c].pad = 0; }
+        int ck[8];
+        for (int k = 0; k < K; ++k) {
+            ck[k] = (int)((mean[k] - out.cell_lo) * out.inv_wc);
+            if (ck[k] > nc - 1) ck[k] = nc - 1;
+            if (k && ck[k] <= ck[k - 1]) { *why = "two state means share a lookup cell"; return 1; }
+            out.cell[ck[k]].boundary = mean[k];
+        }
+        for (int c = 0; c < nc; ++c) {
+            int below = 0;
+            for (int k = 0; k < K; ++k) below += (ck[k] < c) ? 1 : 0;
+            out.cell[c].seg_below = below;
+        }
+    }
 
     // check positions: the extrema of T_{NC} (where the interpolation error peaks) and two more per gap
     long double chk[4 * NC + 1];

@@ -28,6 +28,17 @@ struct EmisSegment {                 // 32 bytes, one per segment, read by the k
     int32_t pad[2];
 };
 
+// Segment lookup: [seg[0].lo, x_hi] is cut into n_cells equal cells narrower than the smallest gap between two
+// means, so a cell holds at most one mean: the segment of x is seg_below + (x >= boundary).  The cell of a mean is
+// computed with the same double operations as the cell of an observation (both are monotone in x), which makes
+// the lookup exact whatever the rounding at the cell edges.
+struct EmisCell {                    // 16 bytes
+    double boundary;                 // the mean inside this cell, +inf when there is none
+    int32_t seg_below;               // segment of the observations of this cell that are below the boundary
+    int32_t pad;
+};
+constexpr int EMIS_MAX_CELLS = 256;
+
 struct EmisTable {
     int K = 0;
     int n_seg = 0;                   // K + 1
@@ -37,6 +48,9 @@ struct EmisTable {
     double s_max = 0;                // max |score| over the domain (bounds the magnitude of the DP values)
     double width_sigma = 0;          // target interval width in units of sd
     EmisSegment seg[EMIS_MAX_SEG];
+    double cell_lo = 0, inv_wc = 0;  // cell index = (int)((x - cell_lo) * inv_wc), clamped to n_cells - 1
+    int n_cells = 0;
+    EmisCell cell[EMIS_MAX_CELLS];
     std::vector<double> coef;        // [n_int][K][EMIS_DEG + 1], c0 first
 };
 

@@ -122,6 +122,8 @@ struct FastViterbiArgs {
     double logDelta[8];
     double a, b;                // log off-diagonal / diagonal transition probability
     double x_lo, x_hi;          // table domain
+    double cell_lo, inv_wc;     // segment lookup cells
+    int32_t n_cells_m1;
     double eps;                 // eps_tab + eps_spec
     double b0, s_step;          // |value| bound of the recurrence: B = b0 + (n + 1) s_step
     uint16_t *bp;               // [G][ncols]

@@ -43,7 +43,9 @@ namespace {
 
 constexpr int FAST_NT = 1024;
 constexpr int NCF = EMIS_DEG + 1;
-constexpr int SEG_DOUBLES = EMIS_MAX_SEG * 4;   // segment records at the start of the LDS image
+constexpr int SEG_DOUBLES = EMIS_MAX_SEG * 4 + EMIS_MAX_CELLS * 2;   // segment records + lookup cells at the start of the LDS image
+constexpr int CELL_OFF = EMIS_MAX_SEG * 4;
+typedef double dbl2_t __attribute__((ext_vector_type(2)));
 
 template <int K>
 __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbiArgs A) {
@@ -77,23 +79,23 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             continue;
         }
         uint16_t *bpc = A.bp + (int64_t)s0 * A.ncols + col;
-        // decision band of this task: 4 (n + 1) (eps + 4 u B), B = |logDelta|max + |a| + (n + 1)(s_max + |b|)
+            // decision band of this task: 4 (n + 1) (eps + 4 u B), B = |logDelta|max + |a| + (n + 1)(s_max + |b|)
         const double np1 = (double)(n + 1);
         const double B = A.b0 + np1 * A.s_step;
         const double thr = 4.0 * np1 * (A.eps + 0x1p-51 * B);
 
-        double nu[K], sc[K];
-        bool flag = false;
-        double xn = xc[0];
-        for (int i = 0; i < n; ++i) {
-            const double xv = xn;
-            if (i + 1 < n) xn = xc[i + 1];
+        double nu[K];
+        bool seqflag = false;   // an observation the table cannot score: the whole sequence goes to the exact kernel
+        // scores of one observation from the table (K polynomials of the position inside its interval)
+        auto scores = [&](double xv, double (&sc)[K]) {
             const bool ok = (xv >= A.x_lo) && (xv <= A.x_hi);   // false for NaN
-            flag |= !ok;
-            const double xs = ok ? xv : A.mean[0];
-            int seg = 0;
-#pragma unroll
-            for (int k = 0; k < K; ++k) seg += (xs >= A.mean[k]) ? 1 : 0;
+            seqflag |= !ok;
+            const double xs = ok ? xv : A.x_lo;
+            // segment (which state means lie below xs) from the lookup cells: at most one mean per cell
+            int ci = (int)((xs - A.cell_lo) * A.inv_wc);
+            ci = ci > A.n_cells_m1 ? A.n_cells_m1 : ci;
+            const double2 cl = *reinterpret_cast<const double2 *>(tab + CELL_OFF + 2 * ci);   // boundary, {seg_below, pad}
+            const int seg = (int)(uint32_t)__double_as_longlong(cl.y) + ((xs >= cl.x) ? 1 : 0);
             const double2 sg = *reinterpret_cast<const double2 *>(tab + 4 * seg);           // lo, inv_w
             const int2 sn = *reinterpret_cast<const int2 *>(tab + 4 * seg + 2);             // base, n - 1
             const double u = (xs - sg.x) * sg.y;
@@ -112,11 +114,12 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
                 p = __builtin_fma(p, tn, c01.y);
                 sc[k] = __builtin_fma(p, tn, c01.x);
             }
-            if (i == 0) {
-#pragma unroll
-                for (int k = 0; k < K; ++k) nu[k] = A.logDelta[k] + sc[k];
-                continue;
-            }
+        };
+        // One step of the recurrence.  Back-pointer word: bits 0..K-1 "row k keeps itself", bits 6..8 the best
+        // predecessor overall (i1), bits 9..9+K-1 "row k's decision lies inside the error band".  Row k's decision
+        // is certain when |diag - off| > thr and -- if the off-diagonal candidate wins -- the best predecessor
+        // leads the second best by more than thr as well.
+        auto step = [&](const double (&sc)[K]) -> uint32_t {
             double m1 = nu[0], m2 = -__builtin_inf();
             uint32_t i1 = 0;
 #pragma unroll
@@ -126,17 +129,53 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
                 i1 = (v > m1) ? (uint32_t)k : i1;
                 m1 = __builtin_fmax(m1, v);
             }
-            flag |= !(m1 - m2 > thr);
+            const bool top_unsure = !(m1 - m2 > thr);
             const double off = m1 + A.a;
             uint32_t word = i1 << 6;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const double d = nu[k] + A.b;
-                flag |= !(__builtin_fabs(d - off) > thr);
-                word |= (d >= off) ? (1u << k) : 0u;
+                const bool keep = d >= off;
+                const bool unsure = !(__builtin_fabs(d - off) > thr) || (!keep && top_unsure);
+                word |= keep ? (1u << k) : 0u;
+                word |= unsure ? (512u << k) : 0u;
                 nu[k] = __builtin_fmax(d, off) + sc[k];
             }
-            bpc[(int64_t)i * A.ncols] = (uint16_t)word;
+            return word;
+        };
+        // observations are streamed four genes (32 bytes) per lane and request: a lane walks its own column, so
+        // 8-byte requests would fetch every cache line sixteen times through an L1 that cannot hold 1024 of them
+        auto load4 = [&](const double *p, int cnt, double (&v)[4]) {
+            if (cnt >= 4) {
+                const dbl2_t a0 = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t *>(p));
+                const dbl2_t a1 = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t *>(p) + 1);
+                v[0] = a0.x; v[1] = a0.y; v[2] = a1.x; v[3] = a1.y;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (j < cnt) ? p[j] : 0.0;
+            }
+        };
+        {
+            double sc[K];
+            scores(xc[0], sc);
+#pragma unroll
+            for (int k = 0; k < K; ++k) nu[k] = A.logDelta[k] + sc[k];
+        }
+        double xcur[4], xnext[4];
+        load4(xc + 1, n - 1, xcur);
+        for (int i0 = 1; i0 < n; i0 += 4) {
+            if (i0 + 4 < n) load4(xc + i0 + 4, n - (i0 + 4), xnext);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (i0 + j < n) {
+                    double sc[K];
+                    scores(xcur[j], sc);
+                    const uint32_t word = step(sc);
+                    bpc[(int64_t)(i0 + j) * A.ncols] = (uint16_t)word;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xcur[j] = xnext[j];
         }
         // last row: R's which.max
         double m1 = nu[0], m2 = -__builtin_inf();
@@ -148,16 +187,21 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             cur = (v > m1) ? k : cur;
             m1 = __builtin_fmax(m1, v);
         }
-        flag |= !(m1 - m2 > thr);
-        if (flag) {
+        // the traceback follows the decisions of ONE path: only an uncertain decision ON that path (or an
+        // uncertain final arg-max) can make the exact arithmetic trace a different one
+        uint32_t unsure = (seqflag || !(m1 - m2 > thr)) ? 1u : 0u;
+        const int64_t nc = A.ncols;
+        viterbi_traceback(
+            st, n, cur, [&](int i) { return (uint32_t)bpc[(int64_t)i * nc]; },
+            [&](uint32_t w, int c) {
+                unsure |= (w >> (9 + c)) & 1u;
+                return ((w >> c) & 1u) ? c : (int)((w >> 6) & 7u);
+            });
+        if (unsure) {
             const int e = atomicAdd(A.flag_count, 1);
             A.flag_list[2 * (int64_t)e] = chr;
             A.flag_list[2 * (int64_t)e + 1] = (int32_t)col;
         }
-        const int64_t nc = A.ncols;
-        viterbi_traceback(
-            st, n, cur, [&](int i) { return (uint32_t)bpc[(int64_t)i * nc]; },
-            [](uint32_t w, int c) { return ((w >> c) & 1u) ? c : (int)((w >> 6) & 7u); });
     }
 }
 
@@ -178,6 +222,11 @@ void viterbi_fast_table_image(const EmisTable &t, std::vector<double> &img) {
         img[4 * s + 1] = t.seg[s].inv_w;
         int32_t bn[2] = {t.seg[s].base, t.seg[s].n_m1};
         std::memcpy(&img[4 * s + 2], bn, sizeof(bn));
+    }
+    for (int c = 0; c < t.n_cells; ++c) {
+        img[CELL_OFF + 2 * c] = t.cell[c].boundary;
+        int32_t sb[2] = {t.cell[c].seg_below, 0};
+        std::memcpy(&img[CELL_OFF + 2 * c + 1], sb, sizeof(sb));
     }
     std::copy(t.coef.begin(), t.coef.end(), img.begin() + SEG_DOUBLES);
     if (img.size() & 1) img.push_back(0.0);   // the kernel copies 16 bytes at a time

@@ -12,6 +12,7 @@ at offset g + G*c.  State matrices are uint8 (C, G).
 from __future__ import annotations
 
 import ctypes as ct
+import os
 
 import numpy as np
 import torch
@@ -40,6 +41,8 @@ def init(device=None):
     if device is None:
         device = torch.cuda.current_device()
     check(L.icnv_init(int(device)))
+    if os.environ.get("ICNV_VITERBI_MODE"):     # developer switch: 1 = exact Viterbi kernel only (see viterbi_set_mode)
+        check(L.icnv_viterbi_set_mode(int(os.environ["ICNV_VITERBI_MODE"])))
 
 
 # ------------------------------------------------------------------ smoothing chain
