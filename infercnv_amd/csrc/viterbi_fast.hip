@@ -37,11 +37,28 @@
 
 #pragma clang fp contract(off)
 
+#ifndef ICNV_VF_EXP
+#define ICNV_VF_EXP 0
+#endif
+
 namespace icnv {
 
 namespace {
 
-constexpr int FAST_NT = 1024;
+#ifndef ICNV_VF_NT
+#define ICNV_VF_NT 512    // 2 wavefronts per SIMD measured fastest (256: 5.2 ms, 384: 4.2, 512: 3.65, 640: 4.6, 768: 4.6, 1024: 6.7):
+                          // half as many column streams per XCD (their lines survive in the 4 MiB L2) and no register spills
+#endif
+#ifndef ICNV_VF_SB
+#define ICNV_VF_SB 1
+#endif
+#ifndef ICNV_VF_CH
+#define ICNV_VF_CH 8
+#endif
+#ifndef ICNV_VF_POLICY
+#define ICNV_VF_POLICY 1   // bit 0: observations with the default cache policy (else non-temporal); bit 1: back-pointer / state traffic non-temporal
+#endif
+constexpr int FAST_NT = ICNV_VF_NT;
 constexpr int NCF = EMIS_DEG + 1;
 constexpr int SEG_DOUBLES = EMIS_MAX_SEG * 4 + EMIS_MAX_CELLS * 2;   // segment records + lookup cells at the start of the LDS image
 constexpr int CELL_OFF = EMIS_MAX_SEG * 4;
@@ -86,11 +103,19 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
 
         double nu[K];
         bool seqflag = false;   // an observation the table cannot score: the whole sequence goes to the exact kernel
-        // scores of one observation from the table (K polynomials of the position inside its interval)
-        auto scores = [&](double xv, double (&sc)[K]) {
+        // Scores of one observation from the table, in two stages so that the LDS round trips of several genes
+        // overlap: locate() finds the interval (lookup cell -> segment record -> interval index) and the position
+        // inside it; poly() evaluates the K polynomials.  Coefficients are stored state-major ([k][interval][6]):
+        // records of one state are 48 bytes apart, an odd number of 16-byte bank groups, so the lanes' random
+        // intervals spread over all LDS banks.
+        const int plane = A.n_int * NCF;   // doubles per state
+        auto locate = [&](double xv, int &idx, double &tn) {
             const bool ok = (xv >= A.x_lo) && (xv <= A.x_hi);   // false for NaN
             seqflag |= !ok;
             const double xs = ok ? xv : A.x_lo;
+#if ICNV_VF_EXP & 32
+            tn = xs * 0.01; idx = ((int)(xs * 100.0) & 255) * NCF; return;
+#endif
             // segment (which state means lie below xs) from the lookup cells: at most one mean per cell
             int ci = (int)((xs - A.cell_lo) * A.inv_wc);
             ci = ci > A.n_cells_m1 ? A.n_cells_m1 : ci;
@@ -101,13 +126,21 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             const double u = (xs - sg.x) * sg.y;
             int fi = (int)u;
             fi = fi > sn.y ? sn.y : fi;
-            const double tn = (u - (double)fi) - 0.5;
-            const double *c = coef + (sn.x + fi) * (K * NCF);
+            tn = (u - (double)fi) - 0.5;
+            idx = (sn.x + fi) * NCF;
+        };
+        auto poly = [&](int idx, double tn, double (&sc)[K]) {
+            const double *c = coef + idx;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const double2 c01 = *reinterpret_cast<const double2 *>(c + k * NCF);
-                const double2 c23 = *reinterpret_cast<const double2 *>(c + k * NCF + 2);
-                const double2 c45 = *reinterpret_cast<const double2 *>(c + k * NCF + 4);
+#if ICNV_VF_EXP & 16
+                const double2 c01 = make_double2(tn + k, tn * 2), c23 = make_double2(tn + 3, tn + 4 * k), c45 = make_double2(0.1 * tn, tn + 7);
+                (void)c;
+#else
+                const double2 c01 = *reinterpret_cast<const double2 *>(c + k * plane);
+                const double2 c23 = *reinterpret_cast<const double2 *>(c + k * plane + 2);
+                const double2 c45 = *reinterpret_cast<const double2 *>(c + k * plane + 4);
+#endif
                 double p = __builtin_fma(c45.y, tn, c45.x);
                 p = __builtin_fma(p, tn, c23.y);
                 p = __builtin_fma(p, tn, c23.x);
@@ -134,6 +167,9 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             uint32_t word = i1 << 6;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
+#if ICNV_VF_EXP & 4
+                nu[k] += sc[k]; continue;
+#endif
                 const double d = nu[k] + A.b;
                 const bool keep = d >= off;
                 const bool unsure = !(__builtin_fabs(d - off) > thr) || (!keep && top_unsure);
@@ -143,40 +179,77 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             }
             return word;
         };
-        // observations are streamed four genes (32 bytes) per lane and request: a lane walks its own column, so
-        // 8-byte requests would fetch every cache line sixteen times through an L1 that cannot hold 1024 of them
-        auto load4 = [&](const double *p, int cnt, double (&v)[4]) {
-            if (cnt >= 4) {
-                const dbl2_t a0 = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t *>(p));
-                const dbl2_t a1 = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t *>(p) + 1);
-                v[0] = a0.x; v[1] = a0.y; v[2] = a1.x; v[3] = a1.y;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (j < cnt) ? p[j] : 0.0;
-            }
+        auto gene = [&](double xv, int i) {
+            double sc[K], tn;
+            int idx;
+            locate(xv, idx, tn);
+            poly(idx, tn, sc);
+            const uint32_t word = step(sc);
+#if ICNV_VF_EXP & 2
+            if (word == 0xdeadbeefu)
+#endif
+#if ICNV_VF_POLICY & 2
+            __builtin_nontemporal_store((uint16_t)word, bpc + (int64_t)i * A.ncols);
+#else
+            bpc[(int64_t)i * A.ncols] = (uint16_t)word;
+#endif
+#if ICNV_VF_SB
+            __builtin_amdgcn_sched_barrier(0);   // one gene at a time: interleaving the unrolled genes only spills
+#endif
         };
         {
-            double sc[K];
-            scores(xc[0], sc);
+            double sc[K], tn0;
+            int idx0;
+            locate(xc[0], idx0, tn0);
+            poly(idx0, tn0, sc);
 #pragma unroll
             for (int k = 0; k < K; ++k) nu[k] = A.logDelta[k] + sc[k];
         }
-        double xcur[4], xnext[4];
-        load4(xc + 1, n - 1, xcur);
-        for (int i0 = 1; i0 < n; i0 += 4) {
-            if (i0 + 4 < n) load4(xc + i0 + 4, n - (i0 + 4), xnext);
+        // Observations are streamed CH genes (64 bytes, one aligned half cache line when G is a multiple of 8) per
+        // lane and request: every lane walks its own column, so the memory system sees 64 streams per wavefront;
+        // 8-byte requests would fetch each line sixteen times through an L1 that cannot hold 1024 of them, and
+        // small unaligned pieces of a DRAM burst arrive as separate requests long after the burst was evicted.
+        constexpr int CH = ICNV_VF_CH;
+        auto load_chunk = [&](const double *p, double (&v)[CH]) {
+#if ICNV_VF_EXP & 8
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (i0 + j < n) {
-                    double sc[K];
-                    scores(xcur[j], sc);
-                    const uint32_t word = step(sc);
-                    bpc[(int64_t)(i0 + j) * A.ncols] = (uint16_t)word;
+            for (int j = 0; j < CH; ++j) v[j] = 1.0 + 1e-3 * lane + 0.01 * j;
+            return;
+#endif
+#pragma unroll
+            for (int j = 0; j < CH; j += 2) {
+#if ICNV_VF_POLICY & 1
+                const dbl2_t a0 = *reinterpret_cast<const dbl2_t *>(p + j);
+#else
+                const dbl2_t a0 = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t *>(p + j));
+#endif
+                v[j] = a0.x;
+                v[j + 1] = a0.y;
+            }
+        };
+        int i = 1;
+        {   // wave-uniform peel up to lane 0's next 64-byte boundary
+            const uint64_t a0 = (uint64_t)(uintptr_t)(xc + 1);
+            constexpr uint32_t AL = CH * 8;
+            int peel = (int)(((AL - (uint32_t)(a0 & (AL - 1))) & (AL - 1)) >> 3);
+            peel = __builtin_amdgcn_readfirstlane(peel);
+            for (; peel > 0 && i < n; --peel, ++i) gene(xc[i], i);
+        }
+        if (i + CH <= n) {
+            double xcur[CH], xnext[CH];
+            load_chunk(xc + i, xcur);
+            for (; i + CH <= n; i += CH) {
+                const bool more = i + 2 * CH <= n;
+                if (more) load_chunk(xc + i + CH, xnext);
+#pragma unroll
+                for (int j = 0; j < CH; ++j) gene(xcur[j], i + j);
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) xcur[j] = xnext[j];
                 }
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xcur[j] = xnext[j];
         }
+        for (; i < n; ++i) gene(xc[i], i);
         // last row: R's which.max
         double m1 = nu[0], m2 = -__builtin_inf();
         int cur = 0;
@@ -191,8 +264,16 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         // uncertain final arg-max) can make the exact arithmetic trace a different one
         uint32_t unsure = (seqflag || !(m1 - m2 > thr)) ? 1u : 0u;
         const int64_t nc = A.ncols;
+#if ICNV_VF_EXP & 1
+        if (m1 == 12345.678) 
+#endif
         viterbi_traceback(
-            st, n, cur, [&](int i) { return (uint32_t)bpc[(int64_t)i * nc]; },
+            st, n, cur,
+#if ICNV_VF_POLICY & 2
+            [&](int i) { return (uint32_t)__builtin_nontemporal_load(bpc + (int64_t)i * nc); },
+#else
+            [&](int i) { return (uint32_t)bpc[(int64_t)i * nc]; },
+#endif
             [&](uint32_t w, int c) {
                 unsure |= (w >> (9 + c)) & 1u;
                 return ((w >> c) & 1u) ? c : (int)((w >> 6) & 7u);
@@ -228,7 +309,10 @@ void viterbi_fast_table_image(const EmisTable &t, std::vector<double> &img) {
         int32_t sb[2] = {t.cell[c].seg_below, 0};
         std::memcpy(&img[CELL_OFF + 2 * c + 1], sb, sizeof(sb));
     }
-    std::copy(t.coef.begin(), t.coef.end(), img.begin() + SEG_DOUBLES);
+    for (int i = 0; i < t.n_int; ++i)
+        for (int k = 0; k < t.K; ++k)
+            for (int j = 0; j < NCF; ++j)
+                img[SEG_DOUBLES + ((size_t)k * t.n_int + i) * NCF + j] = t.coef[((size_t)i * t.K + k) * NCF + j];
     if (img.size() & 1) img.push_back(0.0);   // the kernel copies 16 bytes at a time
 }
 

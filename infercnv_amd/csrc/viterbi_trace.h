@@ -1,8 +1,8 @@
 // Traceback shared by the exact and the certified-fast Viterbi kernels: walks one sequence from its
 // last gene to its first, emitting the 1-based state of every gene (uint8), eight consecutive genes
 // per 8-byte store where the alignment allows.  The back-pointer words of eight genes are requested
-// before they are consumed (their addresses do not depend on the state being traced), so the walk
-// is not one exposed memory latency per gene.
+// a whole group before they are consumed (their addresses do not depend on the state being traced),
+// so the walk is not one exposed memory latency per gene.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -17,10 +17,15 @@ __device__ inline void viterbi_traceback(uint8_t *st, int n, int cur, Load load,
     const uint64_t last = base + (uint64_t)(n - 1);
     uint64_t word = 0;
     int i = n - 1;
+    uint32_t Wn[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Wn[j] = (i - j > 0) ? load(i - j) : 0u;
     while (i >= 0) {
         uint32_t W[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) W[j] = (i - j > 0) ? load(i - j) : 0u;
+        for (int j = 0; j < 8; ++j) W[j] = Wn[j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Wn[j] = (i - 8 - j > 0) ? load(i - 8 - j) : 0u;   // the next group, a group ahead
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int g = i - j;
