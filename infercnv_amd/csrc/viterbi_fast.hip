@@ -49,6 +49,9 @@ namespace {
 #define ICNV_VF_NT 512    // 2 wavefronts per SIMD measured fastest (256: 5.2 ms, 384: 4.2, 512: 3.65, 640: 4.6, 768: 4.6, 1024: 6.7):
                           // half as many column streams per XCD (their lines survive in the 4 MiB L2) and no register spills
 #endif
+#ifndef ICNV_VF_TG
+#define ICNV_VF_TG 32   // traceback group: 2 x 32 back-pointer lines in flight per wavefront
+#endif
 #ifndef ICNV_VF_SB
 #define ICNV_VF_SB 1
 #endif
@@ -62,13 +65,29 @@ constexpr int FAST_NT = ICNV_VF_NT;
 constexpr int NCF = EMIS_DEG + 1;
 constexpr int SEG_DOUBLES = EMIS_MAX_SEG * 4 + EMIS_MAX_CELLS * 2;   // segment records + lookup cells at the start of the LDS image
 constexpr int CELL_OFF = EMIS_MAX_SEG * 4;
+// coefficient record of one interval: K x 6 doubles padded to an ODD number of 16-byte bank groups (the lanes'
+// random intervals then spread over all LDS banks) -- the K states sit at immediate offsets of one address
+constexpr int rec_doubles(int K) { return ((K * NCF / 2) | 1) * 2; }
 typedef double dbl2_t __attribute__((ext_vector_type(2)));
+
+// v_min_f64 / v_max_f64 without the compiler's canonicalisation of both inputs (every operand here is the
+// result of an arithmetic instruction; a NaN takes the flagged path anyway)
+__device__ inline double min_raw(double x, double y) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ inline double max_raw(double x, double y) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
 
 template <int K>
 __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbiArgs A) {
     extern __shared__ __attribute__((aligned(16))) double tab[];
     {
-        const int n_dbl = SEG_DOUBLES + A.n_int * K * NCF;
+        const int n_dbl = SEG_DOUBLES + A.n_int * rec_doubles(K);
         const double2 *src = reinterpret_cast<const double2 *>(A.table);
         double2 *dst = reinterpret_cast<double2 *>(tab);
         for (int i = threadIdx.x; i < n_dbl / 2; i += FAST_NT) dst[i] = src[i];
@@ -105,17 +124,12 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         bool seqflag = false;   // an observation the table cannot score: the whole sequence goes to the exact kernel
         // Scores of one observation from the table, in two stages so that the LDS round trips of several genes
         // overlap: locate() finds the interval (lookup cell -> segment record -> interval index) and the position
-        // inside it; poly() evaluates the K polynomials.  Coefficients are stored state-major ([k][interval][6]):
-        // records of one state are 48 bytes apart, an odd number of 16-byte bank groups, so the lanes' random
-        // intervals spread over all LDS banks.
-        const int plane = A.n_int * NCF;   // doubles per state
+        // inside it; poly() evaluates the K polynomials.
+        constexpr int REC = rec_doubles(K);
         auto locate = [&](double xv, int &idx, double &tn) {
             const bool ok = (xv >= A.x_lo) && (xv <= A.x_hi);   // false for NaN
             seqflag |= !ok;
             const double xs = ok ? xv : A.x_lo;
-#if ICNV_VF_EXP & 32
-            tn = xs * 0.01; idx = ((int)(xs * 100.0) & 255) * NCF; return;
-#endif
             // segment (which state means lie below xs) from the lookup cells: at most one mean per cell
             int ci = (int)((xs - A.cell_lo) * A.inv_wc);
             ci = ci > A.n_cells_m1 ? A.n_cells_m1 : ci;
@@ -127,7 +141,7 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             int fi = (int)u;
             fi = fi > sn.y ? sn.y : fi;
             tn = (u - (double)fi) - 0.5;
-            idx = (sn.x + fi) * NCF;
+            idx = (sn.x + fi) * REC;
         };
         auto poly = [&](int idx, double tn, double (&sc)[K]) {
             const double *c = coef + idx;
@@ -137,9 +151,9 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
                 const double2 c01 = make_double2(tn + k, tn * 2), c23 = make_double2(tn + 3, tn + 4 * k), c45 = make_double2(0.1 * tn, tn + 7);
                 (void)c;
 #else
-                const double2 c01 = *reinterpret_cast<const double2 *>(c + k * plane);
-                const double2 c23 = *reinterpret_cast<const double2 *>(c + k * plane + 2);
-                const double2 c45 = *reinterpret_cast<const double2 *>(c + k * plane + 4);
+                const double2 c01 = *reinterpret_cast<const double2 *>(c + k * NCF);
+                const double2 c23 = *reinterpret_cast<const double2 *>(c + k * NCF + 2);
+                const double2 c45 = *reinterpret_cast<const double2 *>(c + k * NCF + 4);
 #endif
                 double p = __builtin_fma(c45.y, tn, c45.x);
                 p = __builtin_fma(p, tn, c23.y);
@@ -158,24 +172,33 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
 #pragma unroll
             for (int k = 1; k < K; ++k) {
                 const double v = nu[k];
-                m2 = __builtin_fmax(m2, __builtin_fmin(m1, v));
+                m2 = max_raw(m2, min_raw(m1, v));
                 i1 = (v > m1) ? (uint32_t)k : i1;
-                m1 = __builtin_fmax(m1, v);
+                m1 = max_raw(m1, v);
             }
             const bool top_unsure = !(m1 - m2 > thr);
+            bool any = top_unsure;
             const double off = m1 + A.a;
             uint32_t word = i1 << 6;
+            double d[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
 #if ICNV_VF_EXP & 4
-                nu[k] += sc[k]; continue;
+                nu[k] += sc[k]; d[k] = 0.0; continue;
 #endif
-                const double d = nu[k] + A.b;
-                const bool keep = d >= off;
-                const bool unsure = !(__builtin_fabs(d - off) > thr) || (!keep && top_unsure);
-                word |= keep ? (1u << k) : 0u;
-                word |= unsure ? (512u << k) : 0u;
-                nu[k] = __builtin_fmax(d, off) + sc[k];
+                d[k] = nu[k] + A.b;
+                any |= !(__builtin_fabs(d[k] - off) > thr);
+                word |= (d[k] >= off) ? (1u << k) : 0u;
+                nu[k] = max_raw(d[k], off) + sc[k];
+            }
+            // the "inside the band" bits are needed by almost no gene: one scalar branch for the whole wavefront
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) != 0, 0)) {
+                asm volatile("; uncertain decision in this wavefront" ::: "memory");   // keeps the block a real branch
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const bool unsure = !(__builtin_fabs(d[k] - off) > thr) || (!(d[k] >= off) && top_unsure);
+                    word |= unsure ? (512u << k) : 0u;
+                }
             }
             return word;
         };
@@ -256,9 +279,9 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
 #pragma unroll
         for (int k = 1; k < K; ++k) {
             const double v = nu[k];
-            m2 = __builtin_fmax(m2, __builtin_fmin(m1, v));
+            m2 = max_raw(m2, min_raw(m1, v));
             cur = (v > m1) ? k : cur;
-            m1 = __builtin_fmax(m1, v);
+            m1 = max_raw(m1, v);
         }
         // the traceback follows the decisions of ONE path: only an uncertain decision ON that path (or an
         // uncertain final arg-max) can make the exact arithmetic trace a different one
@@ -267,7 +290,7 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
 #if ICNV_VF_EXP & 1
         if (m1 == 12345.678) 
 #endif
-        viterbi_traceback(
+        viterbi_traceback<ICNV_VF_TG>(
             st, n, cur,
 #if ICNV_VF_POLICY & 2
             [&](int i) { return (uint32_t)__builtin_nontemporal_load(bpc + (int64_t)i * nc); },
@@ -289,10 +312,10 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
 }  // namespace
 
 size_t viterbi_fast_scratch_bytes(int32_t G, int64_t n_cols) { return (size_t)G * (size_t)n_cols * sizeof(uint16_t); }
-size_t viterbi_fast_lds_bytes(int K, int n_int) { return ((size_t)SEG_DOUBLES + (size_t)n_int * K * NCF) * sizeof(double); }
+size_t viterbi_fast_lds_bytes(int K, int n_int) { return ((size_t)SEG_DOUBLES + (size_t)n_int * rec_doubles(K)) * sizeof(double); }
 int viterbi_fast_max_intervals(int K) {
     // leave 8 KiB of the 160 KiB for the runtime; 16-B granularity
-    return (int)((152 * 1024 - SEG_DOUBLES * sizeof(double)) / ((size_t)K * NCF * sizeof(double)));
+    return (int)((152 * 1024 - SEG_DOUBLES * sizeof(double)) / ((size_t)rec_doubles(K) * sizeof(double)));
 }
 
 // Device image of the table: EMIS_MAX_SEG segment records (lo, inv_w, {base, n-1}, pad) then the coefficients.
@@ -309,10 +332,12 @@ void viterbi_fast_table_image(const EmisTable &t, std::vector<double> &img) {
         int32_t sb[2] = {t.cell[c].seg_below, 0};
         std::memcpy(&img[CELL_OFF + 2 * c + 1], sb, sizeof(sb));
     }
+    const int rec = rec_doubles(t.K);
+    img.resize(SEG_DOUBLES + (size_t)t.n_int * rec, 0.0);
     for (int i = 0; i < t.n_int; ++i)
         for (int k = 0; k < t.K; ++k)
             for (int j = 0; j < NCF; ++j)
-                img[SEG_DOUBLES + ((size_t)k * t.n_int + i) * NCF + j] = t.coef[((size_t)i * t.K + k) * NCF + j];
+                img[SEG_DOUBLES + (size_t)i * rec + k * NCF + j] = t.coef[((size_t)i * t.K + k) * NCF + j];
     if (img.size() & 1) img.push_back(0.0);   // the kernel copies 16 bytes at a time
 }
 

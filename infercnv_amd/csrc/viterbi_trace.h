@@ -1,6 +1,6 @@
 // Traceback shared by the exact and the certified-fast Viterbi kernels: walks one sequence from its
 // last gene to its first, emitting the 1-based state of every gene (uint8), eight consecutive genes
-// per 8-byte store where the alignment allows.  The back-pointer words of eight genes are requested
+// per 8-byte store where the alignment allows.  The back-pointer words of a group of genes are requested
 // a whole group before they are consumed (their addresses do not depend on the state being traced),
 // so the walk is not one exposed memory latency per gene.
 #pragma once
@@ -11,25 +11,26 @@ namespace icnv {
 
 // load(i)  -> raw back-pointer word of gene i (1 <= i < n)
 // step(w, cur) -> predecessor state (0-based) of state `cur` given gene i's word
-template <class Load, class Step>
+template <int TG, class Load, class Step>
 __device__ inline void viterbi_traceback(uint8_t *st, int n, int cur, Load load, Step step) {
     const uint64_t base = (uint64_t)(uintptr_t)st;
     const uint64_t last = base + (uint64_t)(n - 1);
     uint64_t word = 0;
     int i = n - 1;
-    uint32_t Wn[8];
+    // TG genes per group: two groups of back-pointer lines in flight per wavefront hide the HBM latency of the walk
+    uint32_t Wn[TG];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) Wn[j] = (i - j > 0) ? load(i - j) : 0u;
+    for (int j = 0; j < TG; ++j) Wn[j] = (i - j > 0) ? load(i - j) : 0u;
     while (i >= 0) {
-        uint32_t W[8];
+        uint32_t W[TG];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) W[j] = Wn[j];
+        for (int j = 0; j < TG; ++j) W[j] = Wn[j];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Wn[j] = (i - 8 - j > 0) ? load(i - 8 - j) : 0u;   // the next group, a group ahead
+        for (int j = 0; j < TG; ++j) Wn[j] = (i - TG - j > 0) ? load(i - TG - j) : 0u;   // the next group, a group ahead
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < TG; ++j) {
             const int g = i - j;
-            if (g < 0) break;
+            if (g < 0) continue;
             const uint64_t addr = base + (uint64_t)g;
             const int b = (int)(addr & 7);
             word |= (uint64_t)(cur + 1) << (8 * b);
@@ -45,7 +46,7 @@ __device__ inline void viterbi_traceback(uint8_t *st, int n, int cur, Load load,
             }
             if (g > 0) cur = step(W[j], cur);
         }
-        i -= 8;
+        i -= TG;
     }
 }
 

@@ -1,55 +1,60 @@
 #!/usr/bin/env python3
 """Static instruction mix of the fused chain kernel per phase (developer tool; needs hipcc, no GPU).
-Inserts `; MARK <phase>` comments at the phase boundaries of chain_kernel.inc, compiles chain_m15.hip to
-assembly and counts VALU / LDS / VMEM / SALU / scratch instructions between the markers for one variant."""
+Inserts `; MARK <phase>` comments at the phase boundaries of chain_kernel.inc, compiles the 768 x 15 variant to
+assembly and counts VALU / LDS / VMEM / SALU / v_readlane instructions between the markers."""
 import collections, os, re, subprocess, sys, tempfile
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "infercnv_amd", "csrc")
 variant = sys.argv[1] if len(sys.argv) > 1 else "Li768ELi15ELi2ELi0ELi127E"
 src = open(os.path.join(root, "chain_kernel.inc")).read()
-marks = [("        // ---------------- [A] steps 8, 9", "A"), ("        // ---------------- [B] prefetch", "B"),
-         ("        // ---------------- [C] step 22", "C"), ("        // ---------------- [D] steps 10, 11", "D_INIT"),
-         ("                double Lb = Ls + cur;", "D_SLIDE"),
-         ("                __syncthreads();  // every halo read of buf is done", "D_WRITE"),
-         ("            // back to the S layout;", "D_GET"), ("                // ---- exact median over", "MED_MINMAX"),
-         ("                    const int target = ((int)G - 1) >> 1;", "MED_HIST"),
-         ("                        if (t < 64) {   // one wavefront scans", "MED_SCAN"),
-         ("                        const int sbin = sel[0]", "MED_CAND"),
-         ("                            const int want = target - base - sbefore;", "MED_RANK"),
-         ("                        // refine inside the selected bin", "MED_REFINE"),
-         ("        // steps 12, 14 (the bound vectors", "D_ST12_14")]
+marks = [("        // ---------------- [A] steps 8, 9", "A"), ("        // ---------------- [C] step 22", "C"),
+         ("        // ---------------- [D] steps 10, 11", "D_smooth_init"),
+         ("#pragma unroll\n                for (int q = 0; q < LMAX; ++q) {\n                    const int p = p0 + q;\n                    r[q] = A * inv_at(q);", "D_slide"),
+         ("                __syncthreads();  // every halo read of buf (and of the chunk moments) is done", "D_writeback"),
+         ("            // back to the S layout; steps 11.. run on registers", "D_get_minmax"),
+         ("                        const double scale = fmin((double)NB_HIST / (hi - lo), 0x1p1000);", "MED_hist"),
+         ("                        if (t < 64) {   // one wavefront scans", "MED_scan"),
+         ("                        const int sbin = sel[0], sbefore = sel[1], scnt = sel[2];", "MED_collect"),
+         ("                            const int want = target - base - sbefore;", "MED_rank"),
+         ("                        // refine inside the selected bin", "MED_refine(cold)"),
+         ("                  center = (G & 1) ? mid_lo : (mid_lo + mid_hi) * 0.5;", "MED_end"),
+         ("        // steps 12, 14; the step-12 bound vectors", "F_12_14")]
 for m, name in marks:
     if m not in src:
-        print("marker anchor missing:", name); continue
+        print("marker anchor missing:", name)
+        continue
     src = src.replace(m, 'asm volatile("; MARK %s");\n' % name + m, 1)
 tmp = tempfile.mkdtemp()
 open(os.path.join(tmp, "chain_mark.inc"), "w").write(src)
 open(os.path.join(tmp, "m15.hip"), "w").write('#include "%s/chain_mark.inc"\nnamespace icnv { int launch_chain_m15(const ChainArgs &a, int mode, hipStream_t s) { return launch_chain_v<768, 15>(a, mode, s); } }\n' % tmp)
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + root, "-I" + os.path.join(root, "..", "..", "include"),
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + root, "-I" + os.path.join(root, "..", "..", "include"),
                 "-S", "--cuda-device-only", "-o", os.path.join(tmp, "o.s"), os.path.join(tmp, "m15.hip")], check=True, stderr=subprocess.DEVNULL)
-lines = open(os.path.join(tmp, "o.s")).read().split("\n")
-on, cur, stats = False, "PRE", collections.OrderedDict()
-for l in lines:
-    if re.match(r"^_Z\w+:", l):
-        on = variant in l.split(":")[0]
-        cur = "PRE"
-        continue
-    if not on:
-        continue
-    m = re.search(r"; MARK (\w+)", l)
+s = open(os.path.join(tmp, "o.s")).read()
+i = s.index("chain_kernelI" + variant + "EEvNS_9ChainArgsE:")
+j = s.index(".end_amdhsa_kernel", i)
+cur, st = "PRE", collections.OrderedDict()
+for l in s[i:j].split("\n"):
+    l = l.strip()
+    m = re.match(r"; MARK (\S+)", l)
     if m:
-        cur = m.group(1); continue
-    t = l.strip().split()
-    if not t or t[0].startswith((";", ".")) or t[0].endswith(":"):
+        cur = m.group(1)
         continue
-    op = t[0]
-    c = ("scratch" if op.startswith("scratch_") else "valu" if op.startswith("v_") else "lds" if op.startswith("ds_") else
-         "barrier" if op.startswith("s_barrier") else "wait" if op.startswith("s_waitcnt") else "salu" if op.startswith("s_") else
-         "vmem" if op.startswith(("global_", "buffer_", "flat_")) else None)
-    if c:
-        stats.setdefault(cur, collections.Counter())[c] += 1
-    if op == "s_endpgm":
-        on = False
-for k, v in stats.items():
-    print(f"{k:11s}", " ".join(f"{a}={b}" for a, b in sorted(v.items())))
-for l in lines:
-    if ".name:" in l and variant in l: print(l.strip())
+    if not l or l.startswith((".", ";")):
+        continue
+    op = l.split()[0]
+    d = st.setdefault(cur, collections.Counter())
+    if op.startswith("v_"):
+        d["valu"] += 1
+    elif op.startswith("ds_"):
+        d["lds"] += 1
+    elif op.startswith(("global_", "scratch_", "buffer_")):
+        d["vmem"] += 1
+    elif op == "s_barrier":
+        d["barrier"] += 1
+    elif op.startswith("s_"):
+        d["salu"] += 1
+    if op == "v_readlane_b32":
+        d["readlane"] += 1
+for k, d in st.items():
+    print(f"{k:18s}", " ".join(f"{a}={b}" for a, b in sorted(d.items())))
+if os.environ.get("KEEP_ASM"):
+    open(os.environ["KEEP_ASM"], "w").write(s[i:j])
