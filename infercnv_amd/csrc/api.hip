@@ -2,6 +2,7 @@
 // orchestration: device workspace pool, descriptor uploads, reference rounds.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -187,6 +188,14 @@ struct icnv_chain {
     std::vector<uint32_t> inv_codes;
     bool inv_coded = false;   // host copy of the smoothing normalisation table (kept alive for the async upload)
     bool uploaded = false;
+    // Reference-cell cache: the round that first runs the expensive stages (smoothing, centring) on the reference
+    // cells keeps its output (one column per position of ref_idx), so that the later rounds and the apply pass
+    // continue from it instead of smoothing the same cells again (three times per chain otherwise).
+    bool cache_enabled = false;
+    DevBuf d_cache, d_nonref;
+    std::vector<int32_t> nonref;      // cells that are in no reference group
+    const double *cache_in = nullptr; // matrix the cache was computed from (nullptr: invalid)
+    uint32_t cache_mask = 0;          // stages already applied to the cached columns
 };
 
 static uint32_t stages_before(uint32_t mask, uint32_t stage_bit) { return mask & (stage_bit - 1u); }
@@ -300,6 +309,21 @@ static int chain_upload(icnv_chain *ch, hipStream_t s) {
     if ((rc = ch->d_sums.alloc(((size_t)G * ng + ng) * sizeof(double)))) return rc;
     if ((rc = ch->d_cellstats.alloc(std::max<size_t>(ch->ref_idx.size(), 1) * 2 * sizeof(double)))) return rc;
     if ((rc = ch->d_stats.alloc(4 * sizeof(double)))) return rc;
+    {
+        const size_t nref = ch->ref_idx.size();
+        const size_t bytes = nref * (size_t)G * sizeof(double);
+        const char *off = std::getenv("ICNV_REF_CACHE");   // developer switch: ICNV_REF_CACHE=0 recomputes the reference cells
+        if (nref > 0 && nref * 2 <= (size_t)ch->cfg.C && bytes <= ((size_t)16 << 30) && !(off && off[0] == '0') &&
+            (ch->mask & (ICNV_ST_SMOOTH | ICNV_ST_CENTER))) {
+            std::vector<char> is_ref((size_t)ch->cfg.C, 0);
+            for (int32_t c : ch->ref_idx) is_ref[c] = 1;
+            for (int64_t c = 0; c < ch->cfg.C; ++c)
+                if (!is_ref[c]) ch->nonref.push_back((int32_t)c);
+            if ((rc = ch->d_cache.alloc(bytes))) return rc;
+            if ((rc = upload(ch->d_nonref, ch->nonref.data(), ch->nonref.size(), s))) return rc;
+            ch->cache_enabled = true;
+        }
+    }
     if (ch->T >= 1) {
         if ((rc = chain_build_inv_table(ch->chr_start.data(), ch->cfg.n_chr, (int32_t)G, ch->T, ch->inv_tab, ch->inv_codes,
                                         ch->inv_dict, ch->inv_coded)))
@@ -349,6 +373,11 @@ int icnv_chain_round_partial_dev(icnv_chain_t *ch, int round, const double *expr
         const int nref = (int)ch->ref_idx.size();
         a.cells = ch->d_ref.as<int32_t>();
         a.n_cells = nref;
+        if (ch->cache_in == expr_in && (ch->cache_mask & ~a.mask) == 0) {   // continue from the cached columns
+            a.in = ch->d_cache.as<double>();
+            a.in_by_pos = 1;
+            a.mask &= ~ch->cache_mask;
+        }
         if (nref > 0) {
             if ((rc = launch_chain(a, MODE_CELL_STATS, s))) return rc;
         }
@@ -359,6 +388,8 @@ int icnv_chain_round_partial_dev(icnv_chain_t *ch, int round, const double *expr
         return ICNV_OK;
     }
     double *sums = ch->d_sums.as<double>();
+    const bool fill_cache = ch->cache_enabled && (a.mask & (ICNV_ST_SMOOTH | ICNV_ST_CENTER));
+    if (fill_cache) ch->cache_in = nullptr;
     for (int q = 0; q < ng; ++q) {
         const int cnt = ch->ref_off[q + 1] - ch->ref_off[q];
         double *dst = sums + (size_t)q * G;
@@ -370,9 +401,14 @@ int icnv_chain_round_partial_dev(icnv_chain_t *ch, int round, const double *expr
         }
         a.cells = ch->d_ref.as<int32_t>() + ch->ref_off[q];
         a.n_cells = cnt;
+        a.cache_out = fill_cache ? ch->d_cache.as<double>() + (size_t)ch->ref_off[q] * G : nullptr;
         if ((rc = launch_chain(a, MODE_GENE_SUMS, s))) return rc;
         const int nblk = std::min(cnt, 256);
         if ((rc = launch_reduce_partials(a.partial, nblk, (int32_t)G, dst, (double)cnt, cdst, s))) return rc;
+    }
+    if (fill_cache) {
+        ch->cache_in = expr_in;
+        ch->cache_mask = a.mask;
     }
     if (partial_dev) *partial_dev = sums;
     if (n) *n = G * ng + ng;
@@ -403,15 +439,35 @@ int icnv_chain_apply_dev(icnv_chain_t *ch, const double *expr_in, double *expr_o
     a.pre_out = pre_denoise;
     a.cells = nullptr;
     a.n_cells = (int32_t)ch->cfg.C;
+    // The reference cells continue from the cache the rounds left (same matrix, stages a prefix of this chain's);
+    // all other cells run the whole chain.  The cache is consumed: an apply without fresh rounds recomputes.
+    const bool from_cache = ch->cache_in == expr_in && ch->cache_mask != 0 && (ch->cache_mask & ~ch->mask) == 0;
+    const uint32_t cached = ch->cache_mask;
+    ch->cache_in = nullptr;
+    auto run = [&](ChainArgs args) -> int {
+        if (!from_cache) return launch_chain(args, MODE_APPLY, s);
+        int r = ICNV_OK;
+        if (!ch->nonref.empty()) {
+            args.cells = ch->d_nonref.as<int32_t>();
+            args.n_cells = (int32_t)ch->nonref.size();
+            if ((r = launch_chain(args, MODE_APPLY, s))) return r;
+        }
+        args.in = ch->d_cache.as<double>();
+        args.in_by_pos = 1;
+        args.cells = ch->d_ref.as<int32_t>();
+        args.n_cells = (int32_t)ch->ref_idx.size();
+        args.mask = ch->mask & ~cached;
+        return launch_chain(args, MODE_APPLY, s);
+    };
     if (pre_denoise && !(ch->mask & ICNV_ST_DENOISE)) {
         // no denoise stage: the "pre-denoise" matrix is the output itself
         a.pre_out = nullptr;
-        if ((rc = launch_chain(a, MODE_APPLY, s))) return rc;
+        if ((rc = run(a))) return rc;
         ICNV_HIP(hipMemcpyAsync(pre_denoise, expr_out, (size_t)ch->cfg.G * ch->cfg.C * sizeof(double),
                                 hipMemcpyDeviceToDevice, s));
         return ICNV_OK;
     }
-    return launch_chain(a, MODE_APPLY, s);
+    return run(a);
 }
 
 int icnv_chain_get_denoise(icnv_chain_t *ch, double *mu_s, void *stream) {

@@ -62,6 +62,8 @@ struct ChainArgs {
     int32_t inv_coded;          // 1: every distinct value has a code (else the generic kernels read inv_pos)
     const double *inv_dict;     // [256] distinct 1/denominator values, entry 0 = 0.0 (padding)
     double *partial;        // MODE_GENE_SUMS: [gridDim.x * G]
+    double *cache_out;      // MODE_GENE_SUMS, nullable: the stages' output of list position i goes to cache_out[i * G ..]
+    int32_t in_by_pos;      // 1: `in` holds one column per list position (a cache written through cache_out)
     double *cell_stats;     // MODE_CELL_STATS: [n_cells * 2] {sum, sd}
 };
 
