@@ -99,10 +99,11 @@ def main():
 
     G, C_local = args.genes, args.cells
     C_total = C_local * world
-    c0 = rank * C_local
-    x, chr_start = synth.make_matrix_torch(G, C_local, "cuda", cell_offset=c0, C_total=C_total)
+    # cells are dealt to the ranks round-robin (sharded.cyclic_cells): every rank holds its share of every
+    # reference group, so the reference rounds are balanced (the generator puts the reference cells first)
+    x, chr_start = synth.make_matrix_torch(G, C_local, "cuda", cell_offset=rank, cell_stride=world, C_total=C_total)
     refs_global, _ = synth.groups(C_total)
-    refs_local = sharded.localize_groups(refs_global, c0, c0 + C_local)
+    refs_local = sharded.localize_groups_cyclic(refs_global, rank, world)
     means, sd, logPi, logDelta = synth.hmm_params_i6()
 
     out = torch.empty_like(x)
@@ -189,7 +190,7 @@ def main():
             "config": {"workload": f"synthetic {G} genes x {C_local} cells per GPU ({C_total} total), fused smooth chain "
                                    "(steps 8,9,10,11,12,14,22) + per-cell i6 HMM Viterbi, inputs resident in HBM",
                        "genes": G, "cells_per_gpu": C_local, "cells_total": C_total, "window_length": 101,
-                       "hmm": "i6, t=1e-6", "parallelism": f"cell-shard x{world}, 3 small all-reduces"},
+                       "hmm": "i6, t=1e-6", "parallelism": f"cell-shard x{world} (round-robin deal), 3 small all-reduces"},
             "roofline": roof.get(dominant) or (next(iter(roof.values())) if roof else None),
             "roofline_kernel": dominant,
             "roofline_by_kernel": roof,

@@ -36,6 +36,24 @@ def localize_groups(groups, c0: int, c1: int):
     return out
 
 
+def cyclic_cells(C_total: int, world: int, rank: int):
+    """Global indices of the cells rank `rank` holds when cells are dealt round-robin: rank, rank + world, ...
+    Every annotation group -- the reference groups in particular -- is then spread evenly over the ranks, so the
+    reference rounds cost every rank the same (a contiguous block partition of a matrix whose reference cells
+    come first would leave them all on rank 0)."""
+    return np.arange(rank, C_total, world, dtype=np.int64)
+
+
+def localize_groups_cyclic(groups, rank: int, world: int):
+    """Members of each group held by `rank` under the round-robin deal, as LOCAL indices, order preserved."""
+    out = []
+    for g in groups:
+        g = np.asarray(g, dtype=np.int64)
+        m = g[(g % world) == rank]
+        out.append(((m - rank) // world).astype(np.int32))
+    return out
+
+
 def align_to_groups(C_total: int, world: int, group_boundaries):
     """Shard boundaries moved to the nearest group boundary so that every group
     (HMM subcluster / median-filter tile) lives on one GPU.

@@ -128,9 +128,10 @@ def _normal_t(seed, g, c):
 
 
 def make_matrix_torch(G, C, device, cell_offset=0, C_total=None, seed=SEED, n_clones=4, ref_frac=0.10,
-                      chunk_cells=8192):
+                      chunk_cells=8192, cell_stride=1):
     """(C, G) contiguous float64 CUDA tensor (cell-major) + chr_start; same values as make_matrix_np up to
-    libm-vs-device rounding of log/exp/cos."""
+    libm-vs-device rounding of log/exp/cos.  Local cell i is global cell cell_offset + cell_stride * i
+    (a contiguous block: offset c0, stride 1; the round-robin deal of sharded.cyclic_cells: offset rank, stride world)."""
     import torch
     C_total = C if C_total is None else C_total
     chr_start = chr_layout(G)
@@ -143,7 +144,7 @@ def make_matrix_torch(G, C, device, cell_offset=0, C_total=None, seed=SEED, n_cl
     chr_of_gene = torch.as_tensor(np.repeat(np.arange(len(chr_start) - 1), np.diff(chr_start)), device=device)
     for c0 in range(0, C, chunk_cells):
         c1 = min(C, c0 + chunk_cells)
-        c = torch.arange(c0, c1, dtype=torch.int64, device=device) + cell_offset
+        c = torch.arange(c0, c1, dtype=torch.int64, device=device) * cell_stride + cell_offset
         z = _normal_t(seed, g[None, :], c[:, None])
         clone = torch.where(c < n_ref, torch.zeros_like(c), 1 + (c % n_clones))
         k = tab[clone][:, chr_of_gene]

@@ -100,6 +100,9 @@ def test_shard_helpers():
     assert b == [(0, 4), (4, 7), (7, 10)]
     loc = sharded.localize_groups([np.array([9, 0, 5, 4]), np.array([1])], 4, 7)
     assert [list(v) for v in loc] == [[1, 0], []]
+    assert list(sharded.cyclic_cells(10, 3, 1)) == [1, 4, 7]
+    cyc = sharded.localize_groups_cyclic([np.array([9, 0, 5, 4]), np.array([1, 7])], 1, 3)
+    assert [list(v) for v in cyc] == [[1], [0, 2]]          # global 4 -> local 1; globals 1, 7 -> locals 0, 2
     cuts = sharded.align_to_groups(100, 4, [0, 30, 45, 80, 100])
     assert cuts == [(0, 30), (30, 45), (45, 80), (80, 100)]
 
@@ -161,6 +164,12 @@ out, pre = sharded.ShardedChain(eng).run(np.ascontiguousarray(x[:, c0:c1]), want
 want, want_pre = onp.run_chain(x, chr_codes, refs, return_pre_denoise=True)
 assert np.abs(pre - want_pre[:, c0:c1]).max() < 1e-12, np.abs(pre - want_pre[:, c0:c1]).max()
 assert (np.abs(out - want[:, c0:c1]) > 1e-12).mean() < 1e-3
+# the same run with the cells dealt round-robin (what bench.py --gpus N does)
+mine = sharded.cyclic_cells(C, 2, rank)
+eng = OracleEngine(G, chr_codes, sharded.localize_groups_cyclic(refs, rank, 2))
+out, pre = sharded.ShardedChain(eng).run(np.ascontiguousarray(x[:, mine]), want_pre_denoise=True)
+assert np.abs(pre - want_pre[:, mine]).max() < 1e-12, np.abs(pre - want_pre[:, mine]).max()
+assert (np.abs(out - want[:, mine]) > 1e-12).mean() < 1e-3
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
