@@ -137,6 +137,16 @@ int icnv_normalize_log2_dev(const double *expr_in, double *expr_out, int64_t G, 
 int icnv_normalize_log2(const double *expr_in, double *expr_out, int64_t G, int64_t C,
                         double normalize_factor, int32_t do_normalize, int32_t do_log2, double *factor_used);
 
+/* ---- cell-cell distances ------------------------------------ */
+/* parallelDist(t(expr.data[, cells])), method "euclidean", as the reference calls it before hclust
+ * (R/inferCNV_tumor_subclusters.R:191; R/inferCNV_ops.R:1930, 3242; R/inferCNV_heatmap.R:719-1079):
+ * dist_out [n x n] (symmetric, zero diagonal; the R `dist` object is its lower triangle in column order).
+ * cell_idx [n] HOST, 0-based.  fp64 Gram matrix of the group-centred cells on the matrix cores
+ * (v_mfma_f64_16x16x4_f64), D_ij = sqrt(max(0, S_ii + S_jj - 2 S_ij)). */
+int icnv_cell_distances(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx, int64_t n, double *dist_out);
+int icnv_cell_distances_dev(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx, int64_t n, double *dist_out,
+                            void *stream);
+
 /* ---- HMM ---------------------------------------------------------------- */
 /* Viterbi.dthmm.adj (R/inferCNV_HMM.R:1101-1176) for every (cell, chromosome):
  * predict_CNV_via_HMM_on_indiv_cells (R/inferCNV_HMM.R:284-324) with K = 6 and

@@ -82,6 +82,8 @@ PROTOTYPES = {
     "icnv_viterbi_last_stats": (ct.c_int, [ct.POINTER(_i64)]),
     "icnv_hmm_emission_table": (ct.c_int, [_i32, _dp, _dbl, _dp, _dp, _dp, _i64]),
     "icnv_hmm_emission_scores": (ct.c_int, [_i32, _dp, _dbl, _dp, _i64, _i32, _dp, _vp]),
+    "icnv_cell_distances": (ct.c_int, [_vp, _i64, _i64, _ip, _i64, _vp]),
+    "icnv_cell_distances_dev": (ct.c_int, [_vp, _i64, _i64, _ip, _i64, _vp, _vp]),
     "icnv_group_means_dev": (ct.c_int, [_vp, _i64, _i64, _ip, _ip, _i32, _vp, _vp]),
     "icnv_gene_stats": (ct.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "icnv_gene_stats_dev": (ct.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),

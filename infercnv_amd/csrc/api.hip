@@ -997,6 +997,41 @@ int icnv_group_means_dev(const double *expr, int64_t G, int64_t C, const int32_t
                                  d_part.as<double>(), out, s);
 }
 
+// parallelDist(t(expr[, cells])) (Euclidean) as the reference computes it before hclust
+// (R/inferCNV_tumor_subclusters.R:191, R/inferCNV_ops.R:1930, 3242): full symmetric n x n matrix.
+int icnv_cell_distances_dev(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx, int64_t n, double *dist_out,
+                            void *stream) {
+    if (!expr || !dist_out || !cell_idx || G < 1 || G > 0x7fffffff || n < 1 || n > 0x7fffffff)
+        ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    int rc = validate_index_list(cell_idx, n, C, "cell");
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf d_idx, d_off, d_part, d_mean, d_diag;
+    const int32_t off[2] = {0, (int32_t)n};
+    if ((rc = upload(d_idx, cell_idx, (size_t)n, s))) return rc;
+    if ((rc = upload(d_off, off, 2, s))) return rc;
+    const int ns = group_means_nsplit((int32_t)G, 1);
+    if ((rc = d_part.alloc((size_t)ns * G * sizeof(double))) || (rc = d_mean.alloc((size_t)G * sizeof(double))) ||
+        (rc = d_diag.alloc((size_t)n * sizeof(double))))
+        return rc;
+    if ((rc = launch_group_means_ws(expr, (int32_t)G, d_idx.as<int32_t>(), d_off.as<int32_t>(), 1, ns, d_part.as<double>(),
+                                    d_mean.as<double>(), s)))
+        return rc;
+    return launch_cell_distances(expr, (int32_t)G, d_idx.as<int32_t>(), (int32_t)n, d_mean.as<double>(), d_diag.as<double>(),
+                                 dist_out, s);
+}
+
+int icnv_cell_distances(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx, int64_t n, double *dist_out) {
+    if (!expr || !dist_out || G < 1 || C < 1 || n < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    DevBuf din, dout;
+    int rc;
+    if ((rc = din.alloc((size_t)G * C * sizeof(double))) || (rc = dout.alloc((size_t)n * n * sizeof(double)))) return rc;
+    ICNV_HIP(hipMemcpy(din.p, expr, (size_t)G * C * sizeof(double), hipMemcpyHostToDevice));
+    if ((rc = icnv_cell_distances_dev(din.as<double>(), G, C, cell_idx, n, dout.as<double>(), nullptr))) return rc;
+    ICNV_HIP(hipMemcpy(dist_out, dout.p, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost));
+    return ICNV_OK;
+}
+
 int icnv_viterbi_groups_dev(const double *expr, uint8_t *states, int64_t G, int64_t C, const int32_t *chr_start,
                             int32_t n_chr, const int32_t *grp_idx, const int32_t *grp_off, int32_t n_grp, int32_t K,
                             const double *mean, const double *sd_shared_per_grp, const double *logPi,

@@ -154,6 +154,10 @@ int launch_broadcast_states_keep(const uint8_t *grp_states, int32_t G, int64_t C
                                  uint8_t *states, hipStream_t stream);
 int launch_states_to_proxy(const uint8_t *states, double *out, int64_t n, int32_t K, hipStream_t stream);
 
+// ---- cell-cell distances (distance_kernels.hip) ----
+int launch_cell_distances(const double *x, int32_t G, const int32_t *idx_dev, int32_t n, const double *mean_dev,
+                          double *diag_dev, double *out, hipStream_t stream);
+
 // ---- median filter --------------------------------------------------------
 int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, const int32_t *chr_start_dev,
                          int32_t n_chr, const int32_t *tile_idx_dev, const int32_t *tile_off_dev, int32_t n_tiles,

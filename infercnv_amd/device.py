@@ -224,6 +224,16 @@ def group_means(x, groups):
     return out
 
 
+def cell_distances(x, cells):
+    """parallelDist(t(expr.data[, cells])) (Euclidean; R/inferCNV_tumor_subclusters.R:191) -> (n, n) tensor."""
+    L = _lib.load()
+    C, G = _check_matrix(x)
+    idx, ip = i32(cells)
+    out = torch.empty((idx.size, idx.size), dtype=torch.float64, device=x.device)
+    check(L.icnv_cell_distances_dev(_ptr(x), G, C, ip, idx.size, _ptr(out), _stream()))
+    return out
+
+
 def state_consensus(states, groups, overwrite=False):
     """.get_state_consensus (R/inferCNV_HMM.R:977-987) per group -> (n_groups, G) uint8; with
     overwrite=True also returns the state matrix with every member cell set to its group's consensus."""

@@ -618,3 +618,17 @@ def gene_expr_mean_sd(expr, gene_idx, cell_idx):
     """.get_gene_expr_mean_sd_by_cnv (R/inferCNV_HMM.R:84-99): mean() and sd() of c(expr[genes, cells])."""
     v = np.asarray(expr, dtype=np.float64)[np.ix_(np.asarray(gene_idx), np.asarray(cell_idx))].ravel(order="F")
     return float(r_mean(v)), float(r_sd(v.reshape(-1, 1), axis=0)[0])
+
+
+# ----------------------------------------------------------------------------
+# cell-cell distances (SURVEY 8f #4)
+def cell_distances(expr, cells):
+    """parallelDist(t(expr[, cells])), method "euclidean" (R/inferCNV_tumor_subclusters.R:191): direct sums of squared
+    differences, full symmetric matrix."""
+    x = np.asarray(expr, dtype=np.float64)[:, np.asarray(cells, dtype=np.int64)].T      # (n, G)
+    n = x.shape[0]
+    d = np.zeros((n, n))
+    for i in range(n):
+        diff = x[i + 1:] - x[i]
+        d[i, i + 1:] = np.sqrt((diff * diff).sum(axis=1))
+    return d + d.T

@@ -696,3 +696,26 @@ def test_get_spike_dists_block_statistics(dev):
     # the result feeds the i6 predictor directly
     st = hmm.predict_CNV_via_HMM_on_indiv_cells(obj, got).expr_data
     assert (st[level == 3][:, 30:] == 6).mean() > 0.9 and (st[level == 1][:, :30] == 3).mean() > 0.9
+
+
+# ------------------------------------------------------------------ cell-cell distances
+@pytest.mark.parametrize("G,C,n", [(2000, 300, 150), (2001, 90, 70), (512, 64, 64), (777, 200, 129), (64, 5, 1), (33, 40, 2)])
+def test_cell_distances_vs_oracle(dev, G, C, n):
+    """parallelDist(t(expr[, cells])) (R/inferCNV_tumor_subclusters.R:191): the fp64 MFMA Gram formulation against
+    direct sums of squared differences; relative 1e-12 (tile edges, odd G, non-multiples of the 64-cell tile)."""
+    rng = np.random.default_rng(G + n)
+    x = rng.normal(1.0, 0.3, size=(G, C)) + rng.normal(0.0, 2.0, size=(G, 1))     # large per-gene offsets: centring matters
+    cells = rng.permutation(C)[:n].astype(np.int32)
+    got = dev.cell_distances(to_dev(x), cells).cpu().numpy()
+    want = onp.cell_distances(x, cells)
+    assert got.shape == (n, n) and np.all(np.diag(got) == 0.0)
+    np.testing.assert_array_equal(got, got.T)
+    assert np.abs(got - want).max() <= 1e-12 * max(want.max(), 1.0)
+    # translation invariance per gene (the kernel centres internally): exact same structure, tiny numeric change
+    got2 = dev.cell_distances(to_dev(x + 5.0), cells).cpu().numpy()
+    assert np.abs(got2 - want).max() <= 1e-11 * max(want.max(), 1.0)
+    # duplicate cells are at distance (numerically) zero
+    if n >= 2:
+        dup = np.concatenate([cells[:2], cells[:1]]).astype(np.int32)
+        d3 = dev.cell_distances(to_dev(x), dup).cpu().numpy()
+        assert d3[0, 2] <= 1e-6 * max(want.max(), 1.0) and abs(d3[0, 1] - want[0, 1]) <= 1e-12 * max(want.max(), 1.0)
