@@ -748,6 +748,8 @@ struct FastTableCache {
     int32_t *counters = nullptr;   // [0] task counter, [1] flag count, device
     int32_t *host_flag = nullptr;  // pinned, receives the flag count of the last call
     hipEvent_t flag_ev = nullptr;
+    int64_t flag_seqs = 0;         // sequences of the column batch whose flag count host_flag receives
+    int skip_calls = 0;            // > 0: the fast path flagged too much lately, use the exact kernel directly
 };
 FastTableCache g_fast;
 
@@ -818,6 +820,19 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
     double a = 0, b = 0;
     if (g_viterbi_mode == 0 && !sd_per_col_dev && ncols >= 64 && structured_pi(p, a, b)) {
         if ((rc = fast_table_for(p, sd_shared, s, fast))) return rc;
+        // Data the table cannot score (outside its domain, non-finite) or riddled with exact ties is flagged and
+        // redone exactly: right, but slower than the exact kernel alone.  When the last finished call had more
+        // than 5 % of its sequences flagged, the next eight calls skip the fast path (no synchronisation: the
+        // count arrives in pinned memory and is only read once its event has completed).
+        if (fast && g_fast.flag_seqs > 0 && g_fast.flag_ev && hipEventQuery(g_fast.flag_ev) == hipSuccess) {
+            if ((double)*g_fast.host_flag > 0.05 * (double)g_fast.flag_seqs) g_fast.skip_calls = 8;
+            g_fast.flag_seqs = 0;
+        }
+        (void)hipGetLastError();   // hipEventQuery reports "not ready" as an error code
+        if (fast && g_fast.skip_calls > 0) {
+            --g_fast.skip_calls;
+            fast = false;
+        }
     }
     g_viterbi_stats[0] = fast ? 1 : 0;
     g_viterbi_stats[1] = ncols * n_chr;
@@ -880,6 +895,7 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
             return rc;
         ICNV_HIP(hipMemcpyAsync(g_fast.host_flag, fa.flag_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         ICNV_HIP(hipEventRecord(g_fast.flag_ev, s));
+        g_fast.flag_seqs = nc * n_chr;
     }
     return ICNV_OK;
 }

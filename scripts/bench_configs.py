@@ -28,7 +28,7 @@ del out
 means, sd, logPi, logDelta = synth.hmm_params_i6()
 states = torch.empty((C, G), dtype=torch.uint8, device="cuda")
 t = timed(lambda: device.viterbi_cells(pre, cs, means, sd, logPi, logDelta, states=states), 2)
-res["config3_i6_cells_per_gpu"] = {"cells": C, "ms": t * 1e3, "cells_per_s": C / t}
+res["config3_i6_cells_per_gpu"] = {"cells": C, "ms": t * 1e3, "cells_per_s": C / t, **device.viterbi_last_stats()}
 del states
 
 # config 4: i3 at subcluster level, 50k cells per GPU
@@ -42,6 +42,13 @@ groups = [np.arange(s, s + 500, dtype=np.int32) for s in range(0, C4, 500)]
 st4 = torch.empty((C4, G), dtype=torch.uint8, device="cuda")
 t = timed(lambda: device.viterbi_groups(pre4, cs, groups, m3, [sigma] * len(groups), np.log(Pi), np.log(dl), states=st4))
 res["config4_i3_subclusters_per_gpu"] = {"cells": C4, "subclusters": len(groups), "ms": t * 1e3, "cells_per_s": C4 / t}
+# config 4b: the same i3 model per cell (certified fast path with a 3-state table)
+t = timed(lambda: device.viterbi_cells(pre4, cs, m3, sigma, np.log(Pi), np.log(dl), states=st4), 2)
+res["config4b_i3_per_cell"] = {"cells": C4, "ms": t * 1e3, "cells_per_s": C4 / t, **device.viterbi_last_stats()}
+# distances inside one 2 500-cell tumor group (fp64 MFMA Gram matrix)
+cells = np.arange(5000, 7500, dtype=np.int32)
+t = timed(lambda: device.cell_distances(pre4, cells), 3)
+res["group_distances_2500_cells"] = {"cells": 2500, "ms": t * 1e3, "TFLOPs_full_product": 2.0 * 2500 * 2500 * G / t / 1e12}
 del st4, pre4
 
 # config 5: median filter on a 5 000-cell slice (10 tiles of 500 cells)
