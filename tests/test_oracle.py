@@ -346,3 +346,30 @@ def test_gene_filter_restatements():
     assert onp.genes_passing_min_cells(x, 2).tolist() == [2, 3, 4]                       # NA is not counted
     m, s = onp.gene_expr_mean_sd(np.arange(12.0).reshape(3, 4), [0, 2], [1, 3])          # values 1, 9, 3, 11
     assert m == 6.0 and abs(s - np.std([1, 9, 3, 11], ddof=1)) < 1e-15
+
+
+def test_exp2_lean():
+    """The chain kernel's 2^x (infercnv_amd/csrc/chain_kernel.inc::exp2_lean, coefficients in icnv_exp2_coef.h),
+    restated here with the same fma sequence, against 40-digit values: <= 1 ulp on the range it serves."""
+    import re
+    mp = pytest.importorskip("mpmath")
+    mp.mp.dps = 40
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "infercnv_amd", "csrc", "icnv_exp2_coef.h")).read()
+    coef = {int(k): float.fromhex(v) for k, v in re.findall(r"#define ICNV_EXP2_C(\d+) (\S+)", hdr)}
+    assert sorted(coef) == list(range(1, 12))
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-8, 8, 4000), rng.uniform(-1021.9, 1021.9, 1000), [0.0, 0.5, -0.5, 1.5, 2.5, -1021.5]])
+    n = np.rint(x)
+    f = x - n
+    p = np.full_like(x, coef[11])
+    for j in range(10, 0, -1):
+        p = oc.fma(p, f, np.full_like(x, coef[j]))
+    p = oc.fma(p, f, np.ones_like(x))
+    got = np.ldexp(p, n.astype(np.int64))
+    worst = 0.0
+    for xi, gi in zip(x, got):
+        want = mp.power(2, mp.mpf(float(xi)))
+        ulp = np.spacing(float(want)) if float(want) > 2.3e-308 else 5e-324
+        worst = max(worst, float(abs(mp.mpf(float(gi)) - want)) / ulp)
+    assert worst <= 1.0, worst
