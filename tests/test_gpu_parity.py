@@ -126,6 +126,32 @@ def test_chain_each_stage_standalone(dev, stage):
     assert np.abs(got - want).max() < 1e-11 * max(1.0, np.abs(want).max())
 
 
+@pytest.mark.parametrize("mask", [0x7F, 0x3F, 0x0F, 0x70, 0x30, 0x20, 0x01, 0x00])
+def test_chain_many_cells_per_workgroup(dev, mask):
+    """More cells than workgroups: every workgroup streams several cells through its software pipeline (prefetch of the
+    next cell, stores of the previous one) -- for the full chain and for the stage subsets that skip the LDS-resident
+    phases (the continuation masks of the reference-cell cache, single stages)."""
+    from infercnv_amd import synth
+    G, C = 1200, 1500                                     # 256 CUs -> about six cells per workgroup
+    x, cs = synth.make_matrix_np(G, C)
+    x = x - 1.0
+    refs = [np.arange(0, 40, dtype=np.int32), np.arange(40, 90, dtype=np.int32)]
+    got = to_host(dev.smooth_chain(to_dev(x), cs, refs, stage_mask=mask)[0])
+    v = x.copy()
+    if mask & 0x01: v = oc.subtract_ref_expr_from_obs(v, refs)
+    if mask & 0x02: v = oc.apply_max_threshold_bounds(v, 3.0)
+    if mask & 0x04: v = oc.smooth_by_chromosome(v, cs, 101)
+    if mask & 0x08: v = oc.center_columns(v, "median")
+    if mask & 0x10: v = oc.subtract_ref_expr_from_obs(v, refs)
+    if mask & 0x20: v = oc.invert_log2(v)
+    if mask & 0x40:
+        mu, sdv = oc.denoise_params(v, np.concatenate(refs), 1.5)
+        v = oc.denoise_apply(v, mu, sdv)
+        assert (np.abs(got - v) > 1e-11).mean() < 1e-3     # strict-threshold select: edge elements may flip
+    else:
+        assert np.abs(got - v).max() < 1e-11 * max(1.0, np.abs(v).max())
+
+
 def test_chain_options(dev):
     """use_bounds=FALSE, no threshold, short / long / no window, fixed-threshold denoise, no denoise."""
     from infercnv_amd import synth
