@@ -19,15 +19,20 @@ namespace {
 
 typedef double dbl4_t __attribute__((ext_vector_type(4)));
 
-constexpr int DT = 64;        // output tile (cells x cells) per workgroup
 constexpr int KC = 32;        // genes per LDS stage
 constexpr int LDR = KC + 2;   // LDS row stride in doubles: (4 row + 2 k) dwords mod 64 are distinct within a 32-lane group
 
-// One workgroup = 4 wavefronts = 2 x 2 sub-tiles of 32 x 32; a wavefront holds 2 x 2 MFMA accumulators (16 x 16 each).
-__global__ void __launch_bounds__(256) gram_tiles_kernel(const double *__restrict__ x, int G, const int32_t *__restrict__ idx,
+// One workgroup = 4 wavefronts = 2 x 2 sub-tiles; a wavefront holds WM x WM MFMA accumulators (16 x 16 each), so the
+// workgroup's output tile is DT = 32 WM cells square: WM = 2 for small groups (enough tiles to fill 256 CUs),
+// WM = 4 for large ones (each 8-byte LDS operand read then feeds four matrix instructions instead of two).
+template <int WM>
+__global__ void __launch_bounds__(256, (WM == 4 ? 2 : 4)) gram_tiles_kernel(const double *__restrict__ x, int G, const int32_t *__restrict__ idx,
                                                          int n, const double *__restrict__ mean, double *__restrict__ S) {
-    __shared__ double As[DT * LDR];
-    __shared__ double Bs[DT * LDR];
+    constexpr int DT = 32 * WM;
+    constexpr int RPT = DT / 64;          // rows staged per thread and tile
+    extern __shared__ __attribute__((aligned(16))) double smem_d[];
+    double *As = smem_d;
+    double *Bs = smem_d + DT * LDR;
     // upper-triangular tile pair (bi <= bj) of this workgroup
     const int nt = (n + DT - 1) / DT;
     int bi = 0, rem = blockIdx.x;
@@ -36,63 +41,93 @@ __global__ void __launch_bounds__(256) gram_tiles_kernel(const double *__restric
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = w >> 1, wc = w & 1;
-    dbl4_t acc[2][2];
+    dbl4_t acc[WM][WM];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < WM; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = (dbl4_t){0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < WM; ++b) acc[a][b] = (dbl4_t){0.0, 0.0, 0.0, 0.0};
 
-    // staging: thread t loads 8 consecutive genes of row t / 4 (64 rows x 32 genes per tile and stage)
+    // staging: thread t loads 8 consecutive genes of rows t / 4 (+ 64) of each tile.  The next stage is requested into
+    // registers before the current stage's MFMAs and parked in LDS after them: its HBM/L2 latency hides behind the
+    // matrix instructions instead of standing between barriers.
     const int lrow = t >> 2, lseg = (t & 3) * 8;
-    const int ra = bi * DT + lrow, rb = bj * DT + lrow;
-    const double *pa = ra < n ? x + (int64_t)idx[ra] * G : nullptr;
-    const double *pb = rb < n ? x + (int64_t)idx[rb] * G : nullptr;
+    const double *pa[RPT], *pb[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int ra = bi * DT + lrow + 64 * r, rb = bj * DT + lrow + 64 * r;
+        pa[r] = ra < n ? x + (int64_t)idx[ra] * G : nullptr;
+        pb[r] = rb < n ? x + (int64_t)idx[rb] * G : nullptr;
+    }
+    const bool even = (G & 1) == 0;   // 16-byte loads: every row starts at an even element and g is even
 
-    for (int k0 = 0; k0 < G; k0 += KC) {
-        if ((G & 1) == 0) {   // 16-byte loads: every row starts at an even element and g is even
+    double ra_v[RPT][8], rb_v[RPT][8];
+    auto fetch = [&](int k0) {
 #pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                const int g = k0 + lseg + j;
-                const bool in = g < G;
-                const double2 m = in ? *reinterpret_cast<const double2 *>(mean + g) : make_double2(0.0, 0.0);
-                const double2 va = (pa && in) ? *reinterpret_cast<const double2 *>(pa + g) : m;
-                const double2 vb = (pb && in) ? *reinterpret_cast<const double2 *>(pb + g) : m;
-                As[lrow * LDR + lseg + j] = va.x - m.x;
-                As[lrow * LDR + lseg + j + 1] = va.y - m.y;
-                Bs[lrow * LDR + lseg + j] = vb.x - m.x;
-                Bs[lrow * LDR + lseg + j + 1] = vb.y - m.y;
-            }
-        } else {
+        for (int r = 0; r < RPT; ++r) {
+            if (even) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int g = k0 + lseg + j;
-                const double m = g < G ? mean[g] : 0.0;
-                As[lrow * LDR + lseg + j] = (pa && g < G) ? pa[g] - m : 0.0;
-                Bs[lrow * LDR + lseg + j] = (pb && g < G) ? pb[g] - m : 0.0;
+                for (int j = 0; j < 8; j += 2) {
+                    const int g = k0 + lseg + j;
+                    const bool in = g < G;
+                    const double2 m = in ? *reinterpret_cast<const double2 *>(mean + g) : make_double2(0.0, 0.0);
+                    const double2 va = (pa[r] && in) ? *reinterpret_cast<const double2 *>(pa[r] + g) : m;
+                    const double2 vb = (pb[r] && in) ? *reinterpret_cast<const double2 *>(pb[r] + g) : m;
+                    ra_v[r][j] = va.x - m.x; ra_v[r][j + 1] = va.y - m.y;
+                    rb_v[r][j] = vb.x - m.x; rb_v[r][j + 1] = vb.y - m.y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int g = k0 + lseg + j;
+                    const double m = g < G ? mean[g] : 0.0;
+                    ra_v[r][j] = (pa[r] && g < G) ? pa[r][g] - m : 0.0;
+                    rb_v[r][j] = (pb[r] && g < G) ? pb[r][g] - m : 0.0;
+                }
             }
         }
-        __syncthreads();
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                As[(lrow + 64 * r) * LDR + lseg + j] = ra_v[r][j];
+                Bs[(lrow + 64 * r) * LDR + lseg + j] = rb_v[r][j];
+            }
+    };
+    fetch(0);
+    park();
+    __syncthreads();
+    for (int k0 = 0; k0 < G; k0 += KC) {
+        const bool more = k0 + KC < G;
+        if (more) fetch(k0 + KC);
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 4) {
             const int k = kk + (lane >> 4), r = lane & 15;
-            const double a0 = As[(wr * 32 + r) * LDR + k], a1 = As[(wr * 32 + 16 + r) * LDR + k];
-            const double b0 = Bs[(wc * 32 + r) * LDR + k], b1 = Bs[(wc * 32 + 16 + r) * LDR + k];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            double av[WM], bv[WM];
+#pragma unroll
+            for (int a = 0; a < WM; ++a) {
+                av[a] = As[(wr * 16 * WM + 16 * a + r) * LDR + k];
+                bv[a] = Bs[(wc * 16 * WM + 16 * a + r) * LDR + k];
+            }
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int b = 0; b < WM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
+        __syncthreads();   // every wavefront is done with this stage's tiles
+        if (more) park();
         __syncthreads();
     }
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < WM; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < WM; ++b)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int row = bi * DT + wr * 32 + a * 16 + (lane >> 4) + 4 * reg;
-                const int col = bj * DT + wc * 32 + b * 16 + (lane & 15);
+                const int row = bi * DT + wr * 16 * WM + a * 16 + (lane >> 4) + 4 * reg;
+                const int col = bj * DT + wc * 16 * WM + b * 16 + (lane & 15);
                 if (row < n && col < n) {
                     const double v = acc[a][b][reg];
                     S[(int64_t)row * n + col] = v;
@@ -121,12 +156,27 @@ __global__ void gram_to_dist_kernel(double *__restrict__ S, int n, const double 
 int launch_cell_distances(const double *x, int32_t G, const int32_t *idx_dev, int32_t n, const double *mean_dev,
                           double *diag_dev, double *out, hipStream_t stream) {
     if (n <= 0) return ICNV_OK;
+    // 128-cell tiles when they still fill the chip twice over, 64-cell tiles otherwise
+    const int64_t nt128 = (n + 127) / 128;
+    const bool big = nt128 * (nt128 + 1) / 2 >= 2 * (int64_t)num_cus();
+    const int DT = big ? 128 : 64;
     const int64_t nt = (n + DT - 1) / DT;
     const int64_t tiles = nt * (nt + 1) / 2;
     if (tiles > 0x7fffffff) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "too many cells for one distance matrix");
     {
         KernelTimer kt("cell_distances_gram", stream);
-        hipLaunchKernelGGL(gram_tiles_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, x, G, idx_dev, n, mean_dev, out);
+        const size_t lds = (size_t)2 * DT * LDR * sizeof(double);
+        if (big) {
+            static bool attr = false;
+            if (!attr) {
+                ICNV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gram_tiles_kernel<4>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                attr = true;
+            }
+            hipLaunchKernelGGL(gram_tiles_kernel<4>, dim3((unsigned)tiles), dim3(256), lds, stream, x, G, idx_dev, n, mean_dev, out);
+        } else {
+            hipLaunchKernelGGL(gram_tiles_kernel<2>, dim3((unsigned)tiles), dim3(256), lds, stream, x, G, idx_dev, n, mean_dev, out);
+        }
     }
     hipLaunchKernelGGL(gram_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, out, n, diag_dev);
     int64_t blocks = ((int64_t)n * n + 255) / 256;

@@ -17,7 +17,9 @@ for _ in range(reps): d = device.cell_distances(x, cells)
 torch.cuda.synchronize(); device.timing_enable(False)
 ms, k = device.timing_get("cell_distances_gram")
 ms /= k
-nt = (n + 63) // 64
-flops_done = nt * (nt + 1) / 2 * 64 * 64 * 2.0 * G       # upper-triangular tiles only
-print(f"gram kernel {n} cells x {G} genes: {ms:.3f} ms, {flops_done / ms / 1e9:.1f} TFLOP/s fp64 MFMA executed "
+nt128 = (n + 127) // 128
+DT = 128 if nt128 * (nt128 + 1) // 2 >= 2 * torch.cuda.get_device_properties(0).multi_processor_count else 64   # launch_cell_distances' rule
+nt = (n + DT - 1) // DT
+flops_done = nt * (nt + 1) / 2 * DT * DT * 2.0 * G       # upper-triangular tiles only
+print(f"gram kernel {n} cells x {G} genes ({DT}-cell tiles): {ms:.3f} ms, {flops_done / ms / 1e9:.1f} TFLOP/s fp64 MFMA executed "
       f"({2.0 * n * n * G / ms / 1e9:.1f} TFLOP/s counting the full n^2 G product)")
