@@ -290,17 +290,27 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
 #if ICNV_VF_EXP & 1
         if (m1 == 12345.678) 
 #endif
-        viterbi_traceback<ICNV_VF_TG>(
-            st, n, cur,
+        {
+            // OR of the words shifted by the traced state: bit 9 collects the "inside the band" bits of the path's rows
+            uint32_t uacc = 0;
+            auto load_bp = [&](int i) {
 #if ICNV_VF_POLICY & 2
-            [&](int i) { return (uint32_t)__builtin_nontemporal_load(bpc + (int64_t)i * nc); },
+                return (uint32_t)__builtin_nontemporal_load(bpc + (int64_t)i * nc);
 #else
-            [&](int i) { return (uint32_t)bpc[(int64_t)i * nc]; },
+                return (uint32_t)bpc[(int64_t)i * nc];
 #endif
-            [&](uint32_t w, int c) {
-                unsure |= (w >> (9 + c)) & 1u;
-                return ((w >> c) & 1u) ? c : (int)((w >> 6) & 7u);
-            });
+            };
+            auto step_bp = [&](uint32_t w, int c) {
+                const uint32_t tsh = w >> c;
+                uacc |= tsh;
+                return (tsh & 1u) ? c : (int)((w >> 6) & 7u);
+            };
+            const int a0 = (int)((uintptr_t)st & 7u);
+            const int a0u = __builtin_amdgcn_readfirstlane(a0);
+            if (__builtin_amdgcn_ballot_w64(a0 != a0u) == 0) viterbi_traceback_uniform(st, n, cur, a0u, load_bp, step_bp);
+            else viterbi_traceback<ICNV_VF_TG>(st, n, cur, load_bp, step_bp);
+            unsure |= (uacc >> 9) & 1u;
+        }
         if (unsure) {
             const int e = atomicAdd(A.flag_count, 1);
             A.flag_list[2 * (int64_t)e] = chr;
