@@ -106,7 +106,12 @@ int icnv_smooth_chain_dev(const double *expr_in, double *expr_out, double *pre_d
  *   2. all-reduces (sum) that buffer across ranks (RCCL; nothing to do on 1 GPU);
  *   3. icnv_chain_round_finish_dev(): turns the reduced buffer into the
  *      stage's parameters (bounds / mu,s) on the device.
- * Then icnv_chain_apply_dev() streams every local cell through the fused pass. */
+ * Then icnv_chain_apply_dev() streams every local cell through the fused pass.
+ * The rounds and the apply must be given the SAME matrix (expr_in, unchanged in between): the round that
+ * first smooths the reference cells keeps its output (one column per reference cell), and the later rounds and
+ * the apply continue from it instead of smoothing those cells again.  The kept columns are tied to the expr_in
+ * pointer and consumed by the apply; an apply without fresh rounds recomputes every cell from expr_in with the
+ * parameters of the last rounds. */
 typedef struct icnv_chain icnv_chain_t;
 int icnv_chain_begin(icnv_chain_t **chain, const icnv_chain_cfg *cfg);
 int icnv_chain_num_rounds(const icnv_chain_t *chain);
