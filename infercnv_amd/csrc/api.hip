@@ -188,6 +188,10 @@ struct icnv_chain {
     std::vector<uint32_t> inv_codes;
     bool inv_coded = false;   // host copy of the smoothing normalisation table (kept alive for the async upload)
     bool uploaded = false;
+    // Gene sets beyond the fused kernel's LDS-resident limit run the three-pass chain (chain_large.hip)
+    bool large = false;
+    int32_t max_chr_len = 0;
+    DevBuf d_ref_off, d_large_tmp;
     // Reference-cell cache: the round that first runs the expensive stages (smoothing, centring) on the reference
     // cells keeps its output (one column per position of ref_idx), so that the later rounds and the apply pass
     // continue from it instead of smoothing the same cells again (three times per chain otherwise).
@@ -264,9 +268,6 @@ int icnv_chain_begin(icnv_chain_t **out, const icnv_chain_cfg *cfg) {
         ICNV_FAIL(ICNV_ERR_ARG, "window_length must be odd (the reference is undefined for even windows)");
     if ((mask & ICNV_ST_DENOISE) && !std::isnan(cfg->noise_filter) && cfg->noise_filter == 0.0)
         mask &= ~ICNV_ST_DENOISE;  // clear_noise(threshold = 0) is a no-op, R/inferCNV_ops.R:2236
-    if (cfg->G > chain_max_genes())
-        ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "fused smoothing chain supports at most " + std::to_string(chain_max_genes()) +
-                                            " genes (LDS-resident cell vector)");
     const bool needs_ref = mask & (ICNV_ST_SUBTRACT_REF_1 | ICNV_ST_SUBTRACT_REF_2 | ICNV_ST_DENOISE);
     if (needs_ref) {
         if (cfg->n_ref_grp < 1) ICNV_FAIL(ICNV_ERR_ARG, "reference groups required for steps 8/12/22");
@@ -277,6 +278,15 @@ int icnv_chain_begin(icnv_chain_t **out, const icnv_chain_cfg *cfg) {
     ch->cfg = *cfg;
     ch->mask = mask;
     ch->T = (mask & ICNV_ST_SMOOTH) ? (cfg->window_length - 1) / 2 : 0;
+    for (int k = 0; k < cfg->n_chr; ++k) ch->max_chr_len = std::max(ch->max_chr_len, cfg->chr_start[k + 1] - cfg->chr_start[k]);
+    {
+        const char *force = std::getenv("ICNV_CHAIN_LARGE");   // developer switch: the three-pass chain for any size
+        ch->large = (force && force[0] == '1') || cfg->n_chr > 510 || !chain_fused_fits(cfg->G, cfg->n_chr, ch->T);
+        if (ch->large && chain_large_lds_bytes(ch->max_chr_len, ch->T) > 152 * 1024) {
+            delete ch;
+            ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "smoothing chain: a single chromosome (plus the window) exceeds the 160 KiB LDS");
+        }
+    }
     ch->chr_start.assign(cfg->chr_start, cfg->chr_start + cfg->n_chr + 1);
     if (needs_ref) {
         ch->ref_off.assign(cfg->ref_off, cfg->ref_off + cfg->n_ref_grp + 1);
@@ -313,7 +323,7 @@ static int chain_upload(icnv_chain *ch, hipStream_t s) {
         const size_t nref = ch->ref_idx.size();
         const size_t bytes = nref * (size_t)G * sizeof(double);
         const char *off = std::getenv("ICNV_REF_CACHE");   // developer switch: ICNV_REF_CACHE=0 recomputes the reference cells
-        if (nref > 0 && nref * 2 <= (size_t)ch->cfg.C && bytes <= ((size_t)16 << 30) && !(off && off[0] == '0') &&
+        if (!ch->large && nref > 0 && nref * 2 <= (size_t)ch->cfg.C && bytes <= ((size_t)16 << 30) && !(off && off[0] == '0') &&
             (ch->mask & (ICNV_ST_SMOOTH | ICNV_ST_CENTER))) {
             std::vector<char> is_ref((size_t)ch->cfg.C, 0);
             for (int32_t c : ch->ref_idx) is_ref[c] = 1;
@@ -323,6 +333,13 @@ static int chain_upload(icnv_chain *ch, hipStream_t s) {
             if ((rc = upload(ch->d_nonref, ch->nonref.data(), ch->nonref.size(), s))) return rc;
             ch->cache_enabled = true;
         }
+    }
+    if ((rc = upload(ch->d_ref_off, ch->ref_off.data(), ch->ref_off.size(), s))) return rc;
+    if (ch->large) {
+        ch->cache_enabled = false;
+        if (!ch->ref_idx.empty() && (rc = ch->d_large_tmp.alloc(ch->ref_idx.size() * (size_t)G * sizeof(double)))) return rc;
+        ch->uploaded = true;
+        return ICNV_OK;
     }
     if (ch->T >= 1) {
         if ((rc = chain_build_inv_table(ch->chr_start.data(), ch->cfg.n_chr, (int32_t)G, ch->T, ch->inv_tab, ch->inv_codes,
@@ -358,6 +375,70 @@ static ChainArgs chain_args(icnv_chain *ch, const double *in) {
     return a;
 }
 
+// ---- three-pass chain (chain_large.hip): the stages `m` of the chain on `n_rows` rows ----
+static LargeChainArgs large_args(icnv_chain *ch) {
+    LargeChainArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.G = (int32_t)ch->cfg.G;
+    a.chr_start = ch->d_chr.as<int32_t>();
+    a.n_chr = ch->cfg.n_chr;
+    a.T = ch->T;
+    a.max_thresh = ch->cfg.max_thresh;
+    a.b1 = ch->d_b1.as<double>();
+    a.b2 = ch->d_b2.as<double>();
+    a.denoise = ch->d_den.as<double>();
+    return a;
+}
+// stages S and M of mask m: in (rows in_rows) -> out (rows out_rows); returns the bits of m still to do (E)
+static int large_smooth_center(icnv_chain *ch, uint32_t m, const double *in, const int32_t *in_rows, double *out,
+                               const int32_t *out_rows, int32_t n_rows, hipStream_t s) {
+    LargeChainArgs a = large_args(ch);
+    a.in = in; a.in_rows = in_rows; a.out = out; a.out_rows = out_rows; a.n_rows = n_rows;
+    a.mask = m & (ICNV_ST_SUBTRACT_REF_1 | ICNV_ST_MAX_THRESH | ICNV_ST_SMOOTH);
+    int rc = launch_chain_large_smooth(a, ch->max_chr_len, s);
+    if (rc) return rc;
+    if (m & ICNV_ST_CENTER) {
+        a.mask = m & (ICNV_ST_CENTER | ICNV_ST_CENTER_MEAN);
+        if ((rc = launch_chain_large_center(a, s))) return rc;
+    }
+    return ICNV_OK;
+}
+
+static int large_round_partial(icnv_chain *ch, uint32_t bit, uint32_t m, const double *expr_in, hipStream_t s) {
+    const int64_t G = ch->cfg.G;
+    const int ng = ch->cfg.n_ref_grp;
+    const int32_t nref = (int32_t)ch->ref_idx.size();
+    int rc;
+    double *tmp = ch->d_large_tmp.as<double>();   // one row per position of the reference list
+    const bool any_sm = m & (ICNV_ST_SUBTRACT_REF_1 | ICNV_ST_MAX_THRESH | ICNV_ST_SMOOTH | ICNV_ST_CENTER);
+    if (any_sm && nref > 0 && (rc = large_smooth_center(ch, m, expr_in, ch->d_ref.as<int32_t>(), tmp, nullptr, nref, s))) return rc;
+    if (bit == ICNV_ST_DENOISE) {
+        if (nref > 0) {
+            LargeChainArgs a = large_args(ch);
+            a.in = any_sm ? tmp : expr_in;
+            a.in_rows = any_sm ? nullptr : ch->d_ref.as<int32_t>();
+            a.n_rows = nref;
+            a.mask = m & (ICNV_ST_SUBTRACT_REF_2 | ICNV_ST_INVERT_LOG2);
+            a.cell_stats = ch->d_cellstats.as<double>();
+            if ((rc = launch_chain_large_finish(a, s))) return rc;
+        }
+        return launch_reduce_cell_stats(ch->d_cellstats.as<double>(), nref, (int32_t)G, ch->d_stats.as<double>(), s);
+    }
+    // per-gene sums of the reference groups: over the staged rows (positions) or straight over the input's cells
+    return launch_chain_large_group_sums(any_sm ? tmp : expr_in, (int32_t)G, any_sm ? nullptr : ch->d_ref.as<int32_t>(),
+                                         ch->d_ref_off.as<int32_t>(), ng, ch->d_sums.as<double>(), s);
+}
+
+static int large_apply(icnv_chain *ch, const double *expr_in, double *expr_out, double *pre_denoise, hipStream_t s) {
+    const int32_t C = (int32_t)ch->cfg.C;
+    int rc = large_smooth_center(ch, ch->mask, expr_in, nullptr, expr_out, nullptr, C, s);
+    if (rc) return rc;
+    LargeChainArgs a = large_args(ch);
+    a.in = expr_out; a.out = expr_out; a.pre = pre_denoise; a.n_rows = C;
+    a.mask = ch->mask & (ICNV_ST_SUBTRACT_REF_2 | ICNV_ST_INVERT_LOG2 | ICNV_ST_DENOISE);
+    return launch_chain_large_finish(a, s);
+}
+
 int icnv_chain_round_partial_dev(icnv_chain_t *ch, int round, const double *expr_in, double **partial_dev,
                                  int64_t *n, void *stream) {
     if (!ch || !expr_in || round < 0 || round >= (int)ch->round_stage.size()) ICNV_FAIL(ICNV_ERR_ARG, "bad round");
@@ -369,6 +450,17 @@ int icnv_chain_round_partial_dev(icnv_chain_t *ch, int round, const double *expr
     const int ng = ch->cfg.n_ref_grp;
     ChainArgs a = chain_args(ch, expr_in);
     a.mask = stages_before(ch->mask, bit) | (ch->mask & ICNV_ST_CENTER_MEAN);
+    if (ch->large) {
+        if ((rc = large_round_partial(ch, bit, a.mask, expr_in, s))) return rc;
+        if (bit == ICNV_ST_DENOISE) {
+            if (partial_dev) *partial_dev = ch->d_stats.as<double>();
+            if (n) *n = 4;
+        } else {
+            if (partial_dev) *partial_dev = ch->d_sums.as<double>();
+            if (n) *n = G * ng + ng;
+        }
+        return ICNV_OK;
+    }
     if (bit == ICNV_ST_DENOISE) {
         const int nref = (int)ch->ref_idx.size();
         a.cells = ch->d_ref.as<int32_t>();
@@ -433,6 +525,7 @@ int icnv_chain_apply_dev(icnv_chain_t *ch, const double *expr_in, double *expr_o
     hipStream_t s = (hipStream_t)stream;
     int rc = chain_upload(ch, s);
     if (rc) return rc;
+    if (ch->large) return large_apply(ch, expr_in, expr_out, pre_denoise, s);
     ChainArgs a = chain_args(ch, expr_in);
     a.mask = ch->mask;
     a.out = expr_out;

@@ -208,6 +208,12 @@ static bool chain_geom(int64_t G, int n_chr, int T, ChainGeom &g) {
     return false;
 }
 
+bool chain_fused_fits(int64_t G, int32_t n_chr, int32_t T) {
+    ChainGeom g;
+    if (!chain_geom(G, n_chr, T, g)) return false;
+    return !(T >= 1 && T / g.lmax > 64);   // CS_GUARD of chain_kernel.inc
+}
+
 int chain_build_inv_table(const int32_t *chr_start, int32_t n_chr, int32_t G, int32_t T, std::vector<double> &tab,
                           std::vector<uint32_t> &codes, std::vector<double> &dict, bool &coded) {
     ChainGeom g;

@@ -69,6 +69,32 @@ struct ChainArgs {
 
 int launch_chain(const ChainArgs &a, int mode, hipStream_t stream);
 int chain_max_genes();
+bool chain_fused_fits(int64_t G, int32_t n_chr, int32_t T);   // does the LDS-resident fused kernel take this geometry?
+
+// three-pass chain for gene sets beyond the fused kernel's limit (chain_large.hip)
+struct LargeChainArgs {
+    const double *in;          // rows of G doubles
+    double *out;               // S: stage output; M: in place on `out`; E: final matrix (may alias `in`)
+    double *pre;               // E, nullable: matrix before step 22
+    int32_t G;
+    const int32_t *in_rows;    // nullable (identity): row of `in` read by launch row r
+    const int32_t *out_rows;   // nullable (identity): row of `out` / `pre` written by launch row r
+    int32_t n_rows;
+    const int32_t *chr_start;  // device, n_chr + 1
+    int32_t n_chr;
+    int32_t T;
+    uint32_t mask;             // the ICNV_ST_* bits this pass applies
+    double max_thresh;
+    const double *b1, *b2;     // [2*G] lo | hi
+    const double *denoise;     // [2] mu, s
+    double *cell_stats;        // E, nullable: [n_rows * 2] {sum, sd} instead of writing the matrix
+};
+size_t chain_large_lds_bytes(int32_t max_chr_len, int32_t T);
+int launch_chain_large_smooth(const LargeChainArgs &a, int32_t max_chr_len, hipStream_t stream);
+int launch_chain_large_center(const LargeChainArgs &a, hipStream_t stream);
+int launch_chain_large_finish(const LargeChainArgs &a, hipStream_t stream);
+int launch_chain_large_group_sums(const double *x, int32_t G, const int32_t *idx_dev, const int32_t *off_dev, int32_t n_grp,
+                                  double *sums_counts, hipStream_t stream);
 // Host: per-position normalisation table of the smoothing stage for this geometry, in the kernel's
 // [(LMAX+1)/2][NT] double2 layout (R/inferCNV_ops.R:2410-2440: pyramid weights renormalised at chromosome edges).
 int chain_build_inv_table(const int32_t *chr_start, int32_t n_chr, int32_t G, int32_t T, std::vector<double> &tab,

@@ -152,6 +152,54 @@ def test_chain_many_cells_per_workgroup(dev, mask):
         assert np.abs(got - v).max() < 1e-11 * max(1.0, np.abs(v).max())
 
 
+def _random_chr_layout(G, n_chr, rng, with_single=True):
+    cuts = np.sort(rng.choice(np.arange(1, G), size=n_chr - 1, replace=False))
+    cs = np.concatenate([[0], cuts, [G]]).astype(np.int32)
+    if with_single:
+        cs[2] = cs[1] + 1                                   # a single-gene chromosome (left untouched by step 10)
+    return cs
+
+
+@pytest.mark.parametrize("G,C,n_chr,kw", [(24000, 20, 30, {}), (19001, 9, 24, {"window_length": 151}),
+                                          (30000, 6, 2, {"stage_mask": 0x3F}), (26000, 8, 40, {"stage_mask": 0x8F}),
+                                          (21000, 7, 25, {"use_bounds": False, "max_thresh": None})])
+def test_chain_large_gene_sets_vs_oracle(dev, G, C, n_chr, kw):
+    """Gene sets beyond the fused kernel's LDS-resident limit run the three-pass chain (chain_large.hip)."""
+    from infercnv_amd import synth
+    rng = np.random.default_rng(G)
+    x = rng.normal(0.0, 1.0, size=(G, C)) + rng.normal(0.0, 0.5, size=(G, 1))
+    cs = _random_chr_layout(G, n_chr, rng) if n_chr > 2 else np.array([0, 14000, G], dtype=np.int32)
+    refs = [np.array([1, 0], dtype=np.int32), np.arange(2, max(3, C // 3), dtype=np.int32)]
+    out, pre = dev.smooth_chain(to_dev(x), cs, refs, want_pre_denoise=True, **kw)
+    okw = {k: v for k, v in kw.items() if k != "stage_mask"}
+    if kw.get("stage_mask") == 0x8F:
+        v = oc.subtract_ref_expr_from_obs(x, refs)
+        v = oc.apply_max_threshold_bounds(v, 3.0)
+        v = oc.smooth_by_chromosome(v, cs, 101)
+        want = oc.center_columns(v, "mean")
+        assert np.abs(to_host(out) - want).max() < 1e-11
+        return
+    want, want_pre, _ = oc.smooth_chain(x, cs, refs, want_pre_denoise=True, **kw)
+    assert np.abs(to_host(pre) - want_pre).max() < 1e-11 * max(1.0, np.abs(want_pre).max())
+    assert (np.abs(to_host(out) - want) > 1e-11 * max(1.0, np.abs(want).max())).mean() < 1e-3
+
+
+def test_chain_three_pass_equals_fused(dev, monkeypatch):
+    """The three-pass chain forced on a size the fused kernel serves: two independent GPU implementations of the
+    same steps must agree (to rounding: different summation orders in the pyramid)."""
+    from infercnv_amd import synth
+    G, C = 10000, 300
+    x, cs = synth.make_matrix_np(G, C)
+    refs, _ = synth.groups(C)
+    xd = to_dev(x)
+    out_f, pre_f = dev.smooth_chain(xd, cs, refs, want_pre_denoise=True)
+    monkeypatch.setenv("ICNV_CHAIN_LARGE", "1")
+    out_l, pre_l = dev.smooth_chain(xd, cs, refs, want_pre_denoise=True)
+    monkeypatch.delenv("ICNV_CHAIN_LARGE")
+    assert (pre_f - pre_l).abs().max().item() < 1e-12
+    assert ((out_f - out_l).abs() > 1e-12).double().mean().item() < 1e-4
+
+
 def test_chain_options(dev):
     """use_bounds=FALSE, no threshold, short / long / no window, fixed-threshold denoise, no denoise."""
     from infercnv_amd import synth

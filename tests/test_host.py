@@ -57,7 +57,11 @@ def test_argument_validation_happens_before_any_device_work():
     oob = _lib.Cfg(10, 4, [0, 10], [[7]])                  # reference index outside the matrix
     assert L.icnv_chain_begin(ct.byref(h), oob.ptr()) == _lib.ERR_ARG
     big = _lib.Cfg(30000, 4, [0, 30000], [[0]])
-    assert L.icnv_chain_begin(ct.byref(h), big.ptr()) == _lib.ERR_UNSUPPORTED
+    assert L.icnv_chain_begin(ct.byref(h), big.ptr()) == _lib.ERR_UNSUPPORTED     # one chromosome beyond the LDS
+    assert b"chromosome" in L.icnv_last_error()
+    wide = _lib.Cfg(30000, 4, [0, 14000, 30000], [[0]])    # beyond the fused kernel: the three-pass chain takes it
+    assert L.icnv_chain_begin(ct.byref(h), wide.ptr()) == _lib.OK
+    L.icnv_chain_end(h)
     ok = _lib.Cfg(10, 4, [0, 4, 10], [[0], [3, 1]])
     assert L.icnv_chain_begin(ct.byref(h), ok.ptr()) == _lib.OK
     assert L.icnv_chain_num_rounds(h) == 3                 # steps 8, 12, 22
