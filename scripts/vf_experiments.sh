@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer ablation of the certified fast Viterbi kernel: build variants with pieces stubbed out (ICNV_VF_EXP bits:
-# 1 no traceback, 2 no back-pointer stores, 4 no recurrence, 8 no observation loads, 16 no coefficient reads,
+# 1 no traceback, 2 no back-pointer stores (only together with 1), 4 no recurrence, 8 no observation loads, 16 no coefficient reads,
 # 32 no interval lookup) and time each on the bench workload.  Results are wrong by construction -- timing only.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R/infercnv_amd/csrc
 mkdir -p exp_obj
