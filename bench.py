@@ -58,9 +58,17 @@ def cpu_baseline(G, target_seconds=12.0):
     if t < 0.6 * target_seconds and C < 60000:     # the pilot under-estimated the parallel speed: one larger sample
         C = int(min(60000, C * target_seconds / max(t, 1e-3)))
         t = run(C)
-    return {"value": C / t, "unit": "cells/s", "cores": oc.num_threads(), "kind": "port",
-            "sample": f"{G} genes x {C} cells of the same synthetic generator, smooth chain + i6 Viterbi, "
-                      f"oracle/icnv_oracle.c with OpenMP over cells, {t:.1f} s"}
+    res = {"value": C / t, "unit": "cells/s", "cores": oc.num_threads(), "kind": "port",
+           "sample": f"{G} genes x {C} cells of the same synthetic generator, smooth chain + i6 Viterbi, "
+                     f"oracle/icnv_oracle.c with OpenMP over cells, {t:.1f} s"}
+    # the reference's own structure is serial R: one core of the same port, a few seconds
+    oc.set_num_threads(1)
+    c1 = 512
+    t1 = run(c1)
+    oc.set_num_threads(cores)
+    res["single_thread"] = {"value": c1 / t1, "unit": "cells/s", "cores": 1,
+                            "sample": f"{G} genes x {c1} cells, same code on one core, {t1:.1f} s"}
+    return res
 
 
 def main():
