@@ -153,6 +153,16 @@ hip_apply_median_filtering <- function(infercnv_obj, window_size = 7, on_observa
     infercnv_obj
 }
 
+## parallelDist(t(tumor_expr_data)) of .single_tumor_subclustering (R/inferCNV_tumor_subclusters.R:191) as a `dist`
+## object: hclust(hip_cell_dist(tumor_expr_data), method = hclust_method)
+hip_cell_dist <- function(tumor_expr_data) {
+    x <- as.matrix(tumor_expr_data)
+    storage.mode(x) <- "double"
+    d <- .Call("icnv_R_cell_distances", x, seq_len(ncol(x)) - 1L)
+    dimnames(d) <- list(colnames(x), colnames(x))
+    stats::as.dist(d)
+}
+
 ## Swap the package's step functions for the hip ones (called from .onLoad when the option is set).
 .icnv_enable_hip_backend <- function(device = -1L) {
     .Call("icnv_R_init", as.integer(device))

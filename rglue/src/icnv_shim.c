@@ -114,6 +114,17 @@ SEXP icnv_R_median_filter(SEXP expr, SEXP chr_start, SEXP tile_idx, SEXP tile_of
     return out;
 }
 
+/* .Call("icnv_R_cell_distances", expr, cell_idx): full symmetric matrix of parallelDist(t(expr[, cells])) */
+SEXP icnv_R_cell_distances(SEXP expr, SEXP cell_idx) {
+    const R_xlen_t n = XLENGTH(cell_idx);
+    SEXP out = PROTECT(Rf_allocMatrix(REALSXP, (int)n, (int)n));
+    int rc = icnv_cell_distances(REAL(expr), Rf_nrows(expr), Rf_ncols(expr), (const int32_t *)INTEGER(cell_idx), (int64_t)n,
+                                 REAL(out));
+    if (rc) { UNPROTECT(1); fail(rc); }
+    UNPROTECT(1);
+    return out;
+}
+
 SEXP icnv_R_init(SEXP device) {
     int rc = icnv_init(Rf_asInteger(device));
     if (rc) fail(rc);
@@ -126,6 +137,7 @@ static const R_CallMethodDef call_methods[] = {
     {"icnv_R_viterbi_cells", (DL_FUNC)&icnv_R_viterbi_cells, 6},
     {"icnv_R_viterbi_groups", (DL_FUNC)&icnv_R_viterbi_groups, 8},
     {"icnv_R_median_filter", (DL_FUNC)&icnv_R_median_filter, 5},
+    {"icnv_R_cell_distances", (DL_FUNC)&icnv_R_cell_distances, 2},
     {"icnv_R_init", (DL_FUNC)&icnv_R_init, 1},
     {NULL, NULL, 0}};
 
