@@ -4,7 +4,7 @@
     independent 40-digit evaluations of the reference's emission formula
     (R/inferCNV_HMM.R:1129-1133) -- the certified eps_tab must hold;
   * eps_spec: the exact kernel's arithmetic (restated in oracle_np.emission_scores) against the
-    same 40-digit values -- the budgeted 5e-14 must hold with a wide margin;
+    same 40-digit values -- the budgeted 1e-12 must hold with a wide margin;
   * the certified recurrence itself, restated in NumPy from viterbi_fast.hip, against the oracle's
     exact Viterbi: every sequence the margin test does NOT flag must carry the oracle's states,
     also when the band is inflated a million-fold (many flags) and on inputs built to tie.
