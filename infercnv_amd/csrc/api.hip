@@ -933,6 +933,23 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
     g_viterbi_stats[2] = fast ? -1 : 0;
     g_viterbi_stats[3] = fast ? g_fast.tab.n_int : 0;
 
+    // Few sequences (the group modes: one column per subcluster / sample): the lane-per-sequence kernel would take
+    // as long as its longest chromosome on one lane (~2 ms); the wave-per-sequence kernel -- the redo kernel run
+    // over the list of ALL (chromosome, column) pairs, longest chromosomes first -- scores 64 genes at a time.
+    if (!fast && ncols * n_chr <= 8192) {
+        std::vector<int32_t> list;
+        list.reserve((size_t)2 * ncols * n_chr + 1);
+        for (int32_t c : order)
+            for (int64_t col = 0; col < ncols; ++col) { list.push_back(c); list.push_back((int32_t)col); }
+        const int32_t count = (int32_t)(list.size() / 2);
+        list.push_back(count);   // the count rides behind the list
+        DevBuf d_all, d_scr;
+        if ((rc = upload(d_all, list.data(), list.size(), s))) return rc;
+        if ((rc = d_scr.alloc(viterbi_redo_scratch_bytes(max_len)))) return rc;
+        return launch_viterbi_redo(x, states, (int32_t)G, d_chr.as<int32_t>(), p, sd_per_col_dev, sd_shared,
+                                   d_all.as<int32_t>() + 2 * (size_t)count, d_all.as<int32_t>(), d_scr.as<uint32_t>(),
+                                   n_underflow_dev, "viterbi", s);
+    }
     const int64_t bp_elem = fast ? 2 : 4;
     int64_t batch = ((int64_t)4 << 30) / ((int64_t)G * bp_elem);
     batch = std::max<int64_t>(64, (batch / 64) * 64);
@@ -984,8 +1001,8 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
         fa.flag_list = d_list.as<int32_t>();
         ICNV_HIP(hipMemsetAsync(g_fast.counters, 0, 2 * sizeof(int32_t), s));
         if ((rc = launch_viterbi_fast(fa, p.K, s))) return rc;
-        if ((rc = launch_viterbi_redo(fa.x, fa.states, (int32_t)G, d_chr.as<int32_t>(), p, sd_shared, fa.flag_count,
-                                      fa.flag_list, d_redo.as<uint32_t>(), n_underflow_dev, s)))
+        if ((rc = launch_viterbi_redo(fa.x, fa.states, (int32_t)G, d_chr.as<int32_t>(), p, nullptr, sd_shared, fa.flag_count,
+                                      fa.flag_list, d_redo.as<uint32_t>(), n_underflow_dev, "viterbi_redo", s)))
             return rc;
         ICNV_HIP(hipMemcpyAsync(g_fast.host_flag, fa.flag_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         ICNV_HIP(hipEventRecord(g_fast.flag_ev, s));
