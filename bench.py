@@ -68,6 +68,8 @@ def cpu_baseline(G, target_seconds=12.0):
     oc.set_num_threads(cores)
     res["single_thread"] = {"value": c1 / t1, "unit": "cells/s", "cores": 1,
                             "sample": f"{G} genes x {c1} cells, same code on one core, {t1:.1f} s"}
+    # os.cpu_count() counts the node's logical CPUs; a container's CPU quota can be far smaller
+    res["parallel_speedup_over_one_core"] = res["value"] / res["single_thread"]["value"]
     return res
 
 
