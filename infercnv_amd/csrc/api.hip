@@ -1014,6 +1014,8 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
 int icnv_viterbi_set_mode(int mode) {
     if (mode != 0 && mode != 1) ICNV_FAIL(ICNV_ERR_ARG, "mode must be 0 (auto) or 1 (exact kernel only)");
     g_viterbi_mode = mode;
+    g_fast.skip_calls = 0;   // also forgets the "flagged too much lately" state of the adaptive skip
+    g_fast.flag_seqs = 0;
     return ICNV_OK;
 }
 

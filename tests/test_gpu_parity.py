@@ -297,6 +297,51 @@ def test_viterbi_fast_path_equals_exact_kernel_and_oracle(dev):
         dev.viterbi_set_mode(0)
 
 
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_viterbi_fast_path_random_models(dev, seed):
+    """Random HMMs (3 or 6 states, random increasing means with gaps of 0.3 .. 4 sd, random sd and transition
+    probability) on data built to stress the certified path -- values at the state means and mid-points, at the
+    table's domain edges, foreign values -- certified fast path against the exact kernel, bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    K = 6 if seed % 2 == 0 else 3
+    sd = float(rng.uniform(0.02, 0.5))
+    means = 1.0 + np.cumsum(rng.uniform(0.3, 4.0, size=K) * sd)
+    means -= means[K // 2] - 1.0
+    t = float(rng.choice([1e-6, 1e-4, 1e-2, 0.08]))
+    Pi = np.full((K, K), t)
+    np.fill_diagonal(Pi, 1 - 5 * t)                      # the reference's (non-stochastic for K = 3) diagonal
+    delta = np.full(K, t)
+    delta[K // 2] = 1 - 5 * t
+    sizes = rng.integers(1, 400, size=int(rng.integers(3, 9)))
+    sizes[0] = 1
+    G, C = int(sizes.sum()), 256
+    cs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    centre = rng.choice(means, size=(1, C))
+    x = centre + rng.normal(0.0, sd * rng.uniform(0.2, 1.5), size=(G, C))
+    special = rng.random((G, C))
+    mids = (means[:-1] + means[1:]) / 2
+    pool = np.concatenate([means, mids, means + 14 * sd, means - 14 * sd, [means[0] - 40 * sd, means[-1] + 40 * sd]])
+    x = np.where(special < (0.05 if seed < 5 else 0.003), rng.choice(pool, size=(G, C)), x)   # sparse for half the seeds
+    foreign_cols = rng.random(C) < 0.04               # foreign values in a few sequences only (each is redone exactly)
+    x = np.where((special > 0.97) & foreign_cols[None, :], rng.choice([np.nan, np.inf, -np.inf, 1e9, -1e9], size=(G, C)), x)
+    xd = to_dev(x)
+    try:
+        dev.viterbi_set_mode(0)
+        st_fast, bad0 = dev.viterbi_cells(xd, cs, means, sd, np.log(Pi), np.log(delta))
+        stats = dev.viterbi_last_stats()
+        dev.viterbi_set_mode(1)
+        st_exact, bad1 = dev.viterbi_cells(xd, cs, means, sd, np.log(Pi), np.log(delta))
+    finally:
+        dev.viterbi_set_mode(0)
+    assert stats["path"] == "fast"
+    assert stats["flagged"] < 0.85 * stats["sequences"]      # a good share of the answers comes from the certified path itself
+    assert torch.equal(st_fast, st_exact) and int(bad0.item()) == int(bad1.item())
+    # a sample of columns against the CPU oracle as well
+    pick = np.arange(0, C, 37)
+    want, _ = oc.viterbi_cells(x[:, pick], cs, means, sd, np.log(Pi), np.log(delta))
+    np.testing.assert_array_equal(st_fast.cpu().numpy().T[:, pick], want)
+
+
 def test_viterbi_adversarial_near_ties_bit_exact(dev):
     """Inputs sitting on emission-branch boundaries and state mid-points, 1-gene and 2-gene chromosomes."""
     from infercnv_amd import synth
