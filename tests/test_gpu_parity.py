@@ -838,3 +838,19 @@ def test_cell_distances_vs_oracle(dev, G, C, n):
         dup = np.concatenate([cells[:2], cells[:1]]).astype(np.int32)
         d3 = dev.cell_distances(to_dev(x), dup).cpu().numpy()
         assert d3[0, 2] <= 1e-6 * max(want.max(), 1.0) and abs(d3[0, 1] - want[0, 1]) <= 1e-12 * max(want.max(), 1.0)
+
+
+def test_parallelDist_mirror_matches_scipy(dev):
+    """Host mirror of parallelDist(t(tumor_expr_data)): the R `dist` vector (== SciPy's condensed form)."""
+    from scipy.spatial.distance import pdist
+    from infercnv_amd import GeneOrder, InfercnvObject, tumor_subclusters
+    rng = np.random.default_rng(8)
+    G, C = 900, 70
+    x = rng.normal(1.0, 0.2, size=(G, C))
+    obj = InfercnvObject(expr_data=x, gene_order=GeneOrder(chr=np.repeat(["chr1", "chr2"], [400, 500])),
+                         reference_grouped_cell_indices={"normal": np.arange(10)},
+                         observation_grouped_cell_indices={"tumor": np.arange(10, C)})
+    cells = np.arange(10, C)
+    d = tumor_subclusters.parallelDist(obj, cells)
+    want = pdist(x[:, cells].T)
+    assert d.shape == want.shape and np.abs(d - want).max() <= 1e-12 * want.max()
