@@ -58,6 +58,9 @@ namespace {
 #ifndef ICNV_VF_CH
 #define ICNV_VF_CH 8
 #endif
+#ifndef ICNV_VF_PIPE
+#define ICNV_VF_PIPE 0     // 1: score gene j + 1 from the table while gene j's recurrence step runs (measured: no gain, 3.28 vs 3.25 ms -- the SIMDs already issue 90 % of the time)
+#endif
 #ifndef ICNV_VF_POLICY
 #define ICNV_VF_POLICY 1   // bit 0: observations with the default cache policy (else non-temporal); bit 1: back-pointer / state traffic non-temporal
 #endif
@@ -261,11 +264,44 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         if (i + CH <= n) {
             double xcur[CH], xnext[CH];
             load_chunk(xc + i, xcur);
+#if ICNV_VF_PIPE
+            // software pipeline over genes: the table scores of gene j + 1 (two dependent LDS lookups, then the
+            // coefficient gathers) are requested before the recurrence step of gene j, whose arithmetic hides them
+            double sc[K];
+            {
+                double tn0;
+                int idx0;
+                locate(xcur[0], idx0, tn0);
+                poly(idx0, tn0, sc);
+            }
+#endif
             for (; i + CH <= n; i += CH) {
                 const bool more = i + 2 * CH <= n;
                 if (more) load_chunk(xc + i + CH, xnext);
+#if ICNV_VF_PIPE
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    double scn[K], tn1;
+                    int idx1;
+                    const bool have = (j + 1 < CH) || more;
+                    if (have) {
+                        locate(j + 1 < CH ? xcur[(j + 1) % CH] : xnext[0], idx1, tn1);
+                        poly(idx1, tn1, scn);
+                    }
+                    const uint32_t word = step(sc);
+                    bpc[(int64_t)(i + j) * A.ncols] = (uint16_t)word;
+                    if (have) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) sc[k] = scn[k];
+                    }
+#if ICNV_VF_SB
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
+#else
 #pragma unroll
                 for (int j = 0; j < CH; ++j) gene(xcur[j], i + j);
+#endif
                 if (more) {
 #pragma unroll
                     for (int j = 0; j < CH; ++j) xcur[j] = xnext[j];
