@@ -8,9 +8,11 @@
 //     (built in 80-bit arithmetic from the exact functions, verified through these very double
 //     operations; eps_tab), plus the distance of the exact kernel's own arithmetic from the exact
 //     functions (eps_spec);
-//   - the recurrence itself in the same double operations (add, max, add),
+//   - the recurrence on nu_i - i b (the diagonal log transition b is a shift common to all states, so it is
+//     dropped: one add, max, add per state; two roundings and the rounding of a - b per step, against the
+//     exact kernel's two),
 // and tests every decision it takes against the accumulated error bound: with
-//   E_i <= (i + 1) * (eps + 4 u B)   (u = 2^-53, B >= any |value| of the recurrence)
+//   E_i <= (i + 1) * (eps + 6 u B)   (u = 2^-53, B >= any |value| of the recurrence)
 // bounding |nu_fast - nu_exact| after gene i, a decision whose winner leads by more than 2 E_i is
 // the decision the exact arithmetic takes (max is 1-Lipschitz).  A sequence with any decision inside
 // the band (or an observation outside the table's domain, or a non-finite one) is FLAGGED and
@@ -86,6 +88,37 @@ __device__ inline double max_raw(double x, double y) {
     return r;
 }
 
+// the same with a wave-uniform second operand (kept in scalar registers)
+__device__ inline double min_raw_s(double x, double y) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "s"(y));
+    return r;
+}
+__device__ inline double max_raw_s(double x, double y) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "s"(y));
+    return r;
+}
+// "Near the top" masks of three states and the state number of the lanes' near-top state in one block:
+//   m_j = lanes with e_j >= t2;  i1 = m_j ? KA - j : i1   (j = 0, 1, 2: states KA, KA - 1, KA - 2).
+// Written out because (a) the compiler recomputes a comparison with the opposite sense when its mask feeds both a
+// ballot and a select, and (b) gfx950 wants two wait states between a vector instruction that writes a scalar
+// register and a vector instruction that reads it -- the compiler pads its own code with s_nop, but it does not
+// look inside an asm statement.  Three comparisons, then three selects: every select is two instructions behind
+// its comparison.
+template <int KA>
+__device__ inline void near_top3(double e0, double e1, double e2, double t2, uint32_t &i1, uint64_t &m0, uint64_t &m1,
+                                 uint64_t &m2) {
+    asm("v_cmp_ge_f64_e64 %1, %4, %7\n\t"
+        "v_cmp_ge_f64_e64 %2, %5, %7\n\t"
+        "v_cmp_ge_f64_e64 %3, %6, %7\n\t"
+        "v_cndmask_b32_e64 %0, %0, %8, %1\n\t"
+        "v_cndmask_b32_e64 %0, %0, %9, %2\n\t"
+        "v_cndmask_b32_e64 %0, %0, %10, %3"
+        : "+v"(i1), "=&s"(m0), "=&s"(m1), "=&s"(m2)
+        : "v"(e0), "v"(e1), "v"(e2), "s"(t2), "n"(KA), "n"(KA - 1), "n"(KA - 2));
+}
+
 template <int K>
 __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbiArgs A) {
     extern __shared__ __attribute__((aligned(16))) double tab[];
@@ -118,21 +151,23 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             continue;
         }
         uint16_t *bpc = A.bp + (int64_t)s0 * A.ncols + col;
-            // decision band of this task: 4 (n + 1) (eps + 4 u B), B = |logDelta|max + |a| + (n + 1)(s_max + |b|)
+            // decision band of this task: 4 (n + 1) (eps + 6 u B), B = |logDelta|max + |a| + (n + 1)(s_max + |b|)
         const double np1 = (double)(n + 1);
         const double B = A.b0 + np1 * A.s_step;
-        const double thr = 4.0 * np1 * (A.eps + 0x1p-51 * B);
+        const double thr = 4.0 * np1 * (A.eps + 0x1.8p-51 * B);
+        const double ab = A.a - A.b;      // off-diagonal minus diagonal log transition
+        const double t2 = -ab - thr;
 
         double nu[K];
-        bool seqflag = false;   // an observation the table cannot score: the whole sequence goes to the exact kernel
+        uint64_t seqflag = 0;   // lanes with an observation the table cannot score: the whole sequence goes to the exact kernel
         // Scores of one observation from the table, in two stages so that the LDS round trips of several genes
         // overlap: locate() finds the interval (lookup cell -> segment record -> interval index) and the position
         // inside it; poly() evaluates the K polynomials.
         constexpr int REC = rec_doubles(K);
         auto locate = [&](double xv, int &idx, double &tn) {
-            const bool ok = (xv >= A.x_lo) && (xv <= A.x_hi);   // false for NaN
-            seqflag |= !ok;
-            const double xs = ok ? xv : A.x_lo;
+            // clamp into the table's domain; an observation the clamp changes (NaN included) flags its sequence
+            const double xs = max_raw_s(min_raw_s(xv, A.x_hi), A.x_lo);
+            seqflag |= __builtin_amdgcn_ballot_w64(!(xs == xv));
             // segment (which state means lie below xs) from the lookup cells: at most one mean per cell
             int ci = (int)((xs - A.cell_lo) * A.inv_wc);
             ci = ci > A.n_cells_m1 ? A.n_cells_m1 : ci;
@@ -144,7 +179,7 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             int fi = (int)u;
             fi = fi > sn.y ? sn.y : fi;
             tn = (u - (double)fi) - 0.5;
-            idx = (sn.x + fi) * REC;
+            idx = (int)__umul24((uint32_t)(sn.x + fi), (uint32_t)REC);   // interval numbers are far below 2^24
         };
         auto poly = [&](int idx, double tn, double (&sc)[K]) {
             const double *c = coef + idx;
@@ -165,41 +200,49 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
                 sc[k] = __builtin_fma(p, tn, c01.x);
             }
         };
-        // One step of the recurrence.  Back-pointer word: bits 0..K-1 "row k keeps itself", bits 6..8 the best
-        // predecessor overall (i1), bits 9..9+K-1 "row k's decision lies inside the error band".  Row k's decision
-        // is certain when |diag - off| > thr and -- if the off-diagonal candidate wins -- the best predecessor
-        // leads the second best by more than thr as well.
+        // One step of the recurrence, on nu~_i = nu_i - i b (a shift common to all states: every decision and the
+        // final arg-max are those of nu): nu~'_k = max(nu~_k, m1 + (a - b)) + s_k, m1 = max_j nu~_j.  Row k keeps itself
+        // iff e_k = nu~_k - (m1 + (a - b)) >= 0.  Back-pointer word: bits 0..K-1 "row k does NOT keep itself" (the
+        // sign bits of e_k, shifted in one v_alignbit each), bits 6..8 the best predecessor overall (i1), bits
+        // 9..9+K-1 "row k's decision lies inside the error band".  Row k's decision is certain when |e_k| > thr and --
+        // if the off-diagonal candidate wins -- the best predecessor leads the second best by more than thr as well
+        // (exactly one state has nu~_k >= m1 - thr, i.e. e_k >= -(a - b) - thr).  The comparisons leave wave masks;
+        // their combination is scalar work.
         auto step = [&](const double (&sc)[K]) -> uint32_t {
-            double m1 = nu[0], m2 = -__builtin_inf();
-            uint32_t i1 = 0;
+            double m1 = nu[0];
 #pragma unroll
-            for (int k = 1; k < K; ++k) {
-                const double v = nu[k];
-                m2 = max_raw(m2, min_raw(m1, v));
-                i1 = (v > m1) ? (uint32_t)k : i1;
-                m1 = max_raw(m1, v);
-            }
-            const bool top_unsure = !(m1 - m2 > thr);
-            bool any = top_unsure;
-            const double off = m1 + A.a;
-            uint32_t word = i1 << 6;
-            double d[K];
+            for (int k = 1; k < K; ++k) m1 = max_raw(m1, nu[k]);
+            const double c = m1 + ab;
+            uint32_t sb = 0, i1 = 0;   // i1: the one state near the top (when there are two, the rows that need it are flagged)
+            uint64_t band = 0;
+            double e[K];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
+            for (int k = K - 1; k >= 0; --k) {
 #if ICNV_VF_EXP & 4
-                nu[k] += sc[k]; d[k] = 0.0; continue;
+                nu[k] += sc[k]; e[k] = 0.0; continue;
 #endif
-                d[k] = nu[k] + A.b;
-                any |= !(__builtin_fabs(d[k] - off) > thr);
-                word |= (d[k] >= off) ? (1u << k) : 0u;
-                nu[k] = max_raw(d[k], off) + sc[k];
+                e[k] = nu[k] - c;
+                sb = __builtin_amdgcn_alignbit(sb, (uint32_t)__double2hiint(e[k]), 31);   // (sb << 1) | sign(e_k)
+                band |= __builtin_amdgcn_ballot_w64(!(__builtin_fabs(e[k]) > thr));
+                nu[k] = max_raw(nu[k], c) + sc[k];
             }
+            static_assert(K == 3 || K == 6, "near_top3 blocks");
+            uint64_t n0, n1, n2;
+            near_top3<K - 1>(e[K - 1], e[K - 2], e[K - 3], t2, i1, n0, n1, n2);
+            uint64_t two_near = (n0 & n1) | ((n0 | n1) & n2);
+            if (K == 6) {
+                const uint64_t seen = n0 | n1 | n2;
+                near_top3<2>(e[2], e[1], e[0], t2, i1, n0, n1, n2);
+                two_near |= (seen & (n0 | n1 | n2)) | (n0 & n1) | ((n0 | n1) & n2);
+            }
+            uint32_t word = sb | (i1 << 6);
             // the "inside the band" bits are needed by almost no gene: one scalar branch for the whole wavefront
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) != 0, 0)) {
+            if (__builtin_expect((band | two_near) != 0, 0)) {
                 asm volatile("; uncertain decision in this wavefront" ::: "memory");   // keeps the block a real branch
+                const bool top_unsure = (two_near >> lane) & 1u;
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const bool unsure = !(__builtin_fabs(d[k] - off) > thr) || (!(d[k] >= off) && top_unsure);
+                    const bool unsure = !(__builtin_fabs(e[k]) > thr) || (!(e[k] >= 0.0) && top_unsure);
                     word |= unsure ? (512u << k) : 0u;
                 }
             }
@@ -321,7 +364,7 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         }
         // the traceback follows the decisions of ONE path: only an uncertain decision ON that path (or an
         // uncertain final arg-max) can make the exact arithmetic trace a different one
-        uint32_t unsure = (seqflag || !(m1 - m2 > thr)) ? 1u : 0u;
+        uint32_t unsure = (((seqflag >> lane) & 1u) || !(m1 - m2 > thr)) ? 1u : 0u;
         const int64_t nc = A.ncols;
 #if ICNV_VF_EXP & 1
         if (m1 == 12345.678) 
@@ -339,7 +382,7 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             auto step_bp = [&](uint32_t w, int c) {
                 const uint32_t tsh = w >> c;
                 uacc |= tsh;
-                return (tsh & 1u) ? c : (int)((w >> 6) & 7u);
+                return (tsh & 1u) ? (int)((w >> 6) & 7u) : c;
             };
             const int a0 = (int)((uintptr_t)st & 7u);
             const int a0u = __builtin_amdgcn_readfirstlane(a0);
