@@ -181,9 +181,12 @@ int icnv_viterbi_cells_dev(const double *expr, uint8_t *states, int64_t G, int64
  *                           the last column batch, table intervals}; synchronises with the last call
  *   icnv_hmm_emission_table host-only: the table for (K, mean, sd); meta8 = {n_intervals, x_lo, x_hi, eps_tab,
  *                           s_max, degree, n_segments, eps_spec}; seg_out [n_seg*4] = {lo, 1/width, base, n-1};
- *                           coef_out [n_intervals*K*(degree+1)] (nullable)
+ *                           coef_out [n_intervals*K*(degree+1)] (nullable; polynomials of s_k - s_1, row k = 0 zero);
+ *                           eps_tab bounds |table - (s_k - s_1)|, s_max bounds |s_k| and |s_k - s_1|
  *   icnv_hmm_emission_scores host-only: which = 0 the exact scores of R/inferCNV_HMM.R:1129-1133 in 80-bit
- *                           arithmetic, which = 1 the table's scores through the kernel's double operations
+ *                           arithmetic, which = 1 the table's values through the kernel's double operations: the
+ *                           scores RELATIVE TO STATE 1, s_k - s_1 (column 0 is 0; a term common to all states
+ *                           changes no decision of the recurrence, so the table does not carry it)
  *                           (ok_out[i] = 0 and NaN where x[i] is outside the table's domain); out [n*K] */
 int icnv_viterbi_set_mode(int mode);
 int icnv_viterbi_last_stats(int64_t *out4);

@@ -992,7 +992,7 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
         fa.cell_lo = g_fast.tab.cell_lo;
         fa.inv_wc = g_fast.tab.inv_wc;
         fa.n_cells_m1 = g_fast.tab.n_cells - 1;
-        fa.eps = g_fast.tab.eps_tab + EPS_SPEC;
+        fa.eps = g_fast.tab.eps_tab + 2.0 * EPS_SPEC;   // table: s_k - s_1; the exact kernel's difference carries two of its errors
         fa.b0 = dmax + std::fabs(a);
         fa.s_step = g_fast.tab.s_max + std::fabs(b);
         fa.bp = d_bp.as<uint16_t>();

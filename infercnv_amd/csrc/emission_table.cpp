@@ -78,7 +78,8 @@ bool emission_table_eval(const EmisTable &t, const double *mean, double x, doubl
     if (fi < 0) fi = 0;
     const double tn = (u - (double)fi) - 0.5;
     const double *c = t.coef.data() + (size_t)(sg.base + fi) * t.K * NC;
-    for (int k = 0; k < t.K; ++k) {
+    s_out[0] = 0.0;   // the table holds the scores relative to state 1
+    for (int k = 1; k < t.K; ++k) {
         double p = c[k * NC + EMIS_DEG];
         for (int j = EMIS_DEG - 1; j >= 0; --j) p = std::fma(p, tn, c[k * NC + j]);
         s_out[k] = p;
@@ -189,8 +190,8 @@ int build_emission_table(int K, const double *mean, double sd, int max_intervals
             for (int k = 0; k < K; ++k)
                 for (int j = 0; j < NC; ++j) {
                     long double acc = 0.0L;
-                    for (int i = 0; i < NC; ++i) acc += nodes.vinv[j][i] * val[i][k];
-                    c[k * NC + j] = (double)acc;
+                    for (int i = 0; i < NC; ++i) acc += nodes.vinv[j][i] * (val[i][k] - val[i][0]);
+                    c[k * NC + j] = (double)acc;   // state 1's own row is all zeros
                 }
         }
     }
@@ -212,9 +213,11 @@ int build_emission_table(int K, const double *mean, double sd, int max_intervals
                 if (!emission_table_eval(out, mean, x, got)) { *why = "internal: check point outside the domain"; return 2; }
                 exact_ld(K, mean, sd, (long double)x, want);
                 for (int k = 0; k < K; ++k) {
-                    const long double e = fabsl((long double)got[k] - want[k]);
+                    const long double d = want[k] - want[0];
+                    const long double e = fabsl((long double)got[k] - d);
                     if (e > max_err) max_err = e;
                     if (fabsl(want[k]) > s_max) s_max = fabsl(want[k]);
+                    if (fabsl(d) > s_max) s_max = fabsl(d);
                 }
             }
         }

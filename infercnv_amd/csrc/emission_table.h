@@ -3,9 +3,11 @@
 // The reference's emission scores (R/inferCNV_HMM.R:1129-1133, 1156-1160)
 //     lp_k = log P(Z > |x - mean_k| / sd),  e_k = 1 / (-lp_k),  s_k = log(e_k / sum_j e_j)
 // are K smooth functions of the single observation x between consecutive state means (|x - mean_k|
-// kinks at every mean).  The table holds, for every interval of a partition of [x_lo, x_hi] whose
-// cut points include the means, one degree-DEG polynomial per state in the normalised position
-// tn in [-0.5, 0.5] inside the interval.  It is built on the host in 80-bit long double from the
+// kinks at every mean).  Only the differences between the states' scores enter the decisions of the
+// max-plus recurrence (a term common to all states shifts every candidate alike), so the table holds
+//     d_k(x) = s_k(x) - s_1(x) = log e_k - log e_1,   k = 2..K     (d_1 = 0 is not stored on the device)
+// for every interval of a partition of [x_lo, x_hi] whose cut points include the means: one
+// degree-DEG polynomial per state in the normalised position tn in [-0.5, 0.5] inside the interval.  It is built on the host in 80-bit long double from the
 // mathematically exact functions (erfcl / logl) and verified against them through the very double
 // operations the kernel executes; eps_tab is the certified bound the kernel's margin test uses.
 //
@@ -44,14 +46,14 @@ struct EmisTable {
     int n_seg = 0;                   // K + 1
     int n_int = 0;                   // total intervals
     double x_lo = 0, x_hi = 0;       // covered domain; observations outside take the exact path
-    double eps_tab = 0;              // certified bound on |table score - exact score| over the domain
-    double s_max = 0;                // max |score| over the domain (bounds the magnitude of the DP values)
+    double eps_tab = 0;              // certified bound on |table value - (s_k - s_1)| over the domain
+    double s_max = 0;                // max over the domain of |s_k| and |s_k - s_1| (bounds the magnitude of the DP values of both kernels)
     double width_sigma = 0;          // target interval width in units of sd
     EmisSegment seg[EMIS_MAX_SEG];
     double cell_lo = 0, inv_wc = 0;  // cell index = (int)((x - cell_lo) * inv_wc), clamped to n_cells - 1
     int n_cells = 0;
     EmisCell cell[EMIS_MAX_CELLS];
-    std::vector<double> coef;        // [n_int][K][EMIS_DEG + 1], c0 first
+    std::vector<double> coef;        // [n_int][K][EMIS_DEG + 1], c0 first; row k = 0 (state 1) is zero
 };
 
 // Build the table for K states with strictly increasing means and a shared sd.  max_intervals is the
@@ -64,7 +66,8 @@ int build_emission_table(int K, const double *mean, double sd, int max_intervals
 void emission_scores_exact(int K, const double *mean, double sd, double x, double *s_out);
 
 // The kernel's evaluation of the table restated on the host with the same double operations
-// (explicit fma, same order).  Returns false when x is outside the domain / not finite.
+// (explicit fma, same order): s_out[k] = d_k(x), s_out[0] = 0.  Returns false when x is outside the
+// domain / not finite.
 bool emission_table_eval(const EmisTable &t, const double *mean, double x, double *s_out);
 
 }  // namespace icnv

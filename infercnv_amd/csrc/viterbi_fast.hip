@@ -4,10 +4,11 @@
 // the reference's emission arithmetic (K x [Cody's pnorm + log + two divisions + log]).  Its OUTPUT
 // is discrete: the arg-max decisions of the max-plus recurrence.  This kernel computes the same
 // decisions from scores that are within a CERTIFIED distance eps of the exact kernel's scores
-//   - emission scores: K polynomials per observation from the table of emission_table.{h,cpp}
-//     (built in 80-bit arithmetic from the exact functions, verified through these very double
-//     operations; eps_tab), plus the distance of the exact kernel's own arithmetic from the exact
-//     functions (eps_spec);
+//   - emission scores relative to state 1 (a term common to all states changes no decision): K - 1
+//     polynomials per observation from the table of emission_table.{h,cpp} (built in 80-bit arithmetic
+//     from the exact functions, verified through these very double operations; eps_tab), plus twice the
+//     distance of the exact kernel's own arithmetic from the exact functions (2 eps_spec: a difference
+//     of two of its scores);
 //   - the recurrence on nu_i - i b (the diagonal log transition b is a shift common to all states, so it is
 //     dropped: one add, max, add per state; two roundings and the rounding of a - b per step, against the
 //     exact kernel's two),
@@ -70,9 +71,10 @@ constexpr int FAST_NT = ICNV_VF_NT;
 constexpr int NCF = EMIS_DEG + 1;
 constexpr int SEG_DOUBLES = EMIS_MAX_SEG * 4 + EMIS_MAX_CELLS * 2;   // segment records + lookup cells at the start of the LDS image
 constexpr int CELL_OFF = EMIS_MAX_SEG * 4;
-// coefficient record of one interval: K x 6 doubles padded to an ODD number of 16-byte bank groups (the lanes'
-// random intervals then spread over all LDS banks) -- the K states sit at immediate offsets of one address
-constexpr int rec_doubles(int K) { return ((K * NCF / 2) | 1) * 2; }
+// coefficient record of one interval: (K - 1) x 6 doubles (scores relative to state 1, whose row is not stored)
+// padded to an ODD number of 16-byte bank groups (the lanes' random intervals then spread over all LDS banks) --
+// the states sit at immediate offsets of one address
+constexpr int rec_doubles(int K) { return (((K - 1) * NCF / 2) | 1) * 2; }
 typedef double dbl2_t __attribute__((ext_vector_type(2)));
 
 // v_min_f64 / v_max_f64 without the compiler's canonicalisation of both inputs (every operand here is the
@@ -150,7 +152,9 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             if (n == 1) st[0] = 3;
             continue;
         }
-        uint16_t *bpc = A.bp + (int64_t)s0 * A.ncols + col;
+        // back-pointers of this task: n rows of 64 lanes, contiguous (one 128-byte line per gene and wavefront, the
+        // rows of a task next to each other in memory -- the forward pass writes and the traceback reads a stream)
+        uint16_t *bpc = A.bp + ((int64_t)s0 * (ncg * 64) + (task % ncg) * 64 * (int64_t)n + lane);
             // decision band of this task: 4 (n + 1) (eps + 6 u B), B = |logDelta|max + |a| + (n + 1)(s_max + |b|)
         const double np1 = (double)(n + 1);
         const double B = A.b0 + np1 * A.s_step;
@@ -183,15 +187,16 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         };
         auto poly = [&](int idx, double tn, double (&sc)[K]) {
             const double *c = coef + idx;
+            sc[0] = 0.0;   // the table holds s_k - s_1: a term common to all states changes no decision
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
+            for (int k = 1; k < K; ++k) {
 #if ICNV_VF_EXP & 16
                 const double2 c01 = make_double2(tn + k, tn * 2), c23 = make_double2(tn + 3, tn + 4 * k), c45 = make_double2(0.1 * tn, tn + 7);
                 (void)c;
 #else
-                const double2 c01 = *reinterpret_cast<const double2 *>(c + k * NCF);
-                const double2 c23 = *reinterpret_cast<const double2 *>(c + k * NCF + 2);
-                const double2 c45 = *reinterpret_cast<const double2 *>(c + k * NCF + 4);
+                const double2 c01 = *reinterpret_cast<const double2 *>(c + (k - 1) * NCF);
+                const double2 c23 = *reinterpret_cast<const double2 *>(c + (k - 1) * NCF + 2);
+                const double2 c45 = *reinterpret_cast<const double2 *>(c + (k - 1) * NCF + 4);
 #endif
                 double p = __builtin_fma(c45.y, tn, c45.x);
                 p = __builtin_fma(p, tn, c23.y);
@@ -224,7 +229,8 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
                 e[k] = nu[k] - c;
                 sb = __builtin_amdgcn_alignbit(sb, (uint32_t)__double2hiint(e[k]), 31);   // (sb << 1) | sign(e_k)
                 band |= __builtin_amdgcn_ballot_w64(!(__builtin_fabs(e[k]) > thr));
-                nu[k] = max_raw(nu[k], c) + sc[k];
+                nu[k] = max_raw(nu[k], c);
+                if (k > 0) nu[k] += sc[k];
             }
             static_assert(K == 3 || K == 6, "near_top3 blocks");
             uint64_t n0, n1, n2;
@@ -258,9 +264,9 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             if (word == 0xdeadbeefu)
 #endif
 #if ICNV_VF_POLICY & 2
-            __builtin_nontemporal_store((uint16_t)word, bpc + (int64_t)i * A.ncols);
+            __builtin_nontemporal_store((uint16_t)word, bpc + i * 64);
 #else
-            bpc[(int64_t)i * A.ncols] = (uint16_t)word;
+            bpc[i * 64] = (uint16_t)word;
 #endif
 #if ICNV_VF_SB
             __builtin_amdgcn_sched_barrier(0);   // one gene at a time: interleaving the unrolled genes only spills
@@ -332,7 +338,7 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
                         poly(idx1, tn1, scn);
                     }
                     const uint32_t word = step(sc);
-                    bpc[(int64_t)(i + j) * A.ncols] = (uint16_t)word;
+                    bpc[(i + j) * 64] = (uint16_t)word;
                     if (have) {
 #pragma unroll
                         for (int k = 0; k < K; ++k) sc[k] = scn[k];
@@ -365,7 +371,6 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         // the traceback follows the decisions of ONE path: only an uncertain decision ON that path (or an
         // uncertain final arg-max) can make the exact arithmetic trace a different one
         uint32_t unsure = (((seqflag >> lane) & 1u) || !(m1 - m2 > thr)) ? 1u : 0u;
-        const int64_t nc = A.ncols;
 #if ICNV_VF_EXP & 1
         if (m1 == 12345.678) 
 #endif
@@ -374,9 +379,9 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             uint32_t uacc = 0;
             auto load_bp = [&](int i) {
 #if ICNV_VF_POLICY & 2
-                return (uint32_t)__builtin_nontemporal_load(bpc + (int64_t)i * nc);
+                return (uint32_t)__builtin_nontemporal_load(bpc + i * 64);
 #else
-                return (uint32_t)bpc[(int64_t)i * nc];
+                return (uint32_t)bpc[i * 64];
 #endif
             };
             auto step_bp = [&](uint32_t w, int c) {
@@ -384,7 +389,7 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
                 uacc |= tsh;
                 return (tsh & 1u) ? (int)((w >> 6) & 7u) : c;
             };
-            const int a0 = (int)((uintptr_t)st & 7u);
+            const int a0 = (int)((uintptr_t)st & 15u);
             const int a0u = __builtin_amdgcn_readfirstlane(a0);
             if (__builtin_amdgcn_ballot_w64(a0 != a0u) == 0) viterbi_traceback_uniform(st, n, cur, a0u, load_bp, step_bp);
             else viterbi_traceback<ICNV_VF_TG>(st, n, cur, load_bp, step_bp);
@@ -400,7 +405,9 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
 
 }  // namespace
 
-size_t viterbi_fast_scratch_bytes(int32_t G, int64_t n_cols) { return (size_t)G * (size_t)n_cols * sizeof(uint16_t); }
+size_t viterbi_fast_scratch_bytes(int32_t G, int64_t n_cols) {   // columns in blocks of 64
+    return (size_t)G * (size_t)((n_cols + 63) / 64 * 64) * sizeof(uint16_t);
+}
 size_t viterbi_fast_lds_bytes(int K, int n_int) { return ((size_t)SEG_DOUBLES + (size_t)n_int * rec_doubles(K)) * sizeof(double); }
 int viterbi_fast_max_intervals(int K) {
     // leave 8 KiB of the 160 KiB for the runtime; 16-B granularity
@@ -424,9 +431,9 @@ void viterbi_fast_table_image(const EmisTable &t, std::vector<double> &img) {
     const int rec = rec_doubles(t.K);
     img.resize(SEG_DOUBLES + (size_t)t.n_int * rec, 0.0);
     for (int i = 0; i < t.n_int; ++i)
-        for (int k = 0; k < t.K; ++k)
+        for (int k = 1; k < t.K; ++k)
             for (int j = 0; j < NCF; ++j)
-                img[SEG_DOUBLES + (size_t)i * rec + k * NCF + j] = t.coef[((size_t)i * t.K + k) * NCF + j];
+                img[SEG_DOUBLES + (size_t)i * rec + (k - 1) * NCF + j] = t.coef[((size_t)i * t.K + k) * NCF + j];
     if (img.size() & 1) img.push_back(0.0);   // the kernel copies 16 bytes at a time
 }
 

@@ -50,47 +50,54 @@ __device__ inline void viterbi_traceback(uint8_t *st, int n, int cur, Load load,
     }
 }
 
-// The same walk when every lane's state column has the SAME byte alignment a0 = address & 7 (always the case when
-// the number of genes per column is a multiple of 8): the position of a gene inside its 8-byte output word is then
-// wave-uniform, so a whole word is assembled with immediate shifts (one v_lshl_or per gene, +1 per byte added once
-// per dword) and stored without per-gene alignment tests -- about 8 vector instructions per gene instead of 20.
-// Genes in the partial words at either end of the sequence, and gene 0's group, are written byte by byte.
+// The same walk when every lane's state column has the SAME byte alignment a0 = address & 15 (always the case when
+// the number of genes per column is a multiple of 16): the position of a gene inside its 16-byte output word is then
+// wave-uniform, so a block of 32 genes is assembled with immediate shifts (one v_lshl_or per gene, +1 per byte added
+// once per dword) and stored as two aligned 16-byte stores without per-gene alignment tests -- about 8 vector
+// instructions per gene instead of 20.  The back-pointer words of the NEXT
+// block of 32 genes are requested before the current block is walked (their addresses do not depend on the traced
+// state): 32 lines in flight per wavefront instead of one exposed latency per word.
+// Genes in the partial blocks at either end of the sequence, and gene 0's group, are written byte by byte.
 template <class Load, class Step>
 __device__ inline void viterbi_traceback_uniform(uint8_t *st, int n, int cur, int a0, Load load, Step step) {
+    constexpr int TB = 32;
     int g = n - 1;
-    while (g >= 0 && ((a0 + g) & 7) != 7) {   // top partial word
+    while (g >= 0 && ((a0 + g) & 15) != 15) {   // top partial word
         st[g] = (uint8_t)(cur + 1);
         if (g > 0) cur = step(load(g), cur);
         --g;
     }
-    uint32_t Wn[8];
-    if (g >= 8) {
+    uint32_t Wn[TB];
+    if (g >= TB) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Wn[j] = load(g - j);
+        for (int j = 0; j < TB; ++j) Wn[j] = load(g - j);
     }
-    while (g >= 8) {   // genes g .. g-7 fill one aligned word, all of them have a predecessor
-        uint32_t W[8];
+    while (g >= TB) {   // genes g .. g-31 fill one aligned block, all of them have a predecessor
+        uint32_t W[TB];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) W[j] = Wn[j];
-        if (g - 8 >= 8) {
+        for (int j = 0; j < TB; ++j) W[j] = Wn[j];
+        if (g - TB >= TB) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) Wn[j] = load(g - 8 - j);   // the next word's back-pointers, a word ahead
+            for (int j = 0; j < TB; ++j) Wn[j] = load(g - TB - j);   // the next block's back-pointers, a block ahead
         }
-        uint32_t lo = 0, hi = 0;
+        uint32_t d[TB / 4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int byte = 7 - j;
-            if (byte >= 4) hi |= (uint32_t)cur << (8 * (byte - 4));
-            else lo |= (uint32_t)cur << (8 * byte);
+        for (int q = 0; q < TB / 4; ++q) d[q] = 0;
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int byte = TB - 1 - j;
+            d[byte >> 2] |= (uint32_t)cur << (8 * (byte & 3));
             cur = step(W[j], cur);
         }
-        uint2 v;
-        v.x = lo + 0x01010101u;
-        v.y = hi + 0x01010101u;
-        *reinterpret_cast<uint2 *>(st + g - 7) = v;
-        g -= 8;
+        uint4 v0, v1;
+        v0.x = d[0] + 0x01010101u; v0.y = d[1] + 0x01010101u; v0.z = d[2] + 0x01010101u; v0.w = d[3] + 0x01010101u;
+        v1.x = d[4] + 0x01010101u; v1.y = d[5] + 0x01010101u; v1.z = d[6] + 0x01010101u; v1.w = d[7] + 0x01010101u;
+        uint4 *dst = reinterpret_cast<uint4 *>(st + g - (TB - 1));
+        dst[0] = v0;
+        dst[1] = v1;
+        g -= TB;
     }
-    while (g >= 0) {   // bottom partial word and gene 0's group
+    while (g >= 0) {   // bottom partial block and gene 0's group
         st[g] = (uint8_t)(cur + 1);
         if (g > 0) cur = step(load(g), cur);
         --g;
