@@ -55,6 +55,9 @@ namespace {
 #ifndef ICNV_VF_TG
 #define ICNV_VF_TG 32   // traceback group: 2 x 32 back-pointer lines in flight per wavefront
 #endif
+#ifndef ICNV_VF_TB
+#define ICNV_VF_TB 16   // genes per block of the uniform-alignment traceback (= back-pointer lines in flight); 16: 2.54 ms, 32: 2.58, 64: 2.61
+#endif
 #ifndef ICNV_VF_SB
 #define ICNV_VF_SB 1
 #endif
@@ -391,7 +394,7 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             };
             const int a0 = (int)((uintptr_t)st & 15u);
             const int a0u = __builtin_amdgcn_readfirstlane(a0);
-            if (__builtin_amdgcn_ballot_w64(a0 != a0u) == 0) viterbi_traceback_uniform(st, n, cur, a0u, load_bp, step_bp);
+            if (__builtin_amdgcn_ballot_w64(a0 != a0u) == 0) viterbi_traceback_uniform<ICNV_VF_TB>(st, n, cur, a0u, load_bp, step_bp);
             else viterbi_traceback<ICNV_VF_TG>(st, n, cur, load_bp, step_bp);
             unsure |= (uacc >> 9) & 1u;
         }

@@ -58,9 +58,9 @@ __device__ inline void viterbi_traceback(uint8_t *st, int n, int cur, Load load,
 // block of 32 genes are requested before the current block is walked (their addresses do not depend on the traced
 // state): 32 lines in flight per wavefront instead of one exposed latency per word.
 // Genes in the partial blocks at either end of the sequence, and gene 0's group, are written byte by byte.
-template <class Load, class Step>
+template <int TB, class Load, class Step>
 __device__ inline void viterbi_traceback_uniform(uint8_t *st, int n, int cur, int a0, Load load, Step step) {
-    constexpr int TB = 32;
+    static_assert(TB % 16 == 0, "whole 16-byte words");
     int g = n - 1;
     while (g >= 0 && ((a0 + g) & 15) != 15) {   // top partial word
         st[g] = (uint8_t)(cur + 1);
@@ -89,12 +89,14 @@ __device__ inline void viterbi_traceback_uniform(uint8_t *st, int n, int cur, in
             d[byte >> 2] |= (uint32_t)cur << (8 * (byte & 3));
             cur = step(W[j], cur);
         }
-        uint4 v0, v1;
-        v0.x = d[0] + 0x01010101u; v0.y = d[1] + 0x01010101u; v0.z = d[2] + 0x01010101u; v0.w = d[3] + 0x01010101u;
-        v1.x = d[4] + 0x01010101u; v1.y = d[5] + 0x01010101u; v1.z = d[6] + 0x01010101u; v1.w = d[7] + 0x01010101u;
         uint4 *dst = reinterpret_cast<uint4 *>(st + g - (TB - 1));
-        dst[0] = v0;
-        dst[1] = v1;
+#pragma unroll
+        for (int q = 0; q < TB / 16; ++q) {
+            uint4 v;
+            v.x = d[4 * q] + 0x01010101u; v.y = d[4 * q + 1] + 0x01010101u;
+            v.z = d[4 * q + 2] + 0x01010101u; v.w = d[4 * q + 3] + 0x01010101u;
+            dst[q] = v;
+        }
         g -= TB;
     }
     while (g >= 0) {   // bottom partial block and gene 0's group

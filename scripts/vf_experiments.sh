@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R/infercnv_amd/csrc
 mkdir -p exp_obj
 if [ "$1" = build ]; then
   for e in ${EXPS:-1 2 3 4 8 16 32 48 63}; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $(echo $e | sed 's/^/-DICNV_VF_EXP=/; s/_nt/ -DICNV_VF_NT=/; s/_ch/ -DICNV_VF_CH=/; s/_pol/ -DICNV_VF_POLICY=/; s/_sb/ -DICNV_VF_SB=/; s/_tg/ -DICNV_VF_TG=/; s/_pipe/ -DICNV_VF_PIPE=/') -c viterbi_fast.hip -o exp_obj/vf_$e.o &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $(echo $e | sed 's/^/-DICNV_VF_EXP=/; s/_nt/ -DICNV_VF_NT=/; s/_ch/ -DICNV_VF_CH=/; s/_pol/ -DICNV_VF_POLICY=/; s/_sb/ -DICNV_VF_SB=/; s/_tg/ -DICNV_VF_TG=/; s/_pipe/ -DICNV_VF_PIPE=/; s/_tb/ -DICNV_VF_TB=/') -c viterbi_fast.hip -o exp_obj/vf_$e.o &
   done; wait
   for e in ${EXPS:-1 2 3 4 8 16 32 48 63}; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libicnv_exp_$e.so api.o chain_kernels.o chain_m7.o chain_m15.o chain_m23.o chain_l35.o chain_large.o viterbi_kernels.o exp_obj/vf_$e.o emission_table.o median_kernels.o stats_kernels.o distance_kernels.o
