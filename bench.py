@@ -181,8 +181,9 @@ def main():
         if "viterbi" in roof:
             st = device.viterbi_last_stats()
             roof["viterbi"]["note"] = (f"certified fast path ({st['path']}; {st['flagged']} of {st['sequences']} sequences redone exactly): "
-                                       "table-driven emission scores + max-plus recurrence, about 123 fp64 vector instructions and "
-                                       "20 LDS gathers per gene and wavefront; VALU/LDS-bound, no MFMA-shaped work")
+                                       "table-driven emission scores + max-plus recurrence, about 91 fp64/integer vector instructions and "
+                                       "18 LDS gathers per gene and wavefront, every lane streaming its own column; "
+                                       "issue/LDS/latency-bound, no MFMA-shaped work")
         dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
         traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(traffic_file) and G == 10000 and C_local == 50000:   # counters were collected on this shape
