@@ -951,7 +951,12 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
                                    n_underflow_dev, "viterbi", s);
     }
     const int64_t bp_elem = fast ? 2 : 4;
-    int64_t batch = ((int64_t)4 << 30) / ((int64_t)G * bp_elem);
+    int64_t scratch_budget = (int64_t)4 << 30;   // back-pointer scratch per column batch
+    if (const char *e = std::getenv("ICNV_VITERBI_SCRATCH_MB")) {   // developer switch: small batches for the tests
+        const long v = std::atol(e);
+        if (v > 0) scratch_budget = (int64_t)v << 20;
+    }
+    int64_t batch = scratch_budget / ((int64_t)G * bp_elem);
     batch = std::max<int64_t>(64, (batch / 64) * 64);
     batch = std::min(batch, ((ncols + 63) / 64) * 64);
     if ((rc = d_bp.alloc((size_t)G * (size_t)batch * (size_t)bp_elem))) return rc;

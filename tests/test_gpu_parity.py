@@ -342,6 +342,32 @@ def test_viterbi_fast_path_random_models(dev, seed):
     np.testing.assert_array_equal(st_fast.cpu().numpy().T[:, pick], want)
 
 
+def test_viterbi_column_batches(dev, monkeypatch):
+    """The back-pointer scratch bounds the columns of one launch (4 GiB by default: 214 000 cells at 10 000 genes);
+    more cells run as several column batches.  A 1 MiB budget splits 700 cells x 1 500 genes into batches of 320 (fast
+    path, 2-byte back-pointers) / 128 (exact kernel, 4-byte) columns; every batch, the partial last one and the
+    foreign values that send sequences of different batches to the redo kernel must give the single-launch states."""
+    from infercnv_amd import synth
+    pre, cs = _hmm_input(1500, 700, seed=9)
+    pre[37, 5] = np.nan                  # a flagged sequence in the first batch ...
+    pre[900, 650] = 1e9                  # ... and one in the last
+    means, sd, logPi, logDelta = synth.hmm_params_i6()
+    xd = to_dev(pre)
+    ref, bad_ref = dev.viterbi_cells(xd, cs, means, sd, logPi, logDelta)
+    assert dev.viterbi_last_stats()["path"] == "fast"
+    want, wbad = oc.viterbi_cells(pre, cs, means, sd, logPi, logDelta)
+    np.testing.assert_array_equal(to_host(ref), want)
+    monkeypatch.setenv("ICNV_VITERBI_SCRATCH_MB", "1")
+    try:
+        for mode in (0, 1):
+            dev.viterbi_set_mode(mode)
+            st, bad = dev.viterbi_cells(xd, cs, means, sd, logPi, logDelta)
+            assert dev.viterbi_last_stats()["path"] == ("fast" if mode == 0 else "exact")
+            assert torch.equal(st, ref) and int(bad.item()) == int(bad_ref.item()) == wbad
+    finally:
+        dev.viterbi_set_mode(0)
+
+
 def test_viterbi_adversarial_near_ties_bit_exact(dev):
     """Inputs sitting on emission-branch boundaries and state mid-points, 1-gene and 2-gene chromosomes."""
     from infercnv_amd import synth
