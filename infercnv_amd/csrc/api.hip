@@ -1338,16 +1338,31 @@ int icnv_median_filter_dev(const double *expr_in, double *expr_out, int64_t G, i
     ICNV_HIP(hipMemcpyAsync(expr_out, expr_in, (size_t)G * C * sizeof(double), hipMemcpyDeviceToDevice, s));
     if (n_tiles == 0) return ICNV_OK;
     std::vector<int32_t> blk_off((size_t)n_tiles + 1, 0);
+    const int cpp = median_cells_per_patch(window_size);
+    for (int t = 0; t < n_tiles; ++t) blk_off[t + 1] = blk_off[t] + (tile_off[t + 1] - tile_off[t] + cpp - 1) / cpp;
+    // patch descriptors of the 9 x 9 kernel: one 16-byte record per 32-gene block {first gene of the chromosome, its
+    // length, first gene of the block} and per cell patch {offset of the tile's cell list, its length, first cell}
+    std::vector<int32_t> gdesc, cdesc;
+    for (int k = 0; k < n_chr; ++k)
+        for (int g0 = 0; g0 < chr_start[k + 1] - chr_start[k]; g0 += MEDIAN_GENES_PER_PATCH) {
+            const int32_t r[4] = {chr_start[k], chr_start[k + 1] - chr_start[k], g0, 0};
+            gdesc.insert(gdesc.end(), r, r + 4);
+        }
     for (int t = 0; t < n_tiles; ++t)
-        blk_off[t + 1] = blk_off[t] + (tile_off[t + 1] - tile_off[t] + MEDIAN_CELLS_PER_PATCH - 1) / MEDIAN_CELLS_PER_PATCH;
-    DevBuf d_chr, d_idx, d_off, d_blk;
+        for (int c0 = 0; c0 < tile_off[t + 1] - tile_off[t]; c0 += cpp) {
+            const int32_t r[4] = {tile_off[t], tile_off[t + 1] - tile_off[t], c0, 0};
+            cdesc.insert(cdesc.end(), r, r + 4);
+        }
+    DevBuf d_chr, d_idx, d_off, d_blk, d_gd, d_cd;
+    if (!gdesc.empty() && (rc = upload(d_gd, gdesc.data(), gdesc.size(), s))) return rc;
+    if (!cdesc.empty() && (rc = upload(d_cd, cdesc.data(), cdesc.size(), s))) return rc;
     if ((rc = upload(d_chr, chr_start, (size_t)n_chr + 1, s))) return rc;
     if ((rc = upload(d_idx, tile_idx, (size_t)tile_off[n_tiles], s))) return rc;
     if ((rc = upload(d_off, tile_off, (size_t)n_tiles + 1, s))) return rc;
     if ((rc = upload(d_blk, blk_off.data(), blk_off.size(), s))) return rc;
     return launch_median_filter(expr_in, expr_out, (int32_t)G, C, d_chr.as<int32_t>(), n_chr, d_idx.as<int32_t>(),
                                 d_off.as<int32_t>(), n_tiles, d_blk.as<int32_t>(), chr_start, blk_off[n_tiles],
-                                window_size, s);
+                                window_size, d_gd.as<int32_t>(), d_cd.as<int32_t>(), s);
 }
 
 int icnv_median_filter(const double *expr_in, double *expr_out, int64_t G, int64_t C, const int32_t *chr_start,

@@ -54,8 +54,8 @@ class Net:
             vals[i], vals[j] = b, a     # pure renaming
             return
         lo, hi = self.new(), self.new()
-        self.ops.append((lo, "fmin", a, b))
-        self.ops.append((hi, "fmax", a, b))
+        self.ops.append((lo, "ICNV_FMIN", a, b))
+        self.ops.append((hi, "ICNV_FMAX", a, b))
         vals[i], vals[j] = lo, hi
 
     def merge(self, A, B):
@@ -99,10 +99,38 @@ def build_median81(pair=False):
     return net, result
 
 
+def build_shared_window():
+    """Two outputs that are neighbours along the column axis share eight of their nine sorted columns: positions
+    31..40 of the merged 72 shared values (the only ones that can be the median of 72 + 9) are computed once."""
+    net = Net()
+    cols = [[f"s[{9 * c + k}]" for k in range(9)] for c in range(8)]
+    m01, m23 = net.merge(cols[0], cols[1]), net.merge(cols[2], cols[3])
+    m45, m67 = net.merge(cols[4], cols[5]), net.merge(cols[6], cols[7])
+    AB = net.merge(net.merge(m01, m23), net.merge(m45, m67))
+    win = AB[31:41]
+    net.prune(win)
+    return net, win
+
+
+def build_window_finish():
+    """Median of the 81 = position 9 of the merge of the shared window (10 sorted values) with the output's own
+    sorted column (9 values)."""
+    net = Net()
+    fin = net.merge([f"w[{k}]" for k in range(10)], [f"p[{k}]" for k in range(9)])
+    net.prune([fin[9]])
+    return net, fin[9]
+
+
+def evaluate_env(net, env):
+    for dst, op, x, y in net.ops:
+        env[dst] = min(env[x], env[y]) if op == "ICNV_FMIN" else max(env[x], env[y])
+    return env
+
+
 def evaluate(net, result, a):
     env = {f"a[{i}]": a[i] for i in range(81)}
     for dst, op, x, y in net.ops:
-        env[dst] = min(env[x], env[y]) if op == "fmin" else max(env[x], env[y])
+        env[dst] = min(env[x], env[y]) if op == "ICNV_FMIN" else max(env[x], env[y])
     return tuple(env[r] for r in result) if isinstance(result, tuple) else env[result]
 
 
@@ -149,16 +177,43 @@ def main():
         want = sr[m // 2] if m % 2 else (sr[m // 2 - 1] + sr[m // 2]) * 0.5
         got = r40 if m % 2 else (r40 + r41) * 0.5
         assert got == want, "padded selection is wrong"
+    # shared-window pair: ten sorted columns, outputs over columns 0..8 and 1..9
+    netw, win = build_shared_window()
+    netf, resf = build_window_finish()
+    for trial in range(2000):
+        mode = trial % 3
+        if mode == 0:
+            vals = [rng.gauss(0, 1) for _ in range(90)]
+        elif mode == 1:
+            vals = [float(rng.randint(0, 4)) for _ in range(90)]
+        else:
+            vals = [float(i) for i in range(90)]
+            rng.shuffle(vals)
+        cols = [sorted(vals[9 * c:9 * c + 9]) for c in range(10)]
+        env = {f"s[{9 * c + k}]": cols[c + 1][k] for c in range(8) for k in range(9)}
+        env = evaluate_env(netw, env)
+        w = [env[x] for x in win]
+        assert w == sorted(w)
+        for own, lo in ((cols[0], 0), (cols[9], 9)):
+            e2 = {f"w[{k}]": w[k] for k in range(10)}
+            e2.update({f"p[{k}]": own[k] for k in range(9)})
+            e2 = evaluate_env(netf, e2)
+            want = sorted(vals[lo:lo + 81])[40]
+            assert e2[resf] == want, "shared-window pair network is wrong"
     n_ops = len(net.ops)
     lines = [
         "// GENERATED by gen_median_net.py -- do not edit.",
         f"// Exact median of 81 values given as nine sorted columns a[9*c + k] (k ascending): {n_ops} min/max",
         "// operations (Batcher odd-even merges 9+9, 18+18, a pruned 36+36 and a pruned 10+9).",
         "#pragma once",
+        "#ifndef ICNV_FMIN   // the including file may map these to the bare v_min_f64 / v_max_f64",
+        "#define ICNV_FMIN(a, b) fmin(a, b)",
+        "#define ICNV_FMAX(a, b) fmax(a, b)",
+        "#endif",
         "#define ICNV_SORT9(v) do { \\",
     ]
     for i, j in SORT9:
-        lines.append(f"    {{ const double lo_ = fmin(v[{i}], v[{j}]); v[{j}] = fmax(v[{i}], v[{j}]); v[{i}] = lo_; }} \\")
+        lines.append(f"    {{ const double lo_ = ICNV_FMIN(v[{i}], v[{j}]); v[{j}] = ICNV_FMAX(v[{i}], v[{j}]); v[{i}] = lo_; }} \\")
     lines.append("} while (0)")
     lines.append("")
     lines.append("__device__ inline double median81_sorted_columns(const double (&a)[81]) {")
@@ -175,10 +230,27 @@ def main():
     lines.append(f"    r40 = {result2[0]};")
     lines.append(f"    r41 = {result2[1]};")
     lines.append("}")
+    lines.append("")
+    lines.append(f"// Two outputs that are neighbours along the column axis share eight sorted columns s[9*c + k]: positions 31..40 of")
+    lines.append(f"// their merged 72 values ({len(netw.ops)} min/max, once per pair) ...")
+    lines.append("__device__ inline void median72_window(const double (&s)[72], double (&w)[10]) {")
+    for dst, op, x, y in netw.ops:
+        lines.append(f"    const double {dst} = {op}({x}, {y});")
+    for k, x in enumerate(win):
+        lines.append(f"    w[{k}] = {x};")
+    lines.append("}")
+    lines.append("")
+    lines.append(f"// ... and each output's median is position 9 of that window merged with its own sorted column ({len(netf.ops)} min/max)")
+    lines.append("__device__ inline double median_window_finish(const double (&w)[10], const double (&p)[9]) {")
+    for dst, op, x, y in netf.ops:
+        lines.append(f"    const double {dst} = {op}({x}, {y});")
+    lines.append(f"    return {resf};")
+    lines.append("}")
     here = os.path.dirname(os.path.abspath(__file__))
     with open(os.path.join(here, "median9x9_net.h"), "w") as fh:
         fh.write("\n".join(lines) + "\n")
-    print(f"median81 network: {n_ops} min/max ops; sort9: {len(SORT9)} compare-exchanges")
+    print(f"median81 network: {n_ops} min/max ops; sort9: {len(SORT9)} compare-exchanges; "
+          f"shared window: {len(netw.ops)} per pair + {len(netf.ops)} per output")
 
 
 if __name__ == "__main__":

@@ -189,7 +189,9 @@ int launch_cell_distances(const double *x, int32_t G, const int32_t *idx_dev, in
 int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, const int32_t *chr_start_dev,
                          int32_t n_chr, const int32_t *tile_idx_dev, const int32_t *tile_off_dev, int32_t n_tiles,
                          const int32_t *blk_off_dev, const int32_t *chr_start_host, int32_t total_cell_patches,
-                         int32_t window_size, hipStream_t stream);
-constexpr int MEDIAN_CELLS_PER_PATCH = 8;
+                         int32_t window_size, const int32_t *gene_block_desc_dev, const int32_t *cell_patch_desc_dev,
+                         hipStream_t stream);
+constexpr int MEDIAN_GENES_PER_PATCH = 32;
+int median_cells_per_patch(int32_t window_size);   // cells of one workgroup's output patch (the host builds the patch prefix per tile)
 
 }  // namespace icnv

@@ -1,14 +1,34 @@
 // 2-D median denoise (apply_median_filtering / .median_filter,
 // R/noise_reduction.R:43-113) for gfx950.
 //
-// A workgroup produces a 32-gene x 8-cell patch of one (tile, chromosome)
-// (interior outputs of the default window_size 7 take the sorted-column network path, see below)
-// block: the (32+2h) x (8+2h) input patch (h = half_window+1, so the effective
+// A workgroup produces a patch of 32 genes x 8 (16 for the default window) cells of one (tile, chromosome)
+// block: the (32+2h) x (cells+2h) input patch (h = half_window+1, so the effective
 // window is (window_size+2)^2, clamped at the block's edges) is gathered
-// through the tile's cell-index vector into LDS; every thread then selects the
-// median of its clamped window by a value-bounded quickselect (exact order
-// statistics; even counts average the two middle values like stats::median).
+// through the tile's cell-index vector into LDS.
+//   window_size 7 (9 x 9 windows, the default): median_filter9_kernel -- sorted columns shared through LDS,
+//     two outputs per thread that share eight of their nine columns, branch-free min/max networks;
+//   other window sizes: median_filter_kernel -- every thread selects the median of its clamped window by a
+//     value-bounded quickselect (exact order statistics; even counts average the two middle values like
+//     stats::median).
 #include "icnv_internal.h"
+
+// v_min_f64 / v_max_f64 without the compiler's canonicalisation of operands that come straight from memory (one
+// extra v_max_f64 x, x per loaded value: +13 % on the 9 x 9 networks); the instructions themselves return the
+// non-NaN operand like fmin / fmax
+__device__ static inline double icnv_mf_min(double x, double y) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ static inline double icnv_mf_max(double x, double y) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+#ifdef ICNV_MF_RAW_MINMAX   // measured: the asm statements cost the register allocator one occupancy step (3.15 vs 2.14 ms)
+#define ICNV_FMIN(a, b) icnv_mf_min(a, b)
+#define ICNV_FMAX(a, b) icnv_mf_max(a, b)
+#endif
 #include "median9x9_net.h"
 
 namespace icnv {
@@ -18,8 +38,8 @@ namespace {
 constexpr int MF_TG = 32;  // genes per patch
 constexpr int MF_TC = 8;   // cells per patch
 constexpr int MF_MAXH = 8; // supports window_size <= 15
+constexpr int MF9_TC = 16; // cells per patch of the 9 x 9 kernel: two per thread
 
-template <bool FAST9>
 __global__ void __launch_bounds__(MF_TG *MF_TC) median_filter_kernel(
     const double *__restrict__ in, double *__restrict__ out, int G, const int32_t *__restrict__ chr_start,
     const int32_t *__restrict__ tile_idx, const int32_t *__restrict__ tile_off, int n_tiles,
@@ -62,68 +82,6 @@ __global__ void __launch_bounds__(MF_TG *MF_TC) median_filter_kernel(
 
     const int tx = threadIdx.x % MF_TG, ty = threadIdx.x / MF_TG;
     const int gx = g0 + tx, cy = c0 + ty;
-    if constexpr (FAST9) {
-        // window_size 7 -> 9 x 9 windows.  Stage A: every (output gene, patch cell) pair gets its nine
-        // values along the genes sorted once (25 compare-exchanges) and shared through LDS by the nine
-        // outputs whose window contains it.  Stage B (interior outputs): the exact median of nine sorted
-        // columns by pruned odd-even merge networks (median9x9_net.h, 686 min/max, no branches).
-        double *sortedc = patch + PW * PH;                       // [PH][MF_TG][9]
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int c = ty + half * MF_TC;
-            double v[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) v[k] = patch[c * PW + tx + k];
-            ICNV_SORT9(v);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) sortedc[(c * MF_TG + tx) * 9 + k] = v[k];
-        }
-        __syncthreads();
-        if (gx >= xdim || cy >= ydim) return;
-        if (gx - 4 >= 0 && gx + 4 <= xdim - 1 && cy - 4 >= 0 && cy + 4 <= ydim - 1) {
-            double a[81];
-#pragma unroll
-            for (int c = 0; c < 9; ++c)
-#pragma unroll
-                for (int k = 0; k < 9; ++k) a[9 * c + k] = sortedc[((ty + c) * MF_TG + tx) * 9 + k];
-            out[(int64_t)idx[cy] * G + cs + gx] = median81_sorted_columns(a);
-            return;
-        }
-        // Border output: its clamped window (R/noise_reduction.R:101-106) holds m < 81 values.  The
-        // missing positions are padded with n_lo x -inf and the rest +inf so that the wanted order
-        // statistics of the real values sit at ranks 40 (and 41 for an even m) of the padded 81; the
-        // output sorts its own nine columns and runs the same branch-free network.
-        {
-            const int xa = (gx - 4 < 0 ? 0 : gx - 4) - (g0 - 4), xb = (gx + 4 > xdim - 1 ? xdim - 1 : gx + 4) - (g0 - 4);
-            const int ya = (cy - 4 < 0 ? 0 : cy - 4) - (c0 - 4), yb = (cy + 4 > ydim - 1 ? ydim - 1 : cy + 4) - (c0 - 4);
-            const int m = (xb - xa + 1) * (yb - ya + 1);
-            const int n_lo = (m & 1) ? (81 - m) / 2 : 41 - m / 2;
-            int npad = 0;
-            double a[81];
-#pragma unroll
-            for (int c = 0; c < 9; ++c) {
-                const int yy = ty + c;
-                double v[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const int xx = tx + k;
-                    double val = patch[yy * PW + xx];
-                    if (!(yy >= ya && yy <= yb && xx >= xa && xx <= xb)) {
-                        val = (npad < n_lo) ? -__builtin_inf() : __builtin_inf();
-                        ++npad;
-                    }
-                    v[k] = val;
-                }
-                ICNV_SORT9(v);
-#pragma unroll
-                for (int k = 0; k < 9; ++k) a[9 * c + k] = v[k];
-            }
-            double r40, r41;
-            median81_pair_sorted_columns(a, r40, r41);
-            out[(int64_t)idx[cy] * G + cs + gx] = (m & 1) ? r40 : (r40 + r41) * 0.5;
-            return;
-        }
-    }
     if (gx >= xdim || cy >= ydim) return;
     // clamped window (R/noise_reduction.R:101-106), in patch coordinates
     const int xa = (gx - h < 0 ? 0 : gx - h) - (g0 - h), xb = (gx + h > xdim - 1 ? xdim - 1 : gx + h) - (g0 - h);
@@ -157,12 +115,183 @@ __global__ void __launch_bounds__(MF_TG *MF_TC) median_filter_kernel(
     out[(int64_t)idx[cy] * G + cs + gx] = (m & 1) ? v_lo : (v_lo + v_hi) * 0.5;
 }
 
+
+// One patch of the 9 x 9 kernel: stage A (column sorts into LDS), then the outputs of thread (tx, ty).
+__device__ inline void median9_patch(int cs, int xdim, int g0, int ydim, int c0, const int32_t *__restrict__ idx, int tx,
+                                     int ty, const double *patch, double *sortedc, double *__restrict__ out, int G) {
+    constexpr int h = 4;
+    constexpr int PW = MF_TG + 2 * h;
+    constexpr int PH = MF9_TC + 2 * h;
+#pragma unroll
+    for (int q = 0; q < PH / MF_TC; ++q) {
+        const int c = ty + q * MF_TC;
+        double v[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = patch[c * PW + tx + k];
+        ICNV_SORT9(v);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sortedc[(c * MF_TG + tx) * 9 + k] = v[k];
+    }
+    __syncthreads();
+    const int gx = g0 + tx;
+    if (gx >= xdim) return;
+    const int r0 = 2 * ty;                       // patch row of the first column of output A's window
+    const int cyA = c0 + r0, cyB = cyA + 1;
+    if (cyA >= ydim) return;
+    const bool gene_in = gx - 4 >= 0 && gx + 4 <= xdim - 1;
+    if (gene_in && cyA - 4 >= 0 && cyB + 4 <= ydim - 1) {   // both outputs interior (B exists then)
+        double w[10];
+        {
+            double s[72];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) s[9 * c + k] = sortedc[((r0 + 1 + c) * MF_TG + tx) * 9 + k];
+            median72_window(s, w);
+        }
+        double p[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) p[k] = sortedc[(r0 * MF_TG + tx) * 9 + k];
+        out[(int64_t)idx[cyA] * G + cs + gx] = median_window_finish(w, p);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) p[k] = sortedc[((r0 + 9) * MF_TG + tx) * 9 + k];
+        out[(int64_t)idx[cyB] * G + cs + gx] = median_window_finish(w, p);
+        return;
+    }
+    // one output at a time: interior ones by the single-output network over their nine shared columns, border ones
+    // over their own padded columns
+#pragma unroll 1
+    for (int which = 0; which < 2; ++which) {
+        const int cy = cyA + which, row0 = r0 + which;
+        if (cy >= ydim) break;
+        double a[81];
+        if (gene_in && cy - 4 >= 0 && cy + 4 <= ydim - 1) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) a[9 * c + k] = sortedc[((row0 + c) * MF_TG + tx) * 9 + k];
+            out[(int64_t)idx[cy] * G + cs + gx] = median81_sorted_columns(a);
+            continue;
+        }
+        const int xa = (gx - 4 < 0 ? 0 : gx - 4) - (g0 - 4), xb = (gx + 4 > xdim - 1 ? xdim - 1 : gx + 4) - (g0 - 4);
+        const int ya = (cy - 4 < 0 ? 0 : cy - 4) - (c0 - 4), yb = (cy + 4 > ydim - 1 ? ydim - 1 : cy + 4) - (c0 - 4);
+        const int m = (xb - xa + 1) * (yb - ya + 1);
+        const int n_lo = (m & 1) ? (81 - m) / 2 : 41 - m / 2;
+        int npad = 0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            const int yy = row0 + c;
+            double v[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int xx = tx + k;
+                double val = patch[yy * PW + xx];
+                if (!(yy >= ya && yy <= yb && xx >= xa && xx <= xb)) {
+                    val = (npad < n_lo) ? -__builtin_inf() : __builtin_inf();
+                    ++npad;
+                }
+                v[k] = val;
+            }
+            ICNV_SORT9(v);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) a[9 * c + k] = v[k];
+        }
+        double r40, r41;
+        median81_pair_sorted_columns(a, r40, r41);
+        out[(int64_t)idx[cy] * G + cs + gx] = (m & 1) ? r40 : (r40 + r41) * 0.5;
+    }
+}
+
+
+// window_size 7 -> 9 x 9 windows.
+//   Stage A: every (output gene, patch cell) pair gets its nine values along the genes sorted once (25
+//     compare-exchanges) and shared through LDS by the nine outputs whose window contains it.
+//   Stage B: a thread owns the outputs of two neighbouring cells.  Their windows share eight of the nine sorted
+//     columns: positions 31..40 of the merged 72 shared values -- the only ones that can be the median of 72 + 9 --
+//     come from one pruned odd-even merge network per PAIR (668 min/max), and each output finishes with its own
+//     column (18 min/max): 352 min/max per output instead of the 686 of a network per output (median9x9_net.h,
+//     generated and verified by gen_median_net.py; no branches, no data-dependent loops).
+//   Border outputs (clamped windows, m < 81 values; R/noise_reduction.R:101-106) pad the missing positions with
+//     n_lo x -inf and +inf so that the wanted order statistics of the real values sit at ranks 40 (and 41 for an
+//     even m) of the padded 81, sort their own nine columns and run the two-rank variant of the single-output
+//     network -- branch-free as well, so a wavefront that mixes interior and border outputs does not serialise on a
+//     slow data-dependent path.
+__global__ void __launch_bounds__(MF_TG *MF_TC) median_filter9_kernel(
+    const double *__restrict__ in, double *__restrict__ out, int G, const int32_t *__restrict__ tile_idx,
+    const int4 *__restrict__ gene_block_desc /* {chromosome's first gene, its length, block's first gene} */,
+    const int4 *__restrict__ cell_patch_desc /* {offset of the tile's cell list, tile length, patch's first cell} */,
+    int gene_blocks, int64_t n_patches) {
+    constexpr int h = 4;
+    constexpr int PW = MF_TG + 2 * h;    // patch width (genes)
+    constexpr int PH = MF9_TC + 2 * h;   // patch height (cells)
+    constexpr int NT = MF_TG * MF_TC;
+    constexpr int EPT = (PW * PH + NT - 1) / NT;   // patch elements per thread
+    extern __shared__ __attribute__((aligned(16))) double patch[];  // [PH][PW], then the sorted columns [PH][MF_TG][9]
+    double *sortedc = patch + PW * PH;
+    // Persistent workgroups walk the patches (gene block fastest).  Two things keep the memory latency off the
+    // critical path: a patch is described by two 16-byte records built on the host (one scalar load each instead of
+    // a chromosome scan and a binary search: ~10 dependent loads), requested TWO patches ahead; and the NEXT patch's
+    // values are requested into registers before the current patch's networks run and parked in LDS afterwards, so the
+    // gather (indirect rows through the tile's cell index) hides behind ~1 000 min/max instead of standing between
+    // barriers.
+    struct Where { int cs, xdim, g0, ydim, c0; const int32_t *idx; };
+    auto where = [&](const int4 gd, const int4 cd) {
+        Where w;
+        w.cs = gd.x; w.xdim = gd.y; w.g0 = gd.z;
+        w.idx = tile_idx + cd.x; w.ydim = cd.y; w.c0 = cd.z;
+        return w;
+    };
+    double stage[EPT];
+    auto gather = [&](const Where &w) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = (int)threadIdx.x + q * NT;
+            const int py = e / PW, px = e - py * PW;
+            const int gx = w.g0 - h + px, cy = w.c0 - h + py;
+            double v = 0.0;
+            if (e < PW * PH && gx >= 0 && gx < w.xdim && cy >= 0 && cy < w.ydim) v = in[(int64_t)w.idx[cy] * G + w.cs + gx];
+            stage[q] = v;
+        }
+    };
+    const int tx = threadIdx.x % MF_TG, ty = threadIdx.x / MF_TG;
+    int64_t pid = blockIdx.x;
+    if (pid >= n_patches) return;
+    Where cur = where(gene_block_desc[pid % gene_blocks], cell_patch_desc[pid / gene_blocks]);
+    gather(cur);
+    int4 gd2 = make_int4(0, 0, 0, 0), cd2 = gd2;   // descriptors of the patch after the next
+    if (pid + gridDim.x < n_patches) {
+        gd2 = gene_block_desc[(pid + gridDim.x) % gene_blocks];
+        cd2 = cell_patch_desc[(pid + gridDim.x) / gene_blocks];
+    }
+    for (; pid < n_patches; pid += gridDim.x) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = (int)threadIdx.x + q * NT;
+            if (e < PW * PH) patch[e] = stage[q];
+        }
+        __syncthreads();
+        const Where w = cur;
+        if (pid + gridDim.x < n_patches) {
+            cur = where(gd2, cd2);
+            gather(cur);
+            const int64_t p2 = pid + 2 * (int64_t)gridDim.x;
+            if (p2 < n_patches) {
+                gd2 = gene_block_desc[p2 % gene_blocks];
+                cd2 = cell_patch_desc[p2 / gene_blocks];
+            }
+        }
+        median9_patch(w.cs, w.xdim, w.g0, w.ydim, w.c0, w.idx, tx, ty, patch, sortedc, out, G);
+        __syncthreads();   // every read of this patch and its sorted columns is done
+    }
+}
+
 }  // namespace
 
 int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, const int32_t *chr_start_dev,
                          int32_t n_chr, const int32_t *tile_idx_dev, const int32_t *tile_off_dev, int32_t n_tiles,
                          const int32_t *blk_off_dev, const int32_t *chr_start_host, int32_t total_cell_patches,
-                         int32_t window_size, hipStream_t stream) {
+                         int32_t window_size, const int32_t *gene_block_desc_dev, const int32_t *cell_patch_desc_dev,
+                         hipStream_t stream) {
     (void)C;
     if (n_tiles <= 0 || n_chr <= 0 || total_cell_patches <= 0) return ICNV_OK;
     const int h = (window_size - 1) / 2 + 1;
@@ -172,21 +301,28 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
     if (gene_blocks <= 0) return ICNV_OK;
     if (n_chr > 65535) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "median filter: more than 65535 chromosomes");
     const bool fast9 = (h == 4);
-    const size_t lds = ((size_t)(MF_TG + 2 * h) * (MF_TC + 2 * h) + (fast9 ? (size_t)(MF_TC + 2 * h) * MF_TG * 9 : 0)) *
-                       sizeof(double);
+    const size_t lds = fast9 ? ((size_t)(MF_TG + 8) * (MF9_TC + 8) + (size_t)(MF9_TC + 8) * MF_TG * 9) * sizeof(double)
+                             : (size_t)(MF_TG + 2 * h) * (MF_TC + 2 * h) * sizeof(double);
     KernelTimer kt("median_filter", stream);
-    for (int base = 0; base < total_cell_patches; base += 32768) {
-        const int nz = (total_cell_patches - base) < 32768 ? (total_cell_patches - base) : 32768;
-        const dim3 grid(gene_blocks, 1, nz);
-        if (fast9)
-            hipLaunchKernelGGL(median_filter_kernel<true>, grid, dim3(MF_TG * MF_TC), lds, stream, in, out, G, chr_start_dev,
-                               tile_idx_dev, tile_off_dev, n_tiles, blk_off_dev, h, base, n_chr);
-        else
-            hipLaunchKernelGGL(median_filter_kernel<false>, grid, dim3(MF_TG * MF_TC), lds, stream, in, out, G,
+    if (fast9) {
+        const int64_t n_patches = (int64_t)gene_blocks * total_cell_patches;
+        int64_t grid = (int64_t)num_cus() * 2;   // two resident workgroups per CU (63 KB of LDS, ~200 registers)
+        if (grid > n_patches) grid = n_patches;
+        hipLaunchKernelGGL(median_filter9_kernel, dim3((unsigned)grid), dim3(MF_TG * MF_TC), lds, stream, in, out, G,
+                           tile_idx_dev, reinterpret_cast<const int4 *>(gene_block_desc_dev),
+                           reinterpret_cast<const int4 *>(cell_patch_desc_dev), gene_blocks, n_patches);
+    } else {
+        for (int base = 0; base < total_cell_patches; base += 32768) {
+            const int nz = (total_cell_patches - base) < 32768 ? (total_cell_patches - base) : 32768;
+            const dim3 grid(gene_blocks, 1, nz);
+            hipLaunchKernelGGL(median_filter_kernel, grid, dim3(MF_TG * MF_TC), lds, stream, in, out, G,
                                chr_start_dev, tile_idx_dev, tile_off_dev, n_tiles, blk_off_dev, h, base, n_chr);
+        }
     }
     ICNV_HIP(hipGetLastError());
     return ICNV_OK;
 }
+
+int median_cells_per_patch(int32_t window_size) { return (window_size - 1) / 2 + 1 == 4 ? MF9_TC : MF_TC; }
 
 }  // namespace icnv
