@@ -1335,7 +1335,18 @@ int icnv_median_filter_dev(const double *expr_in, double *expr_out, int64_t G, i
     if (rc) return rc;
     if ((rc = validate_groups(tile_idx, tile_off, n_tiles, C, "tiles"))) return rc;
     hipStream_t s = (hipStream_t)stream;
-    ICNV_HIP(hipMemcpyAsync(expr_out, expr_in, (size_t)G * C * sizeof(double), hipMemcpyDeviceToDevice, s));
+    // cells that belong to no tile keep their values (R/noise_reduction.R:60-86 only assigns the tiles' blocks); when the
+    // tiles cover every cell -- the usual call: all subclusters and all reference groups -- every element is
+    // written by the filter and the copy (2 x 8 bytes per element) is skipped
+    bool covered = false;
+    if (n_tiles > 0 && (int64_t)tile_off[n_tiles] >= C) {
+        std::vector<bool> seen((size_t)C, false);
+        int64_t n_seen = 0;
+        for (int64_t i = 0; i < tile_off[n_tiles]; ++i)
+            if (!seen[(size_t)tile_idx[i]]) { seen[(size_t)tile_idx[i]] = true; ++n_seen; }
+        covered = n_seen == C;
+    }
+    if (!covered) ICNV_HIP(hipMemcpyAsync(expr_out, expr_in, (size_t)G * C * sizeof(double), hipMemcpyDeviceToDevice, s));
     if (n_tiles == 0) return ICNV_OK;
     std::vector<int32_t> blk_off((size_t)n_tiles + 1, 0);
     const int cpp = median_cells_per_patch(window_size);

@@ -117,8 +117,8 @@ __global__ void __launch_bounds__(MF_TG *MF_TC) median_filter_kernel(
 
 
 // One patch of the 9 x 9 kernel: stage A (column sorts into LDS), then the outputs of thread (tx, ty).
-__device__ inline void median9_patch(int cs, int xdim, int g0, int ydim, int c0, const int32_t *__restrict__ idx, int tx,
-                                     int ty, const double *patch, double *sortedc, double *__restrict__ out, int G) {
+__device__ inline void median9_patch(int cs, int xdim, int g0, int ydim, int c0, const int32_t *rows /* LDS: cell of patch row r */,
+                                     int tx, int ty, const double *patch, double *sortedc, double *__restrict__ out, int G) {
     constexpr int h = 4;
     constexpr int PW = MF_TG + 2 * h;
     constexpr int PH = MF9_TC + 2 * h;
@@ -152,10 +152,10 @@ __device__ inline void median9_patch(int cs, int xdim, int g0, int ydim, int c0,
         double p[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) p[k] = sortedc[(r0 * MF_TG + tx) * 9 + k];
-        out[(int64_t)idx[cyA] * G + cs + gx] = median_window_finish(w, p);
+        out[(int64_t)rows[r0 + 4] * G + cs + gx] = median_window_finish(w, p);
 #pragma unroll
         for (int k = 0; k < 9; ++k) p[k] = sortedc[((r0 + 9) * MF_TG + tx) * 9 + k];
-        out[(int64_t)idx[cyB] * G + cs + gx] = median_window_finish(w, p);
+        out[(int64_t)rows[r0 + 5] * G + cs + gx] = median_window_finish(w, p);
         return;
     }
     // one output at a time: interior ones by the single-output network over their nine shared columns, border ones
@@ -170,7 +170,7 @@ __device__ inline void median9_patch(int cs, int xdim, int g0, int ydim, int c0,
             for (int c = 0; c < 9; ++c)
 #pragma unroll
                 for (int k = 0; k < 9; ++k) a[9 * c + k] = sortedc[((row0 + c) * MF_TG + tx) * 9 + k];
-            out[(int64_t)idx[cy] * G + cs + gx] = median81_sorted_columns(a);
+            out[(int64_t)rows[row0 + 4] * G + cs + gx] = median81_sorted_columns(a);
             continue;
         }
         const int xa = (gx - 4 < 0 ? 0 : gx - 4) - (g0 - 4), xb = (gx + 4 > xdim - 1 ? xdim - 1 : gx + 4) - (g0 - 4);
@@ -198,7 +198,7 @@ __device__ inline void median9_patch(int cs, int xdim, int g0, int ydim, int c0,
         }
         double r40, r41;
         median81_pair_sorted_columns(a, r40, r41);
-        out[(int64_t)idx[cy] * G + cs + gx] = (m & 1) ? r40 : (r40 + r41) * 0.5;
+        out[(int64_t)rows[row0 + 4] * G + cs + gx] = (m & 1) ? r40 : (r40 + r41) * 0.5;
     }
 }
 
@@ -216,7 +216,7 @@ __device__ inline void median9_patch(int cs, int xdim, int g0, int ydim, int c0,
 //     even m) of the padded 81, sort their own nine columns and run the two-rank variant of the single-output
 //     network -- branch-free as well, so a wavefront that mixes interior and border outputs does not serialise on a
 //     slow data-dependent path.
-__global__ void __launch_bounds__(MF_TG *MF_TC) median_filter9_kernel(
+__global__ void __launch_bounds__(MF_TG *MF_TC, 2) median_filter9_kernel(
     const double *__restrict__ in, double *__restrict__ out, int G, const int32_t *__restrict__ tile_idx,
     const int4 *__restrict__ gene_block_desc /* {chromosome's first gene, its length, block's first gene} */,
     const int4 *__restrict__ cell_patch_desc /* {offset of the tile's cell list, tile length, patch's first cell} */,
@@ -241,47 +241,71 @@ __global__ void __launch_bounds__(MF_TG *MF_TC) median_filter9_kernel(
         w.idx = tile_idx + cd.x; w.ydim = cd.y; w.c0 = cd.z;
         return w;
     };
+    // cell index of every patch row, double-buffered in LDS: loaded by PH threads two patches ahead, so neither the
+    // gather nor the output stores wait for an index load
+    int32_t *rowbuf = reinterpret_cast<int32_t *>(sortedc + PH * MF_TG * 9);   // [2][PH]
+    auto load_rows = [&](const Where &w) -> int32_t {
+        const int cy = w.c0 - h + (int)threadIdx.x;
+        return ((int)threadIdx.x < PH && cy >= 0 && cy < w.ydim) ? w.idx[cy] : 0;
+    };
     double stage[EPT];
-    auto gather = [&](const Where &w) {
+    auto gather = [&](const Where &w, const int32_t *rows) {
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
             const int e = (int)threadIdx.x + q * NT;
             const int py = e / PW, px = e - py * PW;
             const int gx = w.g0 - h + px, cy = w.c0 - h + py;
             double v = 0.0;
-            if (e < PW * PH && gx >= 0 && gx < w.xdim && cy >= 0 && cy < w.ydim) v = in[(int64_t)w.idx[cy] * G + w.cs + gx];
+            if (e < PW * PH && gx >= 0 && gx < w.xdim && cy >= 0 && cy < w.ydim) v = in[(int64_t)rows[py] * G + w.cs + gx];
             stage[q] = v;
         }
     };
     const int tx = threadIdx.x % MF_TG, ty = threadIdx.x / MF_TG;
+    const int64_t step = gridDim.x;
     int64_t pid = blockIdx.x;
     if (pid >= n_patches) return;
-    Where cur = where(gene_block_desc[pid % gene_blocks], cell_patch_desc[pid / gene_blocks]);
-    gather(cur);
-    int4 gd2 = make_int4(0, 0, 0, 0), cd2 = gd2;   // descriptors of the patch after the next
-    if (pid + gridDim.x < n_patches) {
-        gd2 = gene_block_desc[(pid + gridDim.x) % gene_blocks];
-        cd2 = cell_patch_desc[(pid + gridDim.x) / gene_blocks];
+    auto desc = [&](int64_t p, int4 &gd, int4 &cd) {
+        gd = gene_block_desc[p % gene_blocks];
+        cd = cell_patch_desc[p / gene_blocks];
+    };
+    int4 gd, cd;
+    desc(pid, gd, cd);
+    Where cur = where(gd, cd);
+    if ((int)threadIdx.x < PH) rowbuf[threadIdx.x] = load_rows(cur);
+    __syncthreads();
+    gather(cur, rowbuf);
+    Where nxt = cur;                 // patch pid + step
+    int32_t nxt_row = 0;             // its row table entry of this thread
+    int4 gd2 = gd, cd2 = cd;         // descriptors of patch pid + 2 step
+    if (pid + step < n_patches) {
+        desc(pid + step, gd, cd);
+        nxt = where(gd, cd);
+        nxt_row = load_rows(nxt);
     }
-    for (; pid < n_patches; pid += gridDim.x) {
+    if (pid + 2 * step < n_patches) desc(pid + 2 * step, gd2, cd2);
+    int buf = 0;
+    for (; pid < n_patches; pid += step) {
+        const bool more = pid + step < n_patches;
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
             const int e = (int)threadIdx.x + q * NT;
             if (e < PW * PH) patch[e] = stage[q];
         }
+        if (more && (int)threadIdx.x < PH) rowbuf[(buf ^ 1) * PH + threadIdx.x] = nxt_row;
         __syncthreads();
         const Where w = cur;
-        if (pid + gridDim.x < n_patches) {
-            cur = where(gd2, cd2);
-            gather(cur);
-            const int64_t p2 = pid + 2 * (int64_t)gridDim.x;
-            if (p2 < n_patches) {
-                gd2 = gene_block_desc[p2 % gene_blocks];
-                cd2 = cell_patch_desc[p2 / gene_blocks];
+        if (more) {
+            cur = nxt;
+            gather(cur, rowbuf + (buf ^ 1) * PH);
+            if (pid + 2 * step < n_patches) {
+                nxt = where(gd2, cd2);
+                nxt_row = load_rows(nxt);
+                if (pid + 3 * step < n_patches) desc(pid + 3 * step, gd2, cd2);
             }
         }
-        median9_patch(w.cs, w.xdim, w.g0, w.ydim, w.c0, w.idx, tx, ty, patch, sortedc, out, G);
-        __syncthreads();   // every read of this patch and its sorted columns is done
+        median9_patch(w.cs, w.xdim, w.g0, w.ydim, w.c0, rowbuf + buf * PH, tx, ty, patch, sortedc, out, G);
+        buf ^= 1;
+        __syncthreads();   // every read of this patch, its sorted columns and its row table is done
     }
 }
 
@@ -301,7 +325,8 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
     if (gene_blocks <= 0) return ICNV_OK;
     if (n_chr > 65535) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "median filter: more than 65535 chromosomes");
     const bool fast9 = (h == 4);
-    const size_t lds = fast9 ? ((size_t)(MF_TG + 8) * (MF9_TC + 8) + (size_t)(MF9_TC + 8) * MF_TG * 9) * sizeof(double)
+    const size_t lds = fast9 ? ((size_t)(MF_TG + 8) * (MF9_TC + 8) + (size_t)(MF9_TC + 8) * MF_TG * 9) * sizeof(double) +
+                                   2 * (MF9_TC + 8) * sizeof(int32_t)
                              : (size_t)(MF_TG + 2 * h) * (MF_TC + 2 * h) * sizeof(double);
     KernelTimer kt("median_filter", stream);
     if (fast9) {
