@@ -186,12 +186,21 @@ int launch_cell_distances(const double *x, int32_t G, const int32_t *idx_dev, in
                           double *diag_dev, double *out, hipStream_t stream);
 
 // ---- median filter --------------------------------------------------------
+// The default window (9 x 9) runs on patch descriptors built by the host (api.hip): interior gene blocks / cell
+// patches for median_filter9_kernel, border items for median_filter9_edge_kernel; other windows use blk_off.
+struct Median9Plan {
+    const int32_t *gene_block_desc = nullptr;   // 4 ints per block: {chromosome's first gene, its length, block's first gene, xdim - 4}
+    const int32_t *cell_patch_desc = nullptr;   // 4 ints per patch: {offset of the tile's cells, tile length, patch's first cell, ydim - 4}
+    const int32_t *edge_desc = nullptr;         // 8 ints per item: {mode, cs, xdim, tile offset | ydim, b0, 0, 0}
+    int32_t n_gene_blocks = 0, n_cell_patches = 0, n_edge_items = 0;
+};
 int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, const int32_t *chr_start_dev,
                          int32_t n_chr, const int32_t *tile_idx_dev, const int32_t *tile_off_dev, int32_t n_tiles,
                          const int32_t *blk_off_dev, const int32_t *chr_start_host, int32_t total_cell_patches,
-                         int32_t window_size, const int32_t *gene_block_desc_dev, const int32_t *cell_patch_desc_dev,
-                         hipStream_t stream);
+                         int32_t window_size, const Median9Plan &plan9, hipStream_t stream);
 constexpr int MEDIAN_GENES_PER_PATCH = 32;
-int median_cells_per_patch(int32_t window_size);   // cells of one workgroup's output patch (the host builds the patch prefix per tile)
+constexpr int MEDIAN9_CELLS_PER_PATCH = 16;
+inline bool median_is_9x9(int32_t window_size) { return (window_size - 1) / 2 + 1 == 4; }
+constexpr int MEDIAN_CELLS_PER_PATCH = 8;   // generic kernel
 
 }  // namespace icnv

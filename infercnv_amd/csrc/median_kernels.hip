@@ -116,8 +116,9 @@ __global__ void __launch_bounds__(MF_TG *MF_TC) median_filter_kernel(
 }
 
 
-// One patch of the 9 x 9 kernel: stage A (column sorts into LDS), then the outputs of thread (tx, ty).
-__device__ inline void median9_patch(int cs, int xdim, int g0, int ydim, int c0, const int32_t *rows /* LDS: cell of patch row r */,
+// One patch of the 9 x 9 interior kernel: stage A (column sorts into LDS), then the outputs of thread (tx, ty).  The
+// patch holds interior outputs only: genes [g0, gend) with gend <= xdim - 4, cells [c0, cend) with c0 >= 4, cend <= ydim - 4.
+__device__ inline void median9_patch(int cs, int g0, int gend, int c0, int cend, const int32_t *rows /* LDS: cell of patch row r */,
                                      int tx, int ty, const double *patch, double *sortedc, double *__restrict__ out, int G) {
     constexpr int h = 4;
     constexpr int PW = MF_TG + 2 * h;
@@ -134,12 +135,11 @@ __device__ inline void median9_patch(int cs, int xdim, int g0, int ydim, int c0,
     }
     __syncthreads();
     const int gx = g0 + tx;
-    if (gx >= xdim) return;
+    if (gx >= gend) return;
     const int r0 = 2 * ty;                       // patch row of the first column of output A's window
     const int cyA = c0 + r0, cyB = cyA + 1;
-    if (cyA >= ydim) return;
-    const bool gene_in = gx - 4 >= 0 && gx + 4 <= xdim - 1;
-    if (gene_in && cyA - 4 >= 0 && cyB + 4 <= ydim - 1) {   // both outputs interior (B exists then)
+    if (cyA >= cend) return;
+    if (cyB < cend) {
         double w[10];
         {
             double s[72];
@@ -158,50 +158,96 @@ __device__ inline void median9_patch(int cs, int xdim, int g0, int ydim, int c0,
         out[(int64_t)rows[r0 + 5] * G + cs + gx] = median_window_finish(w, p);
         return;
     }
-    // one output at a time: interior ones by the single-output network over their nine shared columns, border ones
-    // over their own padded columns
-#pragma unroll 1
-    for (int which = 0; which < 2; ++which) {
-        const int cy = cyA + which, row0 = r0 + which;
-        if (cy >= ydim) break;
-        double a[81];
-        if (gene_in && cy - 4 >= 0 && cy + 4 <= ydim - 1) {
+    // the last interior cell of a tile with an odd number of them: the single-output network over its nine columns
+    double a[81];
 #pragma unroll
-            for (int c = 0; c < 9; ++c)
+    for (int c = 0; c < 9; ++c)
 #pragma unroll
-                for (int k = 0; k < 9; ++k) a[9 * c + k] = sortedc[((row0 + c) * MF_TG + tx) * 9 + k];
-            out[(int64_t)rows[row0 + 4] * G + cs + gx] = median81_sorted_columns(a);
-            continue;
-        }
-        const int xa = (gx - 4 < 0 ? 0 : gx - 4) - (g0 - 4), xb = (gx + 4 > xdim - 1 ? xdim - 1 : gx + 4) - (g0 - 4);
-        const int ya = (cy - 4 < 0 ? 0 : cy - 4) - (c0 - 4), yb = (cy + 4 > ydim - 1 ? ydim - 1 : cy + 4) - (c0 - 4);
-        const int m = (xb - xa + 1) * (yb - ya + 1);
-        const int n_lo = (m & 1) ? (81 - m) / 2 : 41 - m / 2;
-        int npad = 0;
-#pragma unroll
-        for (int c = 0; c < 9; ++c) {
-            const int yy = row0 + c;
-            double v[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const int xx = tx + k;
-                double val = patch[yy * PW + xx];
-                if (!(yy >= ya && yy <= yb && xx >= xa && xx <= xb)) {
-                    val = (npad < n_lo) ? -__builtin_inf() : __builtin_inf();
-                    ++npad;
-                }
-                v[k] = val;
-            }
-            ICNV_SORT9(v);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) a[9 * c + k] = v[k];
-        }
-        double r40, r41;
-        median81_pair_sorted_columns(a, r40, r41);
-        out[(int64_t)rows[row0 + 4] * G + cs + gx] = (m & 1) ? r40 : (r40 + r41) * 0.5;
-    }
+        for (int k = 0; k < 9; ++k) a[9 * c + k] = sortedc[((r0 + c) * MF_TG + tx) * 9 + k];
+    out[(int64_t)rows[r0 + 4] * G + cs + gx] = median81_sorted_columns(a);
 }
 
+// Border outputs of the 9 x 9 filter (clamped windows, m < 81 values; R/noise_reduction.R:101-106), one per thread,
+// no interior outputs in the workgroup: the missing positions are padded with n_lo x -inf and +inf so that the wanted
+// order statistics of the real values sit at ranks 40 (and 41 for an even m: stats::median averages the two middle
+// values) of the padded 81; the thread sorts its own nine columns and runs the two-rank variant of the single-output
+// network.  Branch-free like the interior path; kept apart from it because a wavefront that mixes the two pays for both
+// (border outputs are 3.4 % of a 500-cell x 450-gene block but cost 3 x an interior output).
+//   mode 0: the border GENES of one chromosome (first and last four; all genes of a chromosome shorter than nine) for 32
+//           consecutive cells of a tile, corners included;  b0 = first cell
+//   mode 1: the border CELLS of one tile (first and last four; all cells of a tile smaller than nine) for 32 consecutive
+//           interior genes [4, xdim - 4) of a chromosome;  b0 = first gene
+__global__ void __launch_bounds__(256, 2) median_filter9_edge_kernel(const double *__restrict__ in, double *__restrict__ out, int G,
+                                                                     const int32_t *__restrict__ tile_idx,
+                                                                     const int4 *__restrict__ item_desc) {
+    __shared__ double ep[40 * 16];
+    const int4 d0 = item_desc[2 * blockIdx.x], d1 = item_desc[2 * blockIdx.x + 1];
+    const int mode = d0.x, cs = d0.y, xdim = d0.z, ydim = d1.x, b0 = d1.y;
+    const int32_t *idx = tile_idx + d0.w;
+    const int t = threadIdx.x;
+    int g, cy;          // this thread's output (chromosome-relative gene, tile-relative cell)
+    bool active;
+    if (mode == 0) {    // LDS: 40 cells (b0 - 4 ..) x 16 genes (0..7 | xdim-8 .. xdim-1)
+        for (int e = t; e < 640; e += 256) {
+            const int row = e >> 4, col = e & 15;
+            const int c = b0 - 4 + row, gx = col < 8 ? col : xdim - 16 + col;
+            ep[e] = (c >= 0 && c < ydim && gx >= 0 && gx < xdim) ? in[(int64_t)idx[c] * G + cs + gx] : 0.0;
+        }
+        const int og = t >> 5;
+        cy = b0 + (t & 31);
+        g = (xdim >= 9 && og >= 4) ? xdim - 8 + og : og;
+        active = cy < ydim && (xdim >= 9 || og < xdim);
+    } else {            // LDS: 16 cells (0..7 | ydim-8 .. ydim-1) x 40 genes (b0 - 4 ..)
+        for (int e = t; e < 640; e += 256) {
+            const int row = e / 40, col = e - row * 40;
+            const int c = row < 8 ? row : ydim - 16 + row, gx = b0 - 4 + col;
+            ep[e] = (c >= 0 && c < ydim && gx >= 0 && gx < xdim) ? in[(int64_t)idx[c] * G + cs + gx] : 0.0;
+        }
+        const int oc = t >> 5;
+        g = b0 + (t & 31);
+        cy = (ydim >= 9 && oc >= 4) ? ydim - 8 + oc : oc;
+        active = g < xdim - 4 && (ydim >= 9 || oc < ydim);
+    }
+    __syncthreads();
+    if (!active) return;
+    const int xa = g - 4 < 0 ? 0 : g - 4, xb = g + 4 > xdim - 1 ? xdim - 1 : g + 4;
+    const int ya = cy - 4 < 0 ? 0 : cy - 4, yb = cy + 4 > ydim - 1 ? ydim - 1 : cy + 4;
+    const int m = (xb - xa + 1) * (yb - ya + 1);
+    const int n_lo = (m & 1) ? (81 - m) / 2 : 41 - m / 2;
+    // LDS position of (gene xx, cell yy) of this thread's window: left / right (upper / lower) group of its mode
+    int base, sx, sy;
+    if (mode == 0) {
+        sx = 1; sy = 16;
+        base = ((g < 4 || xdim < 9) ? 0 : 16 - xdim) - (b0 - 4) * 16;
+    } else {
+        sx = 1; sy = 40;
+        base = ((cy < 4 || ydim < 9) ? 0 : (16 - ydim) * 40) - (b0 - 4);
+    }
+    int npad = 0;
+    double a[81];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        const int yy = cy - 4 + c;
+        double v[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int xx = g - 4 + k;
+            const bool in_win = yy >= ya && yy <= yb && xx >= xa && xx <= xb;
+            double val = in_win ? ep[base + yy * sy + xx * sx] : 0.0;
+            if (!in_win) {
+                val = (npad < n_lo) ? -__builtin_inf() : __builtin_inf();
+                ++npad;
+            }
+            v[k] = val;
+        }
+        ICNV_SORT9(v);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a[9 * c + k] = v[k];
+    }
+    double r40, r41;
+    median81_pair_sorted_columns(a, r40, r41);
+    out[(int64_t)idx[cy] * G + cs + g] = (m & 1) ? r40 : (r40 + r41) * 0.5;
+}
 
 // window_size 7 -> 9 x 9 windows.
 //   Stage A: every (output gene, patch cell) pair gets its nine values along the genes sorted once (25
@@ -211,15 +257,12 @@ __device__ inline void median9_patch(int cs, int xdim, int g0, int ydim, int c0,
 //     come from one pruned odd-even merge network per PAIR (668 min/max), and each output finishes with its own
 //     column (18 min/max): 352 min/max per output instead of the 686 of a network per output (median9x9_net.h,
 //     generated and verified by gen_median_net.py; no branches, no data-dependent loops).
-//   Border outputs (clamped windows, m < 81 values; R/noise_reduction.R:101-106) pad the missing positions with
-//     n_lo x -inf and +inf so that the wanted order statistics of the real values sit at ranks 40 (and 41 for an
-//     even m) of the padded 81, sort their own nine columns and run the two-rank variant of the single-output
-//     network -- branch-free as well, so a wavefront that mixes interior and border outputs does not serialise on a
-//     slow data-dependent path.
+//   This kernel produces the INTERIOR outputs only (gene >= 4 from either end of the chromosome, cell >= 4 from either
+//     end of the tile); median_filter9_edge_kernel above produces the rest.
 __global__ void __launch_bounds__(MF_TG *MF_TC, 2) median_filter9_kernel(
     const double *__restrict__ in, double *__restrict__ out, int G, const int32_t *__restrict__ tile_idx,
-    const int4 *__restrict__ gene_block_desc /* {chromosome's first gene, its length, block's first gene} */,
-    const int4 *__restrict__ cell_patch_desc /* {offset of the tile's cell list, tile length, patch's first cell} */,
+    const int4 *__restrict__ gene_block_desc /* {chromosome's first gene, its length, block's first gene, end of its interior genes} */,
+    const int4 *__restrict__ cell_patch_desc /* {offset of the tile's cell list, tile length, patch's first cell, end of its interior cells} */,
     int gene_blocks, int64_t n_patches) {
     constexpr int h = 4;
     constexpr int PW = MF_TG + 2 * h;    // patch width (genes)
@@ -234,11 +277,11 @@ __global__ void __launch_bounds__(MF_TG *MF_TC, 2) median_filter9_kernel(
     // values are requested into registers before the current patch's networks run and parked in LDS afterwards, so the
     // gather (indirect rows through the tile's cell index) hides behind ~1 000 min/max instead of standing between
     // barriers.
-    struct Where { int cs, xdim, g0, ydim, c0; const int32_t *idx; };
+    struct Where { int cs, xdim, g0, gend, ydim, c0, cend; const int32_t *idx; };
     auto where = [&](const int4 gd, const int4 cd) {
         Where w;
-        w.cs = gd.x; w.xdim = gd.y; w.g0 = gd.z;
-        w.idx = tile_idx + cd.x; w.ydim = cd.y; w.c0 = cd.z;
+        w.cs = gd.x; w.xdim = gd.y; w.g0 = gd.z; w.gend = gd.w;
+        w.idx = tile_idx + cd.x; w.ydim = cd.y; w.c0 = cd.z; w.cend = cd.w;
         return w;
     };
     // cell index of every patch row, double-buffered in LDS: loaded by PH threads two patches ahead, so neither the
@@ -303,7 +346,7 @@ __global__ void __launch_bounds__(MF_TG *MF_TC, 2) median_filter9_kernel(
                 if (pid + 3 * step < n_patches) desc(pid + 3 * step, gd2, cd2);
             }
         }
-        median9_patch(w.cs, w.xdim, w.g0, w.ydim, w.c0, rowbuf + buf * PH, tx, ty, patch, sortedc, out, G);
+        median9_patch(w.cs, w.g0, w.gend, w.c0, w.cend, rowbuf + buf * PH, tx, ty, patch, sortedc, out, G);
         buf ^= 1;
         __syncthreads();   // every read of this patch, its sorted columns and its row table is done
     }
@@ -314,29 +357,33 @@ __global__ void __launch_bounds__(MF_TG *MF_TC, 2) median_filter9_kernel(
 int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, const int32_t *chr_start_dev,
                          int32_t n_chr, const int32_t *tile_idx_dev, const int32_t *tile_off_dev, int32_t n_tiles,
                          const int32_t *blk_off_dev, const int32_t *chr_start_host, int32_t total_cell_patches,
-                         int32_t window_size, const int32_t *gene_block_desc_dev, const int32_t *cell_patch_desc_dev,
-                         hipStream_t stream) {
+                         int32_t window_size, const Median9Plan &plan9, hipStream_t stream) {
     (void)C;
-    if (n_tiles <= 0 || n_chr <= 0 || total_cell_patches <= 0) return ICNV_OK;
+    static_assert(MF_TG == MEDIAN_GENES_PER_PATCH && MF9_TC == MEDIAN9_CELLS_PER_PATCH && MF_TC == MEDIAN_CELLS_PER_PATCH, "host tables");
+    if (n_tiles <= 0 || n_chr <= 0) return ICNV_OK;
     const int h = (window_size - 1) / 2 + 1;
     if (h > MF_MAXH) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "median filter supports window_size <= 15");
-    int gene_blocks = 0;
-    for (int k = 0; k < n_chr; ++k) gene_blocks += (chr_start_host[k + 1] - chr_start_host[k] + MF_TG - 1) / MF_TG;
-    if (gene_blocks <= 0) return ICNV_OK;
-    if (n_chr > 65535) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "median filter: more than 65535 chromosomes");
-    const bool fast9 = (h == 4);
-    const size_t lds = fast9 ? ((size_t)(MF_TG + 8) * (MF9_TC + 8) + (size_t)(MF9_TC + 8) * MF_TG * 9) * sizeof(double) +
-                                   2 * (MF9_TC + 8) * sizeof(int32_t)
-                             : (size_t)(MF_TG + 2 * h) * (MF_TC + 2 * h) * sizeof(double);
     KernelTimer kt("median_filter", stream);
-    if (fast9) {
-        const int64_t n_patches = (int64_t)gene_blocks * total_cell_patches;
-        int64_t grid = (int64_t)num_cus() * 2;   // two resident workgroups per CU (63 KB of LDS, ~200 registers)
-        if (grid > n_patches) grid = n_patches;
-        hipLaunchKernelGGL(median_filter9_kernel, dim3((unsigned)grid), dim3(MF_TG * MF_TC), lds, stream, in, out, G,
-                           tile_idx_dev, reinterpret_cast<const int4 *>(gene_block_desc_dev),
-                           reinterpret_cast<const int4 *>(cell_patch_desc_dev), gene_blocks, n_patches);
+    if (median_is_9x9(window_size)) {
+        const int64_t n_patches = (int64_t)plan9.n_gene_blocks * plan9.n_cell_patches;
+        if (n_patches > 0) {
+            const size_t lds = ((size_t)(MF_TG + 8) * (MF9_TC + 8) + (size_t)(MF9_TC + 8) * MF_TG * 9) * sizeof(double) +
+                               2 * (MF9_TC + 8) * sizeof(int32_t);
+            int64_t grid = (int64_t)num_cus() * 2;   // two resident workgroups per CU (63 KB of LDS, 256 registers)
+            if (grid > n_patches) grid = n_patches;
+            hipLaunchKernelGGL(median_filter9_kernel, dim3((unsigned)grid), dim3(MF_TG * MF_TC), lds, stream, in, out, G,
+                               tile_idx_dev, reinterpret_cast<const int4 *>(plan9.gene_block_desc),
+                               reinterpret_cast<const int4 *>(plan9.cell_patch_desc), plan9.n_gene_blocks, n_patches);
+        }
+        if (plan9.n_edge_items > 0)
+            hipLaunchKernelGGL(median_filter9_edge_kernel, dim3((unsigned)plan9.n_edge_items), dim3(256), 0, stream, in, out, G,
+                               tile_idx_dev, reinterpret_cast<const int4 *>(plan9.edge_desc));
     } else {
+        if (total_cell_patches <= 0) return ICNV_OK;
+        int gene_blocks = 0;
+        for (int k = 0; k < n_chr; ++k) gene_blocks += (chr_start_host[k + 1] - chr_start_host[k] + MF_TG - 1) / MF_TG;
+        if (gene_blocks <= 0) return ICNV_OK;
+        const size_t lds = (size_t)(MF_TG + 2 * h) * (MF_TC + 2 * h) * sizeof(double);
         for (int base = 0; base < total_cell_patches; base += 32768) {
             const int nz = (total_cell_patches - base) < 32768 ? (total_cell_patches - base) : 32768;
             const dim3 grid(gene_blocks, 1, nz);
@@ -347,7 +394,5 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
     ICNV_HIP(hipGetLastError());
     return ICNV_OK;
 }
-
-int median_cells_per_patch(int32_t window_size) { return (window_size - 1) / 2 + 1 == 4 ? MF9_TC : MF_TC; }
 
 }  // namespace icnv

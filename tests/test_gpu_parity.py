@@ -482,6 +482,31 @@ def test_median_filter_exact(dev):
         np.testing.assert_array_equal(to_host(out), want)
 
 
+def test_median_filter_block_boundaries(dev):
+    """The 9 x 9 filter splits every (tile, chromosome) block into interior outputs (32-gene x 16-cell patches starting
+    four in from the edges) and border outputs (separate kernel: border genes of a chromosome, border cells of a tile):
+    chromosome lengths and tile sizes around every boundary of that split (8 | 9, one interior row, odd / even
+    numbers of interior cells, one full patch +- 1, two gene blocks +- 1), ties included."""
+    rng = np.random.default_rng(14)
+    sizes = [8, 9, 10, 17, 36, 40, 41, 73, 3]
+    G = sum(sizes)
+    cs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    tile_sizes = [8, 9, 10, 11, 24, 25, 40, 41, 2]
+    C = sum(tile_sizes) + 3
+    x = np.round(rng.normal(size=(G, C)), 1)           # one decimal: many ties
+    x[:, ::7] = rng.normal(size=(G, len(range(0, C, 7))))
+    perm = rng.permutation(C)
+    off = np.concatenate([[0], np.cumsum(tile_sizes)])
+    tiles = [perm[off[i]:off[i + 1]] for i in range(len(tile_sizes))]
+    out = dev.median_filter(to_dev(x), cs, tiles, 7)
+    want = oc.median_filter(x, cs, tiles, 7)
+    np.testing.assert_array_equal(to_host(out), want)
+    # tiles that cover every cell: the pass-through copy is skipped, every element must still be written
+    tiles_all = tiles + [perm[off[-1]:]]
+    out2 = dev.median_filter(to_dev(x), cs, tiles_all, 7)
+    np.testing.assert_array_equal(to_host(out2), oc.median_filter(x, cs, tiles_all, 7))
+
+
 # ------------------------------------------------------------------ host mirror == device path == oracle
 def test_host_mirror_runs_reference_workflow(dev, example):
     from infercnv_amd import GeneOrder, InfercnvObject, hmm, noise_reduction, ops
