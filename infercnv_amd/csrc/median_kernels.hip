@@ -269,8 +269,8 @@ __global__ void __launch_bounds__(MF_TG *MF_TC, 2) median_filter9_kernel(
     constexpr int PH = MF9_TC + 2 * h;   // patch height (cells)
     constexpr int NT = MF_TG * MF_TC;
     constexpr int EPT = (PW * PH + NT - 1) / NT;   // patch elements per thread
-    extern __shared__ __attribute__((aligned(16))) double patch[];  // [PH][PW], then the sorted columns [PH][MF_TG][9]
-    double *sortedc = patch + PW * PH;
+    extern __shared__ __attribute__((aligned(16))) double patch2[];  // 2 x [PH][PW], then the sorted columns [PH][MF_TG][9]
+    double *sortedc = patch2 + 2 * PW * PH;
     // Persistent workgroups walk the patches (gene block fastest).  Two things keep the memory latency off the
     // critical path: a patch is described by two 16-byte records built on the host (one scalar load each instead of
     // a chromosome scan and a binary search: ~10 dependent loads), requested TWO patches ahead; and the NEXT patch's
@@ -286,7 +286,10 @@ __global__ void __launch_bounds__(MF_TG *MF_TC, 2) median_filter9_kernel(
     };
     // cell index of every patch row, double-buffered in LDS: loaded by PH threads two patches ahead, so neither the
     // gather nor the output stores wait for an index load
-    int32_t *rowbuf = reinterpret_cast<int32_t *>(sortedc + PH * MF_TG * 9);   // [2][PH]
+    // The patch is double-buffered and the row table triple-buffered: a wavefront that runs ahead into the next patch
+    // parks its values and writes the row table of the patch after it while the slowest wavefront still reads the
+    // current ones, so a patch costs two barriers (patch parked | columns sorted) instead of three.
+    int32_t *rowbuf = reinterpret_cast<int32_t *>(sortedc + PH * MF_TG * 9);   // [3][PH]
     auto load_rows = [&](const Where &w) -> int32_t {
         const int cy = w.c0 - h + (int)threadIdx.x;
         return ((int)threadIdx.x < PH && cy >= 0 && cy < w.ydim) ? w.idx[cy] : 0;
@@ -326,29 +329,29 @@ __global__ void __launch_bounds__(MF_TG *MF_TC, 2) median_filter9_kernel(
         nxt_row = load_rows(nxt);
     }
     if (pid + 2 * step < n_patches) desc(pid + 2 * step, gd2, cd2);
-    int buf = 0;
-    for (; pid < n_patches; pid += step) {
+    int it = 0;   // patch counter of this workgroup: patch buffer it & 1, row table it % 3
+    for (; pid < n_patches; pid += step, ++it) {
         const bool more = pid + step < n_patches;
+        double *patch = patch2 + (it & 1) * (PW * PH);
+        const int rb = it % 3, rb_next = (it + 1) % 3;
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
             const int e = (int)threadIdx.x + q * NT;
             if (e < PW * PH) patch[e] = stage[q];
         }
-        if (more && (int)threadIdx.x < PH) rowbuf[(buf ^ 1) * PH + threadIdx.x] = nxt_row;
-        __syncthreads();
+        if (more && (int)threadIdx.x < PH) rowbuf[rb_next * PH + threadIdx.x] = nxt_row;
+        __syncthreads();   // also: every wavefront is done with the previous patch's sorted columns
         const Where w = cur;
         if (more) {
             cur = nxt;
-            gather(cur, rowbuf + (buf ^ 1) * PH);
+            gather(cur, rowbuf + rb_next * PH);
             if (pid + 2 * step < n_patches) {
                 nxt = where(gd2, cd2);
                 nxt_row = load_rows(nxt);
                 if (pid + 3 * step < n_patches) desc(pid + 3 * step, gd2, cd2);
             }
         }
-        median9_patch(w.cs, w.g0, w.gend, w.c0, w.cend, rowbuf + buf * PH, tx, ty, patch, sortedc, out, G);
-        buf ^= 1;
-        __syncthreads();   // every read of this patch, its sorted columns and its row table is done
+        median9_patch(w.cs, w.g0, w.gend, w.c0, w.cend, rowbuf + rb * PH, tx, ty, patch, sortedc, out, G);
     }
 }
 
@@ -367,9 +370,15 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
     if (median_is_9x9(window_size)) {
         const int64_t n_patches = (int64_t)plan9.n_gene_blocks * plan9.n_cell_patches;
         if (n_patches > 0) {
-            const size_t lds = ((size_t)(MF_TG + 8) * (MF9_TC + 8) + (size_t)(MF9_TC + 8) * MF_TG * 9) * sizeof(double) +
-                               2 * (MF9_TC + 8) * sizeof(int32_t);
-            int64_t grid = (int64_t)num_cus() * 2;   // two resident workgroups per CU (63 KB of LDS, 256 registers)
+            const size_t lds = ((size_t)2 * (MF_TG + 8) * (MF9_TC + 8) + (size_t)(MF9_TC + 8) * MF_TG * 9) * sizeof(double) +
+                               3 * (MF9_TC + 8) * sizeof(int32_t);
+            static bool attr = false;
+            if (!attr) {
+                ICNV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(median_filter9_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                attr = true;
+            }
+            int64_t grid = (int64_t)num_cus() * 2;   // two resident workgroups per CU (70 KB of LDS, 256 registers)
             if (grid > n_patches) grid = n_patches;
             hipLaunchKernelGGL(median_filter9_kernel, dim3((unsigned)grid), dim3(MF_TG * MF_TC), lds, stream, in, out, G,
                                tile_idx_dev, reinterpret_cast<const int4 *>(plan9.gene_block_desc),
