@@ -18,6 +18,7 @@ network exhaustively (0-1 principle) and the whole procedure on random inputs wi
 """
 import os
 import random
+import sys
 
 SORT9 = [(0, 3), (1, 7), (2, 5), (4, 8), (0, 7), (2, 4), (3, 8), (5, 6), (0, 2), (1, 3), (4, 5), (7, 8),
          (1, 4), (3, 6), (5, 7), (0, 1), (2, 4), (3, 5), (6, 8), (2, 3), (4, 5), (6, 7), (1, 2), (3, 4), (5, 6)]
@@ -247,8 +248,14 @@ def main():
     lines.append(f"    return {resf};")
     lines.append("}")
     here = os.path.dirname(os.path.abspath(__file__))
+    text = "\n".join(lines) + "\n"
+    if "--check" in sys.argv:      # tests: the committed header is what this generator (and its verification) produces
+        if open(os.path.join(here, "median9x9_net.h")).read() != text:
+            raise SystemExit("median9x9_net.h is stale: run gen_median_net.py")
+        print("median9x9_net.h is up to date")
+        return
     with open(os.path.join(here, "median9x9_net.h"), "w") as fh:
-        fh.write("\n".join(lines) + "\n")
+        fh.write(text)
     print(f"median81 network: {n_ops} min/max ops; sort9: {len(SORT9)} compare-exchanges; "
           f"shared window: {len(netw.ops)} per pair + {len(netf.ops)} per output")
 

@@ -194,3 +194,14 @@ def test_sharded_chain_two_ranks_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
         assert f"rank {r} ok" in o
+
+
+def test_median_network_header_is_generated_and_verified():
+    """median9x9_net.h (the min/max networks of the 9 x 9 median filter) is exactly what gen_median_net.py writes; the
+    generator checks every network first: sort9 exhaustively (0-1 principle), the single-output, two-rank (padded
+    border windows) and shared-window pair networks on thousands of random inputs with ties."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "infercnv_amd", "csrc", "gen_median_net.py"), "--check"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "up to date" in r.stdout
