@@ -16,7 +16,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out+"/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "median" in r["Kernel_Name"]:
-            k=r["Kernel_Name"].split("(")[0][-28:]
+            k=r["Kernel_Name"].replace("(anonymous namespace)::","").split("(")[0].split("::")[-1]
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(out+"/summary.txt","w") as fo:
     for k,d in agg.items():
