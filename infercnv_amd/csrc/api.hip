@@ -948,7 +948,7 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
         if ((rc = d_scr.alloc(viterbi_redo_scratch_bytes(max_len)))) return rc;
         return launch_viterbi_redo(x, states, (int32_t)G, d_chr.as<int32_t>(), p, sd_per_col_dev, sd_shared,
                                    d_all.as<int32_t>() + 2 * (size_t)count, d_all.as<int32_t>(), d_scr.as<uint32_t>(),
-                                   n_underflow_dev, "viterbi", s);
+                                   n_underflow_dev, max_len, "viterbi", s);
     }
     const int64_t bp_elem = fast ? 2 : 4;
     int64_t scratch_budget = (int64_t)4 << 30;   // back-pointer scratch per column batch
@@ -1007,7 +1007,7 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
         ICNV_HIP(hipMemsetAsync(g_fast.counters, 0, 2 * sizeof(int32_t), s));
         if ((rc = launch_viterbi_fast(fa, p.K, s))) return rc;
         if ((rc = launch_viterbi_redo(fa.x, fa.states, (int32_t)G, d_chr.as<int32_t>(), p, nullptr, sd_shared, fa.flag_count,
-                                      fa.flag_list, d_redo.as<uint32_t>(), n_underflow_dev, "viterbi_redo", s)))
+                                      fa.flag_list, d_redo.as<uint32_t>(), n_underflow_dev, max_len, "viterbi_redo", s)))
             return rc;
         ICNV_HIP(hipMemcpyAsync(g_fast.host_flag, fa.flag_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         ICNV_HIP(hipEventRecord(g_fast.flag_ev, s));
