@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Stress campaign of the 9 x 9 median filter (run on the GPU box): random chromosome lengths, tile sizes, cell
+permutations and tie densities against the CPU oracle, exact equality.
+  python scripts/stress_median_filter.py [first_seed] [n_seeds]"""
+import os, sys, time
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [root, os.path.join(root, "tests"), os.path.join(root, "oracle")]
+import numpy as np, torch
+import oracle_c as oc
+from infercnv_amd import device
+torch.cuda.set_device(0); device.init(0)
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+t0 = time.time(); outputs = 0
+for seed in range(first, first + n):
+    rng = np.random.default_rng(seed)
+    sizes = rng.integers(1, 90, size=int(rng.integers(1, 7)))
+    tsz = rng.integers(1, 70, size=int(rng.integers(1, 6)))
+    G, C = int(sizes.sum()), int(tsz.sum()) + int(rng.integers(0, 4))
+    cs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    x = rng.normal(size=(G, C))
+    if seed % 3 == 0: x = np.round(x, 1)                      # many ties
+    if seed % 5 == 0: x[rng.random((G, C)) < 0.5] = 0.0       # half zeros
+    perm = rng.permutation(C)
+    off = np.concatenate([[0], np.cumsum(tsz)])
+    tiles = [perm[off[i]:off[i + 1]].astype(np.int32) for i in range(len(tsz))]
+    xd = torch.from_numpy(np.ascontiguousarray(x.T)).cuda()
+    got = device.median_filter(xd, cs, tiles, 7).cpu().numpy().T
+    want = oc.median_filter(x, cs, tiles, 7)
+    assert np.array_equal(got, want), "seed %d: mismatch" % seed
+    outputs += G * C
+print("seeds %d..%d: %d outputs identical to the oracle (%.0f s)" % (first, first + n - 1, outputs, time.time() - t0))
