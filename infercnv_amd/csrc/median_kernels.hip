@@ -180,7 +180,7 @@ __device__ inline void median9_patch(int cs, int g0, int gend, int c0, int cend,
 __global__ void __launch_bounds__(256, 2) median_filter9_edge_kernel(const double *__restrict__ in, double *__restrict__ out, int G,
                                                                      const int32_t *__restrict__ tile_idx,
                                                                      const int4 *__restrict__ item_desc) {
-    __shared__ double ep[40 * 16];
+    __shared__ double ep[40 * 17];   // mode 0 rows are padded to 17 doubles: a lane's cell is its row, 16 would put all lanes on one bank
     const int4 d0 = item_desc[2 * blockIdx.x], d1 = item_desc[2 * blockIdx.x + 1];
     const int mode = d0.x, cs = d0.y, xdim = d0.z, ydim = d1.x, b0 = d1.y;
     const int32_t *idx = tile_idx + d0.w;
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(256, 2) median_filter9_edge_kernel(const doubl
         for (int e = t; e < 640; e += 256) {
             const int row = e >> 4, col = e & 15;
             const int c = b0 - 4 + row, gx = col < 8 ? col : xdim - 16 + col;
-            ep[e] = (c >= 0 && c < ydim && gx >= 0 && gx < xdim) ? in[(int64_t)idx[c] * G + cs + gx] : 0.0;
+            ep[row * 17 + col] = (c >= 0 && c < ydim && gx >= 0 && gx < xdim) ? in[(int64_t)idx[c] * G + cs + gx] : 0.0;
         }
         const int og = t >> 5;
         cy = b0 + (t & 31);
@@ -217,8 +217,8 @@ __global__ void __launch_bounds__(256, 2) median_filter9_edge_kernel(const doubl
     // LDS position of (gene xx, cell yy) of this thread's window: left / right (upper / lower) group of its mode
     int base, sx, sy;
     if (mode == 0) {
-        sx = 1; sy = 16;
-        base = ((g < 4 || xdim < 9) ? 0 : 16 - xdim) - (b0 - 4) * 16;
+        sx = 1; sy = 17;
+        base = ((g < 4 || xdim < 9) ? 0 : 16 - xdim) - (b0 - 4) * 17;
     } else {
         sx = 1; sy = 40;
         base = ((cy < 4 || ydim < 9) ? 0 : (16 - ydim) * 40) - (b0 - 4);
