@@ -77,6 +77,10 @@ typedef struct icnv_chain_cfg {
     int32_t window_length;   /* odd; < 2 = no smoothing (R/inferCNV_ops.R:2444)    */
     double max_thresh;       /* step 9 threshold; NaN = skip                       */
     int32_t use_bounds;      /* steps 8/12: 1 = min/max-of-group-means bounds      */
+    int32_t inv_log;         /* subtract_ref_expr_from_obs(inv_log = TRUE): group means as log2(mean(2^x - 1) + 1)
+                                (R/inferCNV_ops.R:1714-1717).  run() never sets it (:771, :952), so it is the
+                                stand-alone step only: stage_mask must be ICNV_ST_SUBTRACT_REF_1 alone.  Sits in
+                                the padding after use_bounds: zero-initialised configurations keep their meaning */
     double sd_amplifier;     /* step 22 (clear_noise_via_ref_mean_sd)              */
     double noise_filter;     /* step 22: NaN = sd-based; else clear_noise(threshold) */
     uint32_t stage_mask;     /* ICNV_ST_* bits                                     */

@@ -40,6 +40,7 @@ class ChainCfg(ct.Structure):
         ("window_length", ct.c_int32),
         ("max_thresh", ct.c_double),
         ("use_bounds", ct.c_int32),
+        ("inv_log", ct.c_int32),
         ("sd_amplifier", ct.c_double),
         ("noise_filter", ct.c_double),
         ("stage_mask", ct.c_uint32),
@@ -154,7 +155,7 @@ class Cfg:
     """Owns the numpy arrays a ChainCfg points to."""
 
     def __init__(self, G, C, chr_start, ref_groups, window_length=101, max_thresh=3.0, use_bounds=True,
-                 sd_amplifier=1.5, noise_filter=None, stage_mask=ST_ALL):
+                 sd_amplifier=1.5, noise_filter=None, stage_mask=ST_ALL, inv_log=False):
         self.chr_start, cp = i32(chr_start)
         idx, off = pack_groups(list(ref_groups) if ref_groups is not None else [])
         self.ref_idx, ip = i32(idx)
@@ -165,6 +166,7 @@ class Cfg:
         c.window_length = int(window_length)
         c.max_thresh = float("nan") if max_thresh is None else float(max_thresh)
         c.use_bounds = int(bool(use_bounds))
+        c.inv_log = int(bool(inv_log))
         c.sd_amplifier = float(sd_amplifier)
         c.noise_filter = float("nan") if noise_filter is None else float(noise_filter)
         c.stage_mask = int(stage_mask)

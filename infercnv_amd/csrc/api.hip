@@ -268,6 +268,9 @@ int icnv_chain_begin(icnv_chain_t **out, const icnv_chain_cfg *cfg) {
         ICNV_FAIL(ICNV_ERR_ARG, "window_length must be odd (the reference is undefined for even windows)");
     if ((mask & ICNV_ST_DENOISE) && !std::isnan(cfg->noise_filter) && cfg->noise_filter == 0.0)
         mask &= ~ICNV_ST_DENOISE;  // clear_noise(threshold = 0) is a no-op, R/inferCNV_ops.R:2236
+    if (cfg->inv_log && mask != ICNV_ST_SUBTRACT_REF_1)
+        ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "inv_log is the stand-alone subtract_ref_expr_from_obs(inv_log = TRUE): stage_mask must be "
+                                        "ICNV_ST_SUBTRACT_REF_1 alone (run() never sets it, R/inferCNV_ops.R:771,952)");
     const bool needs_ref = mask & (ICNV_ST_SUBTRACT_REF_1 | ICNV_ST_SUBTRACT_REF_2 | ICNV_ST_DENOISE);
     if (needs_ref) {
         if (cfg->n_ref_grp < 1) ICNV_FAIL(ICNV_ERR_ARG, "reference groups required for steps 8/12/22");
@@ -282,6 +285,10 @@ int icnv_chain_begin(icnv_chain_t **out, const icnv_chain_cfg *cfg) {
     {
         const char *force = std::getenv("ICNV_CHAIN_LARGE");   // developer switch: the three-pass chain for any size
         ch->large = (force && force[0] == '1') || cfg->n_chr > 510 || !chain_fused_fits(cfg->G, cfg->n_chr, ch->T);
+        if (ch->large && cfg->inv_log) {
+            delete ch;
+            ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "inv_log is not available for gene sets that need the three-pass chain");
+        }
         if (ch->large && chain_large_lds_bytes(ch->max_chr_len, ch->T) > 152 * 1024) {
             delete ch;
             ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "smoothing chain: a single chromosome (plus the window) exceeds the 160 KiB LDS");
@@ -362,6 +369,7 @@ static ChainArgs chain_args(icnv_chain *ch, const double *in) {
     a.n_chr = ch->cfg.n_chr;
     a.T = ch->T;
     a.use_bounds = ch->cfg.use_bounds;
+    a.inv_log = ch->cfg.inv_log;
     a.max_thresh = ch->cfg.max_thresh;
     a.b1 = ch->d_b1.as<double>();
     a.b2 = ch->d_b2.as<double>();
@@ -516,7 +524,7 @@ int icnv_chain_round_finish_dev(icnv_chain_t *ch, int round, void *stream) {
                                          ch->d_den.as<double>(), s);
     double *bounds = (bit == ICNV_ST_SUBTRACT_REF_1) ? ch->d_b1.as<double>() : ch->d_b2.as<double>();
     return launch_bounds_from_sums(ch->d_sums.as<double>(), (int32_t)ch->cfg.G, ch->cfg.n_ref_grp, ch->cfg.use_bounds,
-                                   bounds, s);
+                                   ch->cfg.inv_log, bounds, s);
 }
 
 int icnv_chain_apply_dev(icnv_chain_t *ch, const double *expr_in, double *expr_out, double *pre_denoise,

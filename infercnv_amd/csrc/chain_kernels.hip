@@ -74,12 +74,13 @@ __global__ void reduce_partials_kernel(const double *partial, int nblk, int G, d
 
 // .get_normal_gene_mean_bounds + the min/max / mean-of-means of .subtract_expr
 // (R/inferCNV_ops.R:1708-1735, 1750-1776).  sc = [G*n_grp sums | n_grp counts].
-__global__ void bounds_from_sums_kernel(const double *sc, int G, int n_grp, int use_bounds, double *bounds) {
+__global__ void bounds_from_sums_kernel(const double *sc, int G, int n_grp, int use_bounds, int inv_log, double *bounds) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
     double lo = 0.0, hi = 0.0, tot = 0.0;
     for (int r = 0; r < n_grp; ++r) {
-        const double m = sc[(int64_t)r * G + g] / sc[(int64_t)n_grp * G + r];
+        double m = sc[(int64_t)r * G + g] / sc[(int64_t)n_grp * G + r];
+        if (inv_log) m = log2(m + 1.0);   // the sums are over 2^x - 1 (R/inferCNV_ops.R:1716)
         if (r == 0) { lo = m; hi = m; }
         else { lo = fmin(lo, m); hi = fmax(hi, m); }
         tot += m;
@@ -298,11 +299,11 @@ int launch_reduce_partials(const double *partial, int nblk, int32_t G, double *o
     return ICNV_OK;
 }
 
-int launch_bounds_from_sums(const double *sums_counts, int32_t G, int32_t n_grp, int32_t use_bounds,
+int launch_bounds_from_sums(const double *sums_counts, int32_t G, int32_t n_grp, int32_t use_bounds, int32_t inv_log,
                             double *bounds, hipStream_t stream) {
     KernelTimer kt("bounds_from_sums", stream);
     hipLaunchKernelGGL(bounds_from_sums_kernel, dim3((G + 255) / 256), dim3(256), 0, stream, sums_counts, G, n_grp,
-                       use_bounds, bounds);
+                       use_bounds, inv_log, bounds);
     ICNV_HIP(hipGetLastError());
     return ICNV_OK;
 }

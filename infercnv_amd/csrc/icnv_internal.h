@@ -53,6 +53,7 @@ struct ChainArgs {
     int32_t pad;            // zeros between chromosomes in LDS (set by launch_chain)
     uint32_t mask;          // ICNV_ST_* stages applied in this pass
     int32_t use_bounds;
+    int32_t inv_log;        // MODE_GENE_SUMS with no stage before it: accumulate 2^x - 1 (subtract_ref_expr_from_obs(inv_log = TRUE))
     double max_thresh;
     const double *b1;       // [2*G] lo | hi  (step 8)
     const double *b2;       // [2*G] lo | hi  (step 12)
@@ -101,7 +102,7 @@ int chain_build_inv_table(const int32_t *chr_start, int32_t n_chr, int32_t G, in
                           std::vector<uint32_t> &codes, std::vector<double> &dict, bool &coded);
 int launch_reduce_partials(const double *partial, int nblk, int32_t G, double *out, double count,
                            double *count_out, hipStream_t stream);
-int launch_bounds_from_sums(const double *sums_counts, int32_t G, int32_t n_grp, int32_t use_bounds,
+int launch_bounds_from_sums(const double *sums_counts, int32_t G, int32_t n_grp, int32_t use_bounds, int32_t inv_log,
                             double *bounds, hipStream_t stream);
 int launch_reduce_cell_stats(const double *cell_stats, int32_t n_cells, int32_t G, double *out4,
                              hipStream_t stream);

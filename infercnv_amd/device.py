@@ -47,13 +47,15 @@ def init(device=None):
 
 # ------------------------------------------------------------------ smoothing chain
 def smooth_chain(x, chr_start, ref_groups, window_length=101, max_thresh=3.0, use_bounds=True,
-                 sd_amplifier=1.5, noise_filter=None, stage_mask=_lib.ST_ALL, out=None, want_pre_denoise=False):
+                 sd_amplifier=1.5, noise_filter=None, stage_mask=_lib.ST_ALL, out=None, want_pre_denoise=False,
+                 inv_log=False):
     """Steps 8,9,10,11,12,14,22 of run() (R/inferCNV_ops.R:771-1589) fused on the
-    GPU.  Returns (out, pre_denoise or None)."""
+    GPU.  Returns (out, pre_denoise or None).  inv_log: the stand-alone
+    subtract_ref_expr_from_obs(inv_log=TRUE) (stage_mask must be ST_SUBTRACT_REF_1 alone)."""
     L = _lib.load()
     C, G = _check_matrix(x)
     cfg = Cfg(G, C, chr_start, ref_groups, window_length, max_thresh, use_bounds, sd_amplifier, noise_filter,
-              stage_mask)
+              stage_mask, inv_log)
     if out is None:
         out = torch.empty_like(x)
     pre = torch.empty_like(x) if want_pre_denoise else None

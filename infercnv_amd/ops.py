@@ -24,13 +24,13 @@ def _as_f(a):
 
 
 def _run_chain(obj: InfercnvObject, stage_mask, *, window_length=101, max_thresh=None, use_bounds=True,
-               sd_amplifier=1.5, noise_filter=None, want_pre_denoise=False):
+               sd_amplifier=1.5, noise_filter=None, want_pre_denoise=False, inv_log=False):
     L = _lib.load()
     perm, chr_start = obj.chr_layout()
     x = _as_f(obj.expr_data if perm is None else obj.expr_data[perm])
     G, C = x.shape
     cfg = Cfg(G, C, chr_start, obj.ref_groups_or_proxy(), window_length, max_thresh, use_bounds, sd_amplifier,
-              noise_filter, stage_mask)
+              noise_filter, stage_mask, inv_log)
     out = np.empty_like(x, order="F")
     pre = np.empty_like(x, order="F") if want_pre_denoise else None
     check(L.icnv_smooth_chain(x.ctypes.data_as(ct.c_void_p), out.ctypes.data_as(ct.c_void_p),
@@ -136,11 +136,9 @@ def log2xplus1(infercnv_obj: InfercnvObject) -> InfercnvObject:
 
 # ------------------------------------------------------------------ step 8 / 12
 def subtract_ref_expr_from_obs(infercnv_obj: InfercnvObject, inv_log=False, use_bounds=True) -> InfercnvObject:
-    """R/inferCNV_ops.R:1678-1702.  `inv_log=TRUE` (not used by run()) is not
-    offered by the kernels and raises, rather than silently computing something else."""
-    if inv_log:
-        raise NotImplementedError("inv_log=TRUE is not part of the run() path (R/inferCNV_ops.R:771,952 use FALSE)")
-    out, _ = _run_chain(infercnv_obj, _lib.ST_SUBTRACT_REF_1, use_bounds=use_bounds)
+    """R/inferCNV_ops.R:1678-1702.  `inv_log=TRUE` (not used by run(): :771 and :952 pass FALSE) takes the
+    group means as log2(mean(2^x - 1) + 1) (:1714-1717)."""
+    out, _ = _run_chain(infercnv_obj, _lib.ST_SUBTRACT_REF_1, use_bounds=use_bounds, inv_log=inv_log)
     hs = None
     if infercnv_obj.hspike is not None:  # :1695-1698
         hs = subtract_ref_expr_from_obs(infercnv_obj.hspike, inv_log=inv_log, use_bounds=use_bounds)

@@ -33,21 +33,20 @@
 }
 
 .icnv_chain <- function(infercnv_obj, mask, window_length = 101L, max_thresh = NA_real_, use_bounds = TRUE,
-                        sd_amplifier = 1.5, noise_filter = NA_real_, want_pre = FALSE) {
+                        sd_amplifier = 1.5, noise_filter = NA_real_, want_pre = FALSE, inv_log = FALSE) {
     lay <- .icnv_chr_layout(infercnv_obj)
     ref <- .icnv_pack(.icnv_ref_groups(infercnv_obj))
     x <- as.matrix(infercnv_obj@expr.data)[lay$perm, , drop = FALSE]
     storage.mode(x) <- "double"
     res <- .Call("icnv_R_smooth_chain", x, lay$chr_start, ref$idx, ref$off, as.integer(window_length),
                  as.numeric(max_thresh), as.logical(use_bounds), as.numeric(sd_amplifier),
-                 as.numeric(noise_filter), as.integer(sum(mask)), as.logical(want_pre))
+                 as.numeric(noise_filter), as.integer(sum(mask)), as.logical(want_pre), as.logical(inv_log))
     inv <- order(lay$perm)
     lapply(res, function(m) if (is.null(m)) NULL else m[inv, , drop = FALSE])
 }
 
 hip_subtract_ref_expr_from_obs <- function(infercnv_obj, inv_log = FALSE, use_bounds = TRUE) {
-    if (inv_log) stop("inv_log=TRUE is not offered by the hip backend")
-    infercnv_obj@expr.data <- .icnv_chain(infercnv_obj, .icnv_ST["sub1"], use_bounds = use_bounds)[[1]]
+    infercnv_obj@expr.data <- .icnv_chain(infercnv_obj, .icnv_ST["sub1"], use_bounds = use_bounds, inv_log = inv_log)[[1]]
     if (!is.null(infercnv_obj@.hspike))
         infercnv_obj@.hspike <- hip_subtract_ref_expr_from_obs(infercnv_obj@.hspike, inv_log, use_bounds)
     infercnv_obj

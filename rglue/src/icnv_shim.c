@@ -20,11 +20,12 @@
 
 static void fail(int rc) { Rf_error("libicnv_hip error %d: %s", rc, icnv_last_error()); }
 
-/* .Call("icnv_R_smooth_chain", expr, chr_start, ref_idx, ref_off, window, max_thresh, use_bounds,
+/* .Call("icnv_R_smooth_chain", expr, chr_start, ref_idx, ref_off, window, max_thresh, use_bounds,  [.., inv_log last]
  *       sd_amplifier, noise_filter, stage_mask, want_pre)  ->  list(expr, pre | NULL)
  * expr: REALSXP matrix genes x cells (column-major == cell-major); indices 0-based INTSXP. */
 SEXP icnv_R_smooth_chain(SEXP expr, SEXP chr_start, SEXP ref_idx, SEXP ref_off, SEXP window, SEXP max_thresh,
-                         SEXP use_bounds, SEXP sd_amplifier, SEXP noise_filter, SEXP stage_mask, SEXP want_pre) {
+                         SEXP use_bounds, SEXP sd_amplifier, SEXP noise_filter, SEXP stage_mask, SEXP want_pre,
+                         SEXP inv_log) {
     if (!Rf_isReal(expr) || !Rf_isMatrix(expr)) Rf_error("expr must be a numeric matrix");
     icnv_chain_cfg cfg;
     memset(&cfg, 0, sizeof(cfg));
@@ -35,6 +36,7 @@ SEXP icnv_R_smooth_chain(SEXP expr, SEXP chr_start, SEXP ref_idx, SEXP ref_off, 
     cfg.window_length = Rf_asInteger(window);
     cfg.max_thresh = Rf_asReal(max_thresh);       /* NA_real_ is a NaN: step 9 skipped */
     cfg.use_bounds = Rf_asLogical(use_bounds);
+    cfg.inv_log = Rf_asLogical(inv_log) == TRUE;  /* stand-alone subtract_ref_expr_from_obs(inv_log = TRUE) only */
     cfg.sd_amplifier = Rf_asReal(sd_amplifier);
     cfg.noise_filter = Rf_asReal(noise_filter);
     cfg.stage_mask = (uint32_t)Rf_asInteger(stage_mask);
@@ -132,7 +134,7 @@ SEXP icnv_R_init(SEXP device) {
 }
 
 static const R_CallMethodDef call_methods[] = {
-    {"icnv_R_smooth_chain", (DL_FUNC)&icnv_R_smooth_chain, 11},
+    {"icnv_R_smooth_chain", (DL_FUNC)&icnv_R_smooth_chain, 12},
     {"icnv_R_average_bounds", (DL_FUNC)&icnv_R_average_bounds, 1},
     {"icnv_R_viterbi_cells", (DL_FUNC)&icnv_R_viterbi_cells, 6},
     {"icnv_R_viterbi_groups", (DL_FUNC)&icnv_R_viterbi_groups, 8},

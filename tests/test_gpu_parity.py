@@ -233,6 +233,25 @@ def test_chain_median_edge_cases(dev):
         np.testing.assert_array_equal(to_host(out), want)
 
 
+def test_subtract_ref_inv_log(dev):
+    """subtract_ref_expr_from_obs(inv_log=TRUE): group means as log2(mean(2^x - 1) + 1) (R/inferCNV_ops.R:1714-1717),
+    with and without bounds, several reference groups; only as the stand-alone step."""
+    from infercnv_amd import _lib, synth
+    G, C = 1500, 90
+    x, cs = synth.make_matrix_np(G, C)
+    refs = [np.arange(0, 9, dtype=np.int32), np.array([40, 12, 77, 30], dtype=np.int32), np.array([55], dtype=np.int32)]
+    for use_bounds in (True, False):
+        got, _ = dev.smooth_chain(to_dev(x), cs, refs, stage_mask=_lib.ST_SUBTRACT_REF_1, use_bounds=use_bounds, inv_log=True)
+        want = onp.subtract_ref_expr_from_obs(x, refs, inv_log=True, use_bounds=use_bounds)
+        assert np.abs(to_host(got) - want).max() < 1e-12
+        wantc = oc.subtract_ref_expr_from_obs(x, refs, inv_log=True, use_bounds=use_bounds)
+        assert np.abs(to_host(got) - wantc).max() < 1e-12
+    plain, _ = dev.smooth_chain(to_dev(x), cs, refs, stage_mask=_lib.ST_SUBTRACT_REF_1)
+    assert np.abs(to_host(plain) - to_host(got)).max() > 1e-3            # it is a different statistic
+    with pytest.raises(_lib.IcnvError):                                   # run() never combines it with other stages
+        dev.smooth_chain(to_dev(x), cs, refs, stage_mask=_lib.ST_ALL, inv_log=True)
+
+
 def test_chain_no_reference_cells_uses_all_observations(dev):
     """R/inferCNV_ops.R:1686-1688: without references all cells form one proxy group (host mirror)."""
     from infercnv_amd import GeneOrder, InfercnvObject, ops, synth
