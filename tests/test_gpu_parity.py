@@ -473,6 +473,39 @@ def test_viterbi_groups_and_broadcast(dev):
     np.testing.assert_array_equal(to_host(proxy)[:, member], oc.states_to_proxy(full, 6)[:, member])
 
 
+def test_viterbi_long_chromosomes(dev):
+    """The wave-per-sequence Viterbi (group modes, few columns, flagged sequences) keeps a sequence's back-pointers in
+    LDS up to 4 096 genes per chromosome and in a global scratch beyond: chromosomes of 4 096 and 4 097 genes next to a
+    short one, per-cell (< 64 columns: wave-per-sequence kernel), per-cell on the certified fast path with flagged
+    sequences (redo kernel), and group mode -- all against the oracle, bit for bit."""
+    from infercnv_amd import synth
+    sizes = [4096, 60, 4097]
+    G = sum(sizes)
+    cs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    rng = np.random.default_rng(17)
+    means, sd, logPi, logDelta = synth.hmm_params_i6()
+    for C in (5, 96):
+        state = rng.choice(means, size=(1, C)) + np.where(rng.random((G, C)) < 0.002, 0.5, 0.0).cumsum(axis=0) % 1.0
+        x = state + rng.normal(0.0, 0.12, size=(G, C))
+        if C == 96:
+            x[100, 3] = np.nan            # flagged on the fast path: redone by the wave-per-sequence kernel
+            x[5000, 70] = 1e9
+        st, bad = dev.viterbi_cells(to_dev(x), cs, means, sd, logPi, logDelta)
+        assert dev.viterbi_last_stats()["path"] == ("fast" if C == 96 else "exact")
+        want, wbad = oc.viterbi_cells(x, cs, means, sd, logPi, logDelta)
+        np.testing.assert_array_equal(to_host(st), want)
+        assert int(bad.item()) == wbad
+    groups = [np.arange(0, 30, dtype=np.int32), np.arange(30, 96, dtype=np.int32)]
+    xd = to_dev(x)
+    stg, _ = dev.viterbi_groups(xd, cs, groups, means, [0.05, 0.04], logPi, logDelta)
+    gm = dev.group_means(xd, groups).cpu().numpy().T
+    got = to_host(stg)
+    for q, g in enumerate(groups):
+        want, _ = oc.viterbi_cells(gm[:, q:q + 1], cs, means, [0.05, 0.04][q], logPi, logDelta)
+        np.testing.assert_array_equal(got[:, g[0]], want[:, 0])
+        np.testing.assert_array_equal(got[:, g[-1]], want[:, 0])
+
+
 def test_underflow_is_reported(dev):
     """-Inf in the last nu row -> the reference stop()s (R/inferCNV_HMM.R:1165); we return ICNV_ERR_UNDERFLOW."""
     from infercnv_amd import IcnvError, hmm
