@@ -30,6 +30,11 @@
  *     flavours and are copied to the device by the library.
  *   - The host-buffer flavours upload, run the *_dev path and download.
  *   - Caller owns every buffer it passes; inputs are never modified.
+ *   - Threading: every call acts on the calling thread's current HIP device (icnv_init selects it).  Library state
+ *     (workspace pool, emission-table cache, Viterbi statistics) is kept per device and guarded by mutexes, so
+ *     threads driving DIFFERENT devices may call concurrently.  On one device use ONE stream at a time: scratch
+ *     buffers return to the device's pool when a *_dev call returns while its kernels may still be queued, and the
+ *     next call's work must be ordered behind them (same stream, or a stream the caller has made wait).
  */
 #ifndef ICNV_H
 #define ICNV_H
@@ -180,9 +185,12 @@ int icnv_viterbi_cells_dev(const double *expr, uint8_t *states, int64_t G, int64
  * off-diagonal and one diagonal probability) icnv_viterbi_cells[_dev] computes the emission scores from a
  * verified polynomial table, tests every arg-max decision against a certified error band and recomputes the
  * flagged sequences with the exact kernel: the states are those of the exact kernel, bit for bit.
- *   icnv_viterbi_set_mode   0 = auto (default), 1 = exact kernel only
- *   icnv_viterbi_last_stats out4 = {path of the last call (0 exact / 1 fast), sequences, flagged sequences of
- *                           the last column batch, table intervals}; synchronises with the last call
+ * A column batch with more than 2 % of its sequences flagged is recomputed as a whole by the exact kernel instead
+ * (decided on the device from that batch's own flag count: no state carries over from one call to the next).
+ *   icnv_viterbi_set_mode   0 = auto (default), 1 = exact kernel only; process-wide
+ *   icnv_viterbi_last_stats out4 = {path of the calling thread's device's last call (0 exact / 1 fast / 2 fast,
+ *                           last column batch recomputed by the exact kernel), sequences, flagged sequences of
+ *                           the last column batch, table intervals}; synchronises with that call
  *   icnv_hmm_emission_table host-only: the table for (K, mean, sd); meta8 = {n_intervals, x_lo, x_hi, eps_tab,
  *                           s_max, degree, n_segments, eps_spec}; seg_out [n_seg*4] = {lo, 1/width, base, n-1};
  *                           coef_out [n_intervals*K*(degree+1)] (nullable; polynomials of s_k - s_1, row k = 0 zero);

@@ -1,6 +1,7 @@
 // extern "C" surface of libicnv_hip.so (see include/icnv.h) + host-side
 // orchestration: device workspace pool, descriptor uploads, reference rounds.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -41,8 +42,18 @@ int num_cus() {
 // Grow-only caching allocator so that steady-state calls never hipMalloc/hipFree.
 namespace {
 std::mutex g_pool_mu;
-std::multimap<size_t, void *> g_free;    // size -> block
-std::map<void *, size_t> g_live;         // block -> size
+// Blocks are cached per DEVICE (a block is only ever handed back to the device it was allocated on).  Within a device
+// the pool relies on the single-stream contract of include/icnv.h: a block released by one *_dev call may still be
+// in use by work enqueued on that call's stream, and the next user enqueues on the same stream, i.e. behind it.
+typedef std::pair<int, size_t> PoolKey;  // (device, size)
+std::multimap<PoolKey, void *> g_free;   // (device, size) -> block
+std::map<void *, PoolKey> g_live;        // block -> (device, size)
+
+int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    return dev;
+}
 
 size_t round_size(size_t n) {
     if (n < 256) n = 256;
@@ -56,10 +67,11 @@ size_t round_size(size_t n) {
 
 int pool_alloc(void **p, size_t bytes) {
     const size_t sz = round_size(bytes);
+    const int dev = current_device();
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        auto it = g_free.lower_bound(sz);
-        if (it != g_free.end() && it->first <= sz * 2) {
+        auto it = g_free.lower_bound(PoolKey(dev, sz));
+        if (it != g_free.end() && it->first.first == dev && it->first.second <= sz * 2) {
             *p = it->second;
             g_live[*p] = it->first;
             g_free.erase(it);
@@ -69,11 +81,13 @@ int pool_alloc(void **p, size_t bytes) {
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, sz);
     if (e != hipSuccess) {
-        // release cached blocks and retry once
+        // release this device's cached blocks and retry once
         {
             std::lock_guard<std::mutex> lk(g_pool_mu);
-            for (auto &kv : g_free) (void)hipFree(kv.second);
-            g_free.clear();
+            for (auto it = g_free.begin(); it != g_free.end();) {
+                if (it->first.first == dev) { (void)hipFree(it->second); it = g_free.erase(it); }
+                else ++it;
+            }
         }
         e = hipMalloc(&q, sz);
         if (e != hipSuccess) {
@@ -83,7 +97,7 @@ int pool_alloc(void **p, size_t bytes) {
         }
     }
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    g_live[q] = sz;
+    g_live[q] = PoolKey(dev, sz);
     *p = q;
     return ICNV_OK;
 }
@@ -836,24 +850,42 @@ static void chr_order_longest_first(const int32_t *chr_start, int32_t n_chr, std
 // measured 8.9e-16 (tests/test_viterbi_fast_host.py::test_emission_spec_vs_exact), budgeted three orders of
 // magnitude higher: the band only grows from 9.4e-9 to 1.4e-8 for a 1 072-gene chromosome.
 static constexpr double EPS_SPEC = 1e-12;
-static int g_viterbi_mode = 0;               // 0 = auto (fast when eligible), 1 = exact kernel only
-static int64_t g_viterbi_stats[4] = {0, 0, 0, 0};   // last call: path (0 exact / 1 fast), sequences, flagged, table intervals
+static std::atomic<int> g_viterbi_mode{0};   // 0 = auto (fast when eligible), 1 = exact kernel only (process-wide switch)
+
+// A column batch of the certified fast path whose flagged sequences exceed this share is recomputed as a whole by the
+// lane-per-sequence exact kernel instead of sequence by sequence on the wave-per-sequence redo kernel (which wins only
+// while the list is short).  The decision is taken ON THE DEVICE from the batch's own flag count (both kernels are
+// launched, one of them returns at once): no state survives a call, so which kernels serve a call depends on that
+// call's data alone.
+static constexpr double REDO_MAX_SHARE = 0.02;
 
 namespace {
-struct FastTableCache {
+// State of the per-cell Viterbi of ONE device: the emission table of the last (K, mean, sd), the task / flag counters,
+// the pinned word that receives the flag count of the last column batch and the statistics of the last call.  Guarded
+// by `mu` (a Viterbi call holds it from its first launch to its last enqueue), one instance per device ordinal.
+struct ViterbiCtx {
+    std::mutex mu;
     bool valid = false, eligible = false;
     int K = 0;
     double mean[8] = {0}, sd = 0;
     EmisTable tab;
-    void *dev = nullptr;       // device image, owned (hipMalloc)
+    void *dev = nullptr;           // device image of the table, owned (hipMalloc)
     size_t dev_bytes = 0;
     int32_t *counters = nullptr;   // [0] task counter, [1] flag count, device
-    int32_t *host_flag = nullptr;  // pinned, receives the flag count of the last call
+    int32_t *host_flag = nullptr;  // pinned, receives the flag count of the last column batch
     hipEvent_t flag_ev = nullptr;
-    int64_t flag_seqs = 0;         // sequences of the column batch whose flag count host_flag receives
-    int skip_calls = 0;            // > 0: the fast path flagged too much lately, use the exact kernel directly
+    int64_t stats[4] = {0, 0, 0, 0};   // last call: path (0 exact / 1 fast), sequences, flagged (-1: pending), table intervals
+    int64_t flag_limit = 0;            // of the last column batch: more flagged sequences than this -> exact kernel
 };
-FastTableCache g_fast;
+std::mutex g_vctx_mu;
+std::map<int, ViterbiCtx *> g_vctx;
+ViterbiCtx *viterbi_ctx_ptr() {
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lk(g_vctx_mu);
+    ViterbiCtx *&c = g_vctx[dev];
+    if (!c) c = new ViterbiCtx();
+    return c;
+}
 
 // a = off-diagonal, b = diagonal log transition probability when logPi has that shape (.get_HMM / .i3HMM_get_HMM)
 bool structured_pi(const HmmParams &p, double &a, double &b) {
@@ -869,36 +901,40 @@ bool structured_pi(const HmmParams &p, double &a, double &b) {
 }
 }  // namespace
 
-static int fast_table_for(const HmmParams &p, double sd, hipStream_t s, bool &eligible) {
-    FastTableCache &c = g_fast;
+// caller holds c.mu
+static int fast_table_for(ViterbiCtx &c, const HmmParams &p, double sd, hipStream_t s, bool &eligible) {
     eligible = false;
-    if (!(c.valid && c.K == p.K && c.sd == sd && memcmp(c.mean, p.mean, sizeof(double) * p.K) == 0)) {
-        c.valid = true;
-        c.K = p.K;
-        c.sd = sd;
-        memcpy(c.mean, p.mean, sizeof(c.mean));
-        const char *why = nullptr;
-        c.eligible = build_emission_table(p.K, p.mean, sd, viterbi_fast_max_intervals(p.K), c.tab, &why) == 0;
-        if (c.eligible) {
-            std::vector<double> img;
-            viterbi_fast_table_image(c.tab, img);
-            const size_t bytes = img.size() * sizeof(double);
-            if (bytes > c.dev_bytes) {
-                if (c.dev) (void)hipFree(c.dev);
-                c.dev = nullptr;
-                ICNV_HIP(hipMalloc(&c.dev, bytes));
-                c.dev_bytes = bytes;
-            }
-            ICNV_HIP(hipMemcpy(c.dev, img.data(), bytes, hipMemcpyHostToDevice));
-        }
-    }
     if (!c.counters) {
         ICNV_HIP(hipMalloc((void **)&c.counters, 2 * sizeof(int32_t)));
         ICNV_HIP(hipHostMalloc((void **)&c.host_flag, sizeof(int32_t)));
         *c.host_flag = 0;
         ICNV_HIP(hipEventCreateWithFlags(&c.flag_ev, hipEventDisableTiming));
     }
-    (void)s;
+    if (!(c.valid && c.K == p.K && c.sd == sd && memcmp(c.mean, p.mean, sizeof(double) * p.K) == 0)) {
+        c.valid = false;   // set again only once the table is built AND its device image is in place
+        const char *why = nullptr;
+        const bool ok = build_emission_table(p.K, p.mean, sd, viterbi_fast_max_intervals(p.K), c.tab, &why) == 0;
+        if (ok) {
+            std::vector<double> img;
+            viterbi_fast_table_image(c.tab, img);
+            const size_t bytes = img.size() * sizeof(double);
+            if (bytes > c.dev_bytes) {
+                if (c.dev) (void)hipFree(c.dev);
+                c.dev = nullptr;
+                c.dev_bytes = 0;
+                ICNV_HIP(hipMalloc(&c.dev, bytes));
+                c.dev_bytes = bytes;
+            }
+            // the previous table may still be read by work queued on the stream: order the upload behind it
+            ICNV_HIP(hipStreamSynchronize(s));
+            ICNV_HIP(hipMemcpy(c.dev, img.data(), bytes, hipMemcpyHostToDevice));
+        }
+        c.K = p.K;
+        c.sd = sd;
+        memcpy(c.mean, p.mean, sizeof(c.mean));
+        c.eligible = ok;
+        c.valid = true;
+    }
     eligible = c.eligible;
     return ICNV_OK;
 }
@@ -917,29 +953,18 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
     int32_t max_len = 0;
     for (int k = 0; k < n_chr; ++k) max_len = std::max(max_len, chr_start[k + 1] - chr_start[k]);
 
+    ViterbiCtx &vc = *viterbi_ctx_ptr();
+    std::lock_guard<std::mutex> vlk(vc.mu);
     // the certified fast path needs a shared sd, the .get_HMM transition structure and a table that met its accuracy target
     bool fast = false;
     double a = 0, b = 0;
-    if (g_viterbi_mode == 0 && !sd_per_col_dev && ncols >= 64 && structured_pi(p, a, b)) {
-        if ((rc = fast_table_for(p, sd_shared, s, fast))) return rc;
-        // Data the table cannot score (outside its domain, non-finite) or riddled with exact ties is flagged and
-        // redone exactly: right, but slower than the exact kernel alone.  When the last finished call had more
-        // than 5 % of its sequences flagged, the next eight calls skip the fast path (no synchronisation: the
-        // count arrives in pinned memory and is only read once its event has completed).
-        if (fast && g_fast.flag_seqs > 0 && g_fast.flag_ev && hipEventQuery(g_fast.flag_ev) == hipSuccess) {
-            if ((double)*g_fast.host_flag > 0.05 * (double)g_fast.flag_seqs) g_fast.skip_calls = 8;
-            g_fast.flag_seqs = 0;
-        }
-        (void)hipGetLastError();   // hipEventQuery reports "not ready" as an error code
-        if (fast && g_fast.skip_calls > 0) {
-            --g_fast.skip_calls;
-            fast = false;
-        }
+    if (g_viterbi_mode.load() == 0 && !sd_per_col_dev && ncols >= 64 && structured_pi(p, a, b)) {
+        if ((rc = fast_table_for(vc, p, sd_shared, s, fast))) return rc;
     }
-    g_viterbi_stats[0] = fast ? 1 : 0;
-    g_viterbi_stats[1] = ncols * n_chr;
-    g_viterbi_stats[2] = fast ? -1 : 0;
-    g_viterbi_stats[3] = fast ? g_fast.tab.n_int : 0;
+    vc.stats[0] = fast ? 1 : 0;
+    vc.stats[1] = ncols * n_chr;
+    vc.stats[2] = fast ? -1 : 0;
+    vc.stats[3] = fast ? vc.tab.n_int : 0;
 
     // Few sequences (the group modes: one column per subcluster / sample): the lane-per-sequence kernel would take
     // as long as its longest chromosome on one lane (~2 ms); the wave-per-sequence kernel -- the redo kernel run
@@ -955,19 +980,20 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
         if ((rc = upload(d_all, list.data(), list.size(), s))) return rc;
         if ((rc = d_scr.alloc(viterbi_redo_scratch_bytes(max_len)))) return rc;
         return launch_viterbi_redo(x, states, (int32_t)G, d_chr.as<int32_t>(), p, sd_per_col_dev, sd_shared,
-                                   d_all.as<int32_t>() + 2 * (size_t)count, d_all.as<int32_t>(), d_scr.as<uint32_t>(),
+                                   d_all.as<int32_t>() + 2 * (size_t)count, d_all.as<int32_t>(), 0x7fffffff, d_scr.as<uint32_t>(),
                                    n_underflow_dev, max_len, "viterbi", s);
     }
-    const int64_t bp_elem = fast ? 2 : 4;
+    // the scratch holds the exact kernel's 4-byte back-pointer words; the fast kernel's 2-byte words use its first half
+    // (the exact kernel only runs after the fast kernel of the same batch has finished with them)
     int64_t scratch_budget = (int64_t)4 << 30;   // back-pointer scratch per column batch
     if (const char *e = std::getenv("ICNV_VITERBI_SCRATCH_MB")) {   // developer switch: small batches for the tests
         const long v = std::atol(e);
         if (v > 0) scratch_budget = (int64_t)v << 20;
     }
-    int64_t batch = scratch_budget / ((int64_t)G * bp_elem);
+    int64_t batch = scratch_budget / ((int64_t)G * 4);
     batch = std::max<int64_t>(64, (batch / 64) * 64);
     batch = std::min(batch, ((ncols + 63) / 64) * 64);
-    if ((rc = d_bp.alloc((size_t)G * (size_t)batch * (size_t)bp_elem))) return rc;
+    if ((rc = d_bp.alloc((size_t)G * (size_t)batch * 4))) return rc;
     if (fast) {
         if ((rc = d_list.alloc((size_t)2 * n_chr * batch * sizeof(int32_t)))) return rc;
         if ((rc = d_redo.alloc(viterbi_redo_scratch_bytes(max_len)))) return rc;
@@ -977,7 +1003,7 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
         if (!fast) {
             rc = launch_viterbi(x + c0 * G, states + c0 * G, (int32_t)G, nc, d_chr.as<int32_t>(), d_ord.as<int32_t>(), n_chr,
                                 0, p, sd_per_col_dev ? sd_per_col_dev + c0 : nullptr, sd_shared, d_bp.as<uint32_t>(),
-                                n_underflow_dev, s);
+                                n_underflow_dev, nullptr, 0, s);
             if (rc) return rc;
             continue;
         }
@@ -990,8 +1016,8 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
         fa.chr_start = d_chr.as<int32_t>();
         fa.chr_order = d_ord.as<int32_t>();
         fa.n_chr = n_chr;
-        fa.table = (const double *)g_fast.dev;
-        fa.n_int = g_fast.tab.n_int;
+        fa.table = (const double *)vc.dev;
+        fa.n_int = vc.tab.n_int;
         double dmax = 0.0;
         for (int k = 0; k < p.K; ++k) {
             fa.mean[k] = p.mean[k];
@@ -1000,45 +1026,54 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
         }
         fa.a = a;
         fa.b = b;
-        fa.x_lo = g_fast.tab.x_lo;
-        fa.x_hi = g_fast.tab.x_hi;
-        fa.cell_lo = g_fast.tab.cell_lo;
-        fa.inv_wc = g_fast.tab.inv_wc;
-        fa.n_cells_m1 = g_fast.tab.n_cells - 1;
-        fa.eps = g_fast.tab.eps_tab + 2.0 * EPS_SPEC;   // table: s_k - s_1; the exact kernel's difference carries two of its errors
+        fa.x_lo = vc.tab.x_lo;
+        fa.x_hi = vc.tab.x_hi;
+        fa.cell_lo = vc.tab.cell_lo;
+        fa.inv_wc = vc.tab.inv_wc;
+        fa.n_cells_m1 = vc.tab.n_cells - 1;
+        fa.eps = vc.tab.eps_tab + 2.0 * EPS_SPEC;   // table: s_k - s_1; the exact kernel's difference carries two of its errors
         fa.b0 = dmax + std::fabs(a);
-        fa.s_step = g_fast.tab.s_max + std::fabs(b);
+        fa.s_step = vc.tab.s_max + std::fabs(b);
         fa.bp = d_bp.as<uint16_t>();
-        fa.task_counter = g_fast.counters;
-        fa.flag_count = g_fast.counters + 1;
+        fa.task_counter = vc.counters;
+        fa.flag_count = vc.counters + 1;
         fa.flag_list = d_list.as<int32_t>();
-        ICNV_HIP(hipMemsetAsync(g_fast.counters, 0, 2 * sizeof(int32_t), s));
+        ICNV_HIP(hipMemsetAsync(vc.counters, 0, 2 * sizeof(int32_t), s));
         if ((rc = launch_viterbi_fast(fa, p.K, s))) return rc;
+        // flagged sequences: a short list goes to the wave-per-sequence redo kernel; a batch with more than
+        // REDO_MAX_SHARE of its sequences flagged (data the table cannot score, or riddled with exact ties) is
+        // recomputed as a whole by the lane-per-sequence exact kernel.  Both are launched, the flag count -- on the
+        // device -- decides which of them does the work.
+        const int32_t limit = (int32_t)std::min<double>(REDO_MAX_SHARE * (double)(nc * n_chr), 2e9);
         if ((rc = launch_viterbi_redo(fa.x, fa.states, (int32_t)G, d_chr.as<int32_t>(), p, nullptr, sd_shared, fa.flag_count,
-                                      fa.flag_list, d_redo.as<uint32_t>(), n_underflow_dev, max_len, "viterbi_redo", s)))
+                                      fa.flag_list, limit, d_redo.as<uint32_t>(), n_underflow_dev, max_len, "viterbi_redo", s)))
             return rc;
-        ICNV_HIP(hipMemcpyAsync(g_fast.host_flag, fa.flag_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        ICNV_HIP(hipEventRecord(g_fast.flag_ev, s));
-        g_fast.flag_seqs = nc * n_chr;
+        if ((rc = launch_viterbi(fa.x, fa.states, (int32_t)G, nc, d_chr.as<int32_t>(), d_ord.as<int32_t>(), n_chr, 0, p, nullptr,
+                                 sd_shared, d_bp.as<uint32_t>(), n_underflow_dev, fa.flag_count, limit, s)))
+            return rc;
+        ICNV_HIP(hipMemcpyAsync(vc.host_flag, fa.flag_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        ICNV_HIP(hipEventRecord(vc.flag_ev, s));
+        vc.flag_limit = limit;
     }
     return ICNV_OK;
 }
 
 int icnv_viterbi_set_mode(int mode) {
     if (mode != 0 && mode != 1) ICNV_FAIL(ICNV_ERR_ARG, "mode must be 0 (auto) or 1 (exact kernel only)");
-    g_viterbi_mode = mode;
-    g_fast.skip_calls = 0;   // also forgets the "flagged too much lately" state of the adaptive skip
-    g_fast.flag_seqs = 0;
+    g_viterbi_mode.store(mode);
     return ICNV_OK;
 }
 
 int icnv_viterbi_last_stats(int64_t *out4) {
     if (!out4) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
-    if (g_viterbi_stats[0] == 1 && g_fast.flag_ev) {
-        ICNV_HIP(hipEventSynchronize(g_fast.flag_ev));
-        g_viterbi_stats[2] = *g_fast.host_flag;   // of the last column batch
+    ViterbiCtx &vc = *viterbi_ctx_ptr();
+    std::lock_guard<std::mutex> vlk(vc.mu);
+    if (vc.stats[0] >= 1 && vc.flag_ev) {
+        ICNV_HIP(hipEventSynchronize(vc.flag_ev));
+        vc.stats[2] = *vc.host_flag;   // of the last column batch
+        vc.stats[0] = (vc.stats[2] > vc.flag_limit) ? 2 : 1;   // 2: that batch was recomputed by the exact kernel
     }
-    for (int i = 0; i < 4; ++i) out4[i] = g_viterbi_stats[i];
+    for (int i = 0; i < 4; ++i) out4[i] = vc.stats[i];
     return ICNV_OK;
 }
 

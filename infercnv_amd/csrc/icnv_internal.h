@@ -132,7 +132,7 @@ struct HmmParams {
 int launch_viterbi(const double *x, uint8_t *states, int32_t G, int64_t n_seq_cols, const int32_t *chr_start_dev,
                    const int32_t *chr_order_dev, int32_t n_chr, int32_t max_chr_len, const HmmParams &p,
                    const double *sd_per_col_dev, double sd_shared, uint32_t *bp_scratch, int32_t *n_underflow,
-                   hipStream_t stream);
+                   const int32_t *gate_dev, int32_t gate_limit, hipStream_t stream);   // gate_dev: run only if *gate_dev > gate_limit
 size_t viterbi_scratch_bytes(int32_t G, int64_t n_cols);
 
 // certified fast path (viterbi_fast.hip): table-driven scores + decision-margin test, flagged sequences redone exactly
@@ -169,7 +169,8 @@ int viterbi_redo_slots();
 size_t viterbi_redo_scratch_bytes(int32_t max_chr_len);
 int launch_viterbi_redo(const double *x, uint8_t *states, int32_t G, const int32_t *chr_start_dev, const HmmParams &p,
                         const double *sd_per_col_dev, double sd_shared, const int32_t *flag_count_dev,
-                        const int32_t *flag_list_dev, uint32_t *bp_redo, int32_t *n_underflow, int32_t max_chr_len, const char *timer_name,
+                        const int32_t *flag_list_dev, int32_t max_count /* lists longer than this are left alone */,
+                        uint32_t *bp_redo, int32_t *n_underflow, int32_t max_chr_len, const char *timer_name,
                         hipStream_t stream);
 int group_means_nsplit(int32_t G, int32_t n_grp);
 int launch_group_means_ws(const double *x, int32_t G, const int32_t *grp_idx_dev, const int32_t *grp_off_dev,

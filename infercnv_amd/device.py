@@ -186,11 +186,13 @@ def viterbi_set_mode(mode):
 
 
 def viterbi_last_stats():
-    """{path, sequences, flagged, table_intervals} of the last per-cell Viterbi call (synchronises with it)."""
+    """{path, sequences, flagged, table_intervals, fallback} of the last per-cell Viterbi call on this device
+    (synchronises with it).  path "fast": the certified fast kernel ran; fallback: its last column batch had so many
+    flagged sequences that the exact kernel recomputed the whole batch (decided on the device, per batch)."""
     buf = (ct.c_int64 * 4)()
     check(_lib.load().icnv_viterbi_last_stats(buf))
-    return {"path": "fast" if buf[0] == 1 else "exact", "sequences": int(buf[1]), "flagged": int(buf[2]),
-            "table_intervals": int(buf[3])}
+    return {"path": "fast" if buf[0] >= 1 else "exact", "sequences": int(buf[1]), "flagged": int(buf[2]),
+            "table_intervals": int(buf[3]), "fallback": buf[0] == 2}
 
 
 def viterbi_groups(x, chr_start, groups, means, sd_shared_per_group, logPi, logDelta, states=None):

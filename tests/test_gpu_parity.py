@@ -34,6 +34,14 @@ def dev():
     return device
 
 
+@pytest.fixture(autouse=True)
+def _default_viterbi_mode(dev):
+    """Every test starts from the library's default Viterbi mode (auto), whatever an earlier test left behind."""
+    dev.viterbi_set_mode(0)
+    yield
+    dev.viterbi_set_mode(0)
+
+
 def to_dev(x_gc):
     """(G, C) host matrix -> (C, G) contiguous CUDA tensor (same bytes as R's column-major G x C)."""
     return torch.from_numpy(np.ascontiguousarray(np.asarray(x_gc, dtype=np.float64).T)).cuda()
@@ -317,6 +325,37 @@ def test_viterbi_fast_path_equals_exact_kernel_and_oracle(dev):
 
 
 @pytest.mark.parametrize("seed", list(range(10)))
+def test_viterbi_flag_share_decides_redo_or_exact_fallback_on_device(dev):
+    """A column batch with at most 2 % of its sequences flagged goes to the wave-per-sequence redo kernel, a batch with
+    more is recomputed by the exact kernel -- decided on the device from the batch's own count, so the same call
+    gives the same path whatever ran before it (the round-1 library carried a process-global 'skip the fast path for
+    the next 8 calls' counter).  States are the exact kernel's either way."""
+    from infercnv_amd import synth
+    pre, cs = _hmm_input(2000, 640, seed=33)
+    means, sd, logPi, logDelta = synth.hmm_params_i6()
+    nseq = 22 * 640
+    heavy = pre.copy()
+    heavy[7, ::4] = np.nan                      # one flagged sequence in every fourth cell: 160 of 14 080 = 1.1 % ...
+    heavy[1990, ::2] = 1e9                      # ... plus one in every second: 2.3 % + 1.1 % > 2 %
+    light = pre.copy()
+    light[7, ::8] = np.nan                      # 80 of 14 080 = 0.6 %
+    want = {}
+    dev.viterbi_set_mode(1)
+    for name, x in (("heavy", heavy), ("light", light)):
+        want[name], _ = dev.viterbi_cells(to_dev(x), cs, means, sd, logPi, logDelta)
+        assert dev.viterbi_last_stats()["path"] == "exact"
+    dev.viterbi_set_mode(0)
+    for name, x, fb in (("heavy", heavy, True), ("light", light, False), ("heavy", heavy, True), ("light", light, False)):
+        st, _ = dev.viterbi_cells(to_dev(x), cs, means, sd, logPi, logDelta)
+        stats = dev.viterbi_last_stats()
+        assert stats["path"] == "fast" and stats["sequences"] == nseq and stats["fallback"] is fb, (name, stats)
+        assert (stats["flagged"] > 0.02 * nseq) is fb
+        assert torch.equal(st, want[name])
+    o, _ = oc.viterbi_cells(heavy[:, :8], cs, means, sd, logPi, logDelta)
+    np.testing.assert_array_equal(to_host(want["heavy"])[:, :8], o)
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
 def test_viterbi_fast_path_random_models(dev, seed):
     """Random HMMs (3 or 6 states, random increasing means with gaps of 0.3 .. 4 sd, random sd and transition
     probability) on data built to stress the certified path -- values at the state means and mid-points, at the
@@ -363,8 +402,8 @@ def test_viterbi_fast_path_random_models(dev, seed):
 
 def test_viterbi_column_batches(dev, monkeypatch):
     """The back-pointer scratch bounds the columns of one launch (4 GiB by default: 214 000 cells at 10 000 genes);
-    more cells run as several column batches.  A 1 MiB budget splits 700 cells x 1 500 genes into batches of 320 (fast
-    path, 2-byte back-pointers) / 128 (exact kernel, 4-byte) columns; every batch, the partial last one and the
+    more cells run as several column batches.  A 1 MiB budget splits 700 cells x 1 500 genes into batches of 128
+    columns (the scratch is sized for the exact kernel's 4-byte words on either path); every batch, the partial last one and the
     foreign values that send sequences of different batches to the redo kernel must give the single-launch states."""
     from infercnv_amd import synth
     pre, cs = _hmm_input(1500, 700, seed=9)
