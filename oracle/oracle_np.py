@@ -398,20 +398,29 @@ def get_HMM_i3(t=1e-6):
     return Pi, delta
 
 
-def emission_scores(x, means, sd, log=icnv_log):
-    """R/inferCNV_HMM.R:1129-1133 / 1156-1160 for a vector of x: (len(x), K)."""
+def emission_scores(x, means, sd, log=icnv_log, long_double_sum=False):
+    """R/inferCNV_HMM.R:1129-1133 / 1156-1160 for a vector of x: (len(x), K).
+    long_double_sum: accumulate sum(emission) in the platform's long double (80-bit on x86) and round the total to
+    double once, as R's sum() does (rsum, src/main/summary.c); the default is the spec'd left-to-right double sum
+    that the C oracle and the HIP kernels execute (DESIGN.md "Arithmetic spec")."""
     x = np.asarray(x, dtype=np.float64)
     z = np.abs(x[..., None] - means) / sd
     lp = pnorm_log_upper(z, log=log)
     e = 1.0 / (-1.0 * lp)
-    tot = e[..., 0].copy()
-    for k in range(1, e.shape[-1]):      # sum() left to right (long double in R;
-        tot = tot + e[..., k]            # the double sum is the spec'd order here)
+    if long_double_sum:
+        tot = e[..., 0].astype(np.longdouble)
+        for k in range(1, e.shape[-1]):
+            tot = tot + e[..., k].astype(np.longdouble)
+        tot = tot.astype(np.float64)
+    else:
+        tot = e[..., 0].copy()
+        for k in range(1, e.shape[-1]):      # sum() left to right (long double in R;
+            tot = tot + e[..., k]            # the double sum is the spec'd order here)
     e = e / tot[..., None]
     return log(e)
 
 
-def viterbi_dthmm_adj(x, means, sd_vec, Pi, delta, log=icnv_log):
+def viterbi_dthmm_adj(x, means, sd_vec, Pi, delta, log=icnv_log, long_double_sum=False):
     """R/inferCNV_HMM.R:1101-1176 for a batch: x is (n, S) -- S independent
     sequences of one chromosome.  Returns 1-based states (n, S) int8 and a
     flag array (S,) that is True where the reference would stop() with
@@ -428,10 +437,10 @@ def viterbi_dthmm_adj(x, means, sd_vec, Pi, delta, log=icnv_log):
     with np.errstate(divide="ignore"):
         logPi = np.log(np.asarray(Pi, dtype=np.float64))
         logdelta = np.log(np.asarray(delta, dtype=np.float64))
-    return viterbi_core(x, means, sd, logPi, logdelta, log=log)
+    return viterbi_core(x, means, sd, logPi, logdelta, log=log, long_double_sum=long_double_sum)
 
 
-def viterbi_core(x, means, sd, logPi, logdelta, log=icnv_log):
+def viterbi_core(x, means, sd, logPi, logdelta, log=icnv_log, long_double_sum=False, return_margin=False):
     """The DP itself, with log(Pi), log(delta) and the shared sd already
     prepared on the host (this is what the C-ABI entry point receives)."""
     n, S = x.shape
@@ -439,13 +448,22 @@ def viterbi_core(x, means, sd, logPi, logdelta, log=icnv_log):
     if n < 2:
         return np.full((n, S), 3, dtype=np.int8), np.zeros(S, dtype=bool)
     bp = np.zeros((n, S, K), dtype=np.int8)
-    nu = logdelta[None, :] + emission_scores(x[0], means, sd, log=log)       # (S, K)
+    nu = logdelta[None, :] + emission_scores(x[0], means, sd, log=log, long_double_sum=long_double_sum)   # (S, K)
+    margin = np.full(S, np.inf)     # smallest lead of a winning candidate over the runner-up, any gene / state
     for i in range(1, n):
-        sc = emission_scores(x[i], means, sd, log=log)
+        sc = emission_scores(x[i], means, sd, log=log, long_double_sum=long_double_sum)
         cand = nu[:, :, None] + logPi[None, :, :]                            # [s, j, k]
         bp[i] = np.argmax(cand, axis=1)                                      # first max over j
+        if return_margin:
+            top2 = np.sort(cand, axis=1)[:, -2:, :]
+            with np.errstate(invalid="ignore"):
+                margin = np.fmin(margin, np.min(top2[:, 1, :] - top2[:, 0, :], axis=1))
         nu = np.max(cand, axis=1) + sc
     bad = np.any(nu == -np.inf, axis=1)
+    if return_margin:
+        top2 = np.sort(nu, axis=1)[:, -2:]
+        with np.errstate(invalid="ignore"):
+            margin = np.fmin(margin, top2[:, 1] - top2[:, 0])
     y = np.zeros((n, S), dtype=np.int64)
     y[n - 1] = np.argmax(nu, axis=1)
     rows = np.arange(S)
@@ -453,6 +471,8 @@ def viterbi_core(x, means, sd, logPi, logdelta, log=icnv_log):
         # which.max(logPi[, y[i+1]] + nu[i, ]) == argmax_j(nu[i-th row][j] + logPi[j, y]) ==
         # the back-pointer recorded when row i+1 was computed (same addends, first max)
         y[i] = bp[i + 1, rows, y[i + 1]]
+    if return_margin:
+        return (y + 1).astype(np.int8), bad, margin
     return (y + 1).astype(np.int8), bad
 
 

@@ -324,7 +324,6 @@ def test_viterbi_fast_path_equals_exact_kernel_and_oracle(dev):
         dev.viterbi_set_mode(0)
 
 
-@pytest.mark.parametrize("seed", list(range(10)))
 def test_viterbi_flag_share_decides_redo_or_exact_fallback_on_device(dev):
     """A column batch with at most 2 % of its sequences flagged goes to the wave-per-sequence redo kernel, a batch with
     more is recomputed by the exact kernel -- decided on the device from the batch's own count, so the same call
