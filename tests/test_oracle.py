@@ -280,7 +280,7 @@ def test_viterbi_groups_c_vs_numpy():
 
 def test_hmm_states_fixture_sanity(golden_dir, example, example_log):
     """data/HMM_states.rda came from RNG-derived emission parameters, so it can
-    only be approached (<= 99.1 %).  Guard against gross errors."""
+    only be approached (99.1 %); tests/test_hmm_pin.py pins the exact mismatch count."""
     hs = np.load(os.path.join(golden_dir, "hmm_states_example.npz"))
     gold, mu = hs["HMM_states"], hs["mu"]
     cs = oc.chr_starts_from_codes(example["chr_codes"])
@@ -289,7 +289,7 @@ def test_hmm_states_fixture_sanity(golden_dir, example, example_log):
     Pi, delta = onp.get_HMM_i6(1e-6)
     st, _ = oc.viterbi_groups(pre, cs, groups, mu, [0.24, 0.24], np.log(Pi), np.log(delta))
     agree = (st == gold.astype(np.uint8)).mean()
-    assert agree > 0.97, agree
+    assert abs(agree - 9142 / 9226) < 1e-12, agree
 
 
 def test_median_filter_c_vs_numpy():
