@@ -34,6 +34,10 @@ def _i3HMM_get_HMM(sd_trend, t, i3_p_val=0.05, use_KS=False):
     np.fill_diagonal(Pi, 1 - 5 * t)
     delta = np.array([t, 1 - 5 * t, t], dtype=np.float64)
     mu, sigma = sd_trend["mu"], sd_trend["sigma"]
+    if use_KS and sd_trend.get("KS_delta") is None:
+        raise NotImplementedError(
+            "use_KS=TRUE: the KS-based mean delta (get_HoneyBADGER_setGexpDev, R/inferCNV_i3HMM.R:469-493) is estimated "
+            "from rnorm() draws of R's RNG stream and stays in R; pass it as sd_trend['KS_delta']")
     mean_delta = sd_trend["KS_delta"] if use_KS else sd_trend["mean_delta"]
     return {"state_transitions": Pi, "delta": delta,
             "state_emission_params": {"mean": np.array([mu - mean_delta, mu, mu + mean_delta]),

@@ -15,6 +15,12 @@ Sources (all under /root/reference):
   data/mcmc_obj.rda                 -- realistic i6 emission means / precisions.
   inst/extdata/gencode_downsampled.EXAMPLE_ONLY_DONT_REUSE.txt -- genes per chr
       used to shape the synthetic benchmark.
+  inst/extdata/oligodendroglioma_{expression_downsampled.counts.matrix.gz,
+      annotations_downsampled.txt} + the gene-position file -- the inputs of
+      example/run.R (BASELINE.json configs[0]): CreateInfercnvObject
+      (R/inferCNV.R:133-345) replayed here -> example_run_inputs.npz (the object
+      as run() receives it: ordered count matrix, gene_order, reference /
+      observation groups).
 """
 import os
 import sys
@@ -26,6 +32,84 @@ sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
 import rda  # noqa: E402
 
 REF = "/root/reference"
+
+
+def example_run_inputs():
+    """CreateInfercnvObject (R/inferCNV.R:133-345) on example/run.R's inputs, with its defaults
+    chr_exclude = c('chrX','chrY','chrM'), min_max_counts_per_cell = c(100, +Inf), max_cells_per_group = NULL and
+    ref_group_names = c("Microglia/Macrophage", "Oligodendrocytes (non-malignant)") (example/run.R:8-12).
+    The matrix values are decimals with at most 6 significant digits: stored as integer mantissa / power of ten
+    (value = mant / 10**neg_exp, exactly the double read.table() parses), which compresses to half of the doubles."""
+    import gzip
+    from decimal import Decimal
+    ext = f"{REF}/inst/extdata"
+    with gzip.open(f"{ext}/oligodendroglioma_expression_downsampled.counts.matrix.gz", "rt") as fh:
+        cells = fh.readline().rstrip("\n").split("\t")
+        genes, rows = [], []
+        for line in fh:
+            p = line.rstrip("\n").split("\t")
+            genes.append(p[0])
+            rows.append(p[1:])
+    genes = np.array(genes)
+    mant = np.zeros((len(genes), len(cells)), dtype=np.int64)
+    nexp = np.zeros((len(genes), len(cells)), dtype=np.int8)
+    for i, r in enumerate(rows):
+        for j, tok in enumerate(r):
+            if tok == "0":
+                continue
+            sign, digits, e = Decimal(tok).as_tuple()
+            assert sign == 0 and e <= 0 and -e <= 22
+            m = int("".join(map(str, digits)))
+            assert m < 2 ** 31
+            mant[i, j], nexp[i, j] = m, -e
+            assert m / 10.0 ** (-e) == float(tok)          # one correctly rounded division == strtod
+    # gene positions; chr_exclude (:189-191)
+    pos_name, pos_chr, pos_start, pos_stop = [], [], [], []
+    with open(f"{ext}/gencode_downsampled.EXAMPLE_ONLY_DONT_REUSE.txt") as fh:
+        for line in fh:
+            g, c, a, b = line.rstrip("\n").split("\t")
+            if c in ("chrX", "chrY", "chrM"):
+                continue
+            pos_name.append(g); pos_chr.append(c); pos_start.append(int(a)); pos_stop.append(int(b))
+    assert len(set(pos_name)) == len(pos_name)
+    # .order_reduce (R/inferCNV.R:352-428): drop start+stop == 0, keep genes present in both (matrix order), chr levels
+    # in order of first appearance in the position table, stable order(chr, start, stop)
+    ok = [i for i in range(len(pos_name)) if pos_start[i] + pos_stop[i] != 0]
+    chr_levels = list(dict.fromkeys(pos_chr[i] for i in ok))
+    where = {pos_name[i]: i for i in ok}
+    keep = [gi for gi, g in enumerate(genes) if g in where]
+    key = sorted(range(len(keep)), key=lambda k: (chr_levels.index(pos_chr[where[genes[keep[k]]]]),
+                                                 pos_start[where[genes[keep[k]]]], pos_stop[where[genes[keep[k]]]]))
+    gene_rows = np.array([keep[k] for k in key])
+    chr_codes = np.array([chr_levels.index(pos_chr[where[genes[g]]]) for g in gene_rows], dtype=np.int32)
+    used = sorted(set(chr_codes.tolist()))                 # droplevels (:240)
+    chr_levels = [chr_levels[c] for c in used]
+    chr_codes = np.searchsorted(np.array(used), chr_codes).astype(np.int32)
+    mant, nexp = mant[gene_rows], nexp[gene_rows]
+    x = mant / 10.0 ** nexp.astype(np.float64)
+    # cells: colSums filter (:253-266), annotated cells only, classifications in matrix column order (:290-300)
+    cs = x.sum(axis=0)
+    keep_c = np.nonzero((cs >= 100) & (cs <= np.inf))[0]
+    annot = {}
+    with open(f"{ext}/oligodendroglioma_annotations_downsampled.txt") as fh:
+        for line in fh:
+            c, a = line.rstrip("\n").split("\t")
+            annot[c] = a
+    assert all(c in cells for c in annot)
+    keep_c = np.array([j for j in keep_c if cells[j] in annot])
+    mant, nexp = mant[:, keep_c], nexp[:, keep_c]
+    cls = np.array([annot[cells[j]] for j in keep_c])
+    ref_names = ["Microglia/Macrophage", "Oligodendrocytes (non-malignant)"]
+    obs_names = sorted(set(cls) - set(ref_names))
+    out = dict(mant=mant.astype(np.int32), neg_exp=nexp, chr_codes=chr_codes, chr_levels=np.array(chr_levels),
+               ref_names=np.array(ref_names), obs_names=np.array(obs_names))
+    for i, n in enumerate(ref_names):
+        out[f"ref_{i}"] = np.nonzero(cls == n)[0].astype(np.int32)
+    for i, n in enumerate(obs_names):
+        out[f"obs_{i}"] = np.nonzero(cls == n)[0].astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, "example_run_inputs.npz"), **out)
+    print("example/run.R inputs:", mant.shape, "chr", len(chr_levels), "refs", [len(out[f"ref_{i}"]) for i in range(2)],
+          "obs", {n: len(out[f"obs_{i}"]) for i, n in enumerate(obs_names)})
 
 
 def main():
@@ -69,6 +153,7 @@ def main():
             fh.write(f"{c}\t{n}\n")
     print("expr", expr.shape, "counts", counts.shape, "chr levels", len(chr_levels),
           "HMM_states", hs.shape, "chr counts", counts_by_chr)
+    example_run_inputs()
 
 
 if __name__ == "__main__":

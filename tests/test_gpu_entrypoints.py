@@ -1,0 +1,230 @@
+"""GPU parity tests (-m gpu) of BASELINE.json configs[0] -- example/run.R's real inputs -- and of the C-ABI entry
+points / host-mirror functions that had no GPU test in round 1 (VERDICT r01 "untested entry points"):
+icnv_average_bounds[_dev] and threshold "auto", the K = 3 proxy table, the three i3HMM_predict_* wrappers,
+i3HMM_get_sd_trend, use_KS."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import oracle_c as oc  # noqa: E402
+import oracle_np as onp  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from infercnv_amd import device
+    torch.cuda.set_device(0)
+    device.init(0)
+    device.viterbi_set_mode(0)
+    return device
+
+
+def to_dev(x_gc):
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x_gc, dtype=np.float64).T)).cuda()
+
+
+def to_host(t_cg):
+    return t_cg.cpu().numpy().T
+
+
+@pytest.fixture(scope="module")
+def run_inputs(golden_dir):
+    """The infercnv object example/run.R hands to run(): CreateInfercnvObject replayed by tests/golden/make_golden.py."""
+    d = np.load(os.path.join(golden_dir, "example_run_inputs.npz"))
+    x = d["mant"].astype(np.float64) / 10.0 ** d["neg_exp"].astype(np.float64)
+    refs = {str(n): d[f"ref_{i}"] for i, n in enumerate(d["ref_names"])}
+    obs = {str(n): d[f"obs_{i}"] for i, n in enumerate(d["obs_names"])}
+    return {"counts": x, "chr": d["chr_levels"][d["chr_codes"]], "chr_codes": d["chr_codes"], "refs": refs, "obs": obs}
+
+
+def test_config1_example_run_inputs_through_the_hip_path(dev, run_inputs):
+    """BASELINE.json configs[0] (example/run.R: 184 cells, cutoff = 1, denoise, sd_amplifier = 2, HMM i6): run()'s
+    steps 2, 3, 4 (gene filters, depth normalisation, log2(x + 1)), the smoothing chain 8-14 + 22 and the i6 HMM
+    (per cell and on whole samples), every step through the host mirror -> C ABI -> HIP kernels, against the oracle.
+    Real chromosome layout (chrX/Y/M excluded by CreateInfercnvObject, 22 autosomes of 108 .. 1011 genes), two reference
+    groups of 19 / 23 cells, four tumour groups."""
+    from infercnv_amd import GeneOrder, InfercnvObject, hmm, ops
+    x = run_inputs["counts"]
+    assert x.shape == (9939, 184) and len(run_inputs["refs"]) == 2 and len(run_inputs["obs"]) == 4
+    obj = InfercnvObject(expr_data=x, count_data=x, gene_order=GeneOrder(chr=run_inputs["chr"]),
+                         reference_grouped_cell_indices=run_inputs["refs"],
+                         observation_grouped_cell_indices=run_inputs["obs"])
+    # step 2 (R/inferCNV_ops.R:560-564)
+    o = ops.require_above_min_mean_expr_cutoff(obj, 1)
+    o = ops.require_above_min_cells_ref(o, 3)
+    drop1 = onp.below_min_mean_expr_cutoff(x, 1)
+    keep = np.setdiff1d(np.arange(x.shape[0]), drop1)
+    keep = keep[onp.genes_passing_min_cells(x[keep], 3)]
+    assert o.expr_data.shape[0] == keep.size and 3000 < keep.size < x.shape[0]
+    np.testing.assert_array_equal(o.expr_data, x[keep])
+    np.testing.assert_array_equal(np.asarray(o.gene_order.chr), run_inputs["chr"][keep])
+    # steps 3, 4 (:586, :614)
+    o = ops.log2xplus1(ops.normalize_counts_by_seq_depth(o))
+    want_log = onp.log2xplus1(onp.normalize_counts_by_seq_depth(x[keep]))
+    assert np.abs(o.expr_data - want_log).max() < 1e-12
+    # chain: stand-alone steps in run()'s order and the fused entry, sd_amplifier = 2 as example/run.R passes
+    refs = list(run_inputs["refs"].values())
+    cs = oc.chr_starts_from_codes(run_inputs["chr_codes"][keep])
+    assert len(cs) == 23
+    want_out, want_pre, _ = oc.smooth_chain(o.expr_data, cs, refs, sd_amplifier=2.0, want_pre_denoise=True)
+    s = ops.subtract_ref_expr_from_obs(o)
+    s = ops.apply_max_threshold_bounds(s, 3)
+    s = ops.smooth_by_chromosome(s, 101)
+    s = ops.center_cell_expr_across_chromosome(s, "median")
+    s = ops.subtract_ref_expr_from_obs(s)
+    s14 = ops.invert_log2(s)
+    s22 = ops.clear_noise_via_ref_mean_sd(s14, 2)
+    fused, hmm_in = ops.hip_smooth_chain(o, sd_amplifier=2, return_hmm_input=True)
+    for got in (s14.expr_data, hmm_in.expr_data):
+        assert np.abs(got - want_pre).max() / np.abs(want_pre).max() < 1e-5      # north-star tolerance
+        assert np.abs(got - want_pre).max() < 1e-11
+    for got in (s22.expr_data, fused.expr_data):
+        assert (np.abs(got - want_out) > 1e-10).mean() < 1e-4                    # strict-threshold select at the bounds
+    # i6 HMM: identical inputs (the HIP chain's own output) -> bit-exact states
+    cnv = {k: {"mean": m, "sd": sdv} for k, m, sdv in zip(hmm.CNV_LEVELS, (0.41234766, 0.84075773, 1.01693983, 1.12238786,
+                                                                       1.23842619, 1.44298781),
+                                                          (0.02889, 0.16455, 0.10555, 0.19057, 0.24409, 0.29007))}
+    means = [cnv[k]["mean"] for k in hmm.CNV_LEVELS]
+    sd = float(onp.r_median(np.array([cnv[k]["sd"] for k in hmm.CNV_LEVELS])))
+    Pi, delta = onp.get_HMM_i6(1e-6)
+    cells = hmm.predict_CNV_via_HMM_on_indiv_cells(hmm_in, cnv)
+    want_cells, bad = oc.viterbi_cells(hmm_in.expr_data, cs, means, sd, np.log(Pi), np.log(delta))
+    assert bad == 0
+    np.testing.assert_array_equal(cells.expr_data, want_cells)
+    assert len(np.unique(want_cells)) >= 4                                     # real CNV calls, not one flat state
+    samples = hmm.predict_CNV_via_HMM_on_whole_tumor_samples(hmm_in, True, cnv)
+    groups = list(run_inputs["obs"].values()) + list(run_inputs["refs"].values())
+    gm = to_host(dev.group_means(to_dev(hmm_in.expr_data), groups))
+    for q, g in enumerate(groups):
+        w, _ = oc.viterbi_cells(gm[:, q:q + 1], cs, means, sd, np.log(Pi), np.log(delta))
+        for c in (g[0], g[-1]):
+            np.testing.assert_array_equal(samples.expr_data[:, c], w[:, 0])
+    # the known biology of this data set shows: oligodendroglioma = 1p / 19q co-deletion in the malignant cells
+    chr_of = run_inputs["chr"][keep]
+    mal = np.concatenate(list(run_inputs["obs"].values()))
+    ref = np.concatenate(refs)
+    for arm_chr in ("chr1", "chr19"):
+        rows = chr_of == arm_chr
+        assert (samples.expr_data[np.ix_(rows, mal)] < 3).mean() > 0.3
+        assert (samples.expr_data[np.ix_(rows, ref)] == 3).mean() > 0.9
+
+
+def test_average_bounds_and_auto_threshold(dev):
+    """icnv_average_bounds[_dev] (get_average_bounds, R/inferCNV_ops.R:2723-2742) and step 9 with threshold "auto"
+    (run(): mean(abs(get_average_bounds()), :802-817)."""
+    from infercnv_amd import GeneOrder, InfercnvObject, ops, synth
+    for G, C in ((10000, 130), (4613, 20), (257, 3), (1, 5)):
+        rng = np.random.default_rng(G)
+        x = rng.normal(0.0, 0.4, size=(G, C))
+        x[rng.integers(0, G, 8), rng.integers(0, C, 8)] = rng.choice([7.5, -6.25, 0.0], 8)
+        lo, hi = dev.average_bounds(to_dev(x))
+        wlo, whi = oc.get_average_bounds(x)
+        nlo, nhi = onp.get_average_bounds(x)
+        assert abs(lo - wlo) < 1e-15 and abs(hi - whi) < 1e-15 and abs(lo - nlo) < 1e-15 and abs(hi - nhi) < 1e-15
+    # the reference's own literal (tests/testthat/test_infer_cnv.R:405-433 shape): per-cell min / max, then means
+    m = np.array([[1.0, -2.0, 3.0], [4.0, 5.0, -6.0], [0.5, 0.25, 0.0]])
+    lo, hi = dev.average_bounds(to_dev(m))
+    assert lo == np.mean([0.5, -2.0, -6.0]) and hi == np.mean([4.0, 5.0, 3.0])
+    # host flavour + "auto" through the host mirror
+    cs = synth.chr_layout(600)
+    x = np.random.default_rng(9).normal(0.0, 1.0, size=(600, 40))    # symmetric: both clamps bite
+    chr_names = np.repeat(np.arange(22), np.diff(cs)).astype(str)
+    obj = InfercnvObject(expr_data=x, gene_order=GeneOrder(chr=chr_names),
+                         reference_grouped_cell_indices={"n": np.arange(4, dtype=np.int32)},
+                         observation_grouped_cell_indices={"t": np.arange(4, 40, dtype=np.int32)})
+    lo, hi = ops.get_average_bounds(obj)
+    assert (lo, hi) == tuple(oc.get_average_bounds(x))
+    thr = (abs(lo) + abs(hi)) / 2
+    got = ops.apply_max_threshold_bounds(obj, "auto").expr_data
+    np.testing.assert_array_equal(got, onp.apply_max_threshold_bounds(x, thr))
+    assert (got == thr).any() and (got == -thr).any()
+    with pytest.raises(ValueError):
+        ops.apply_max_threshold_bounds(obj, "automatic")
+
+
+def test_states_to_proxy_i3_and_i6_tables(dev):
+    """assign_HMM_states_to_proxy_expr_vals: i6 {1..6} -> {0, 0.5, 1, 1.5, 2, 3} (R/inferCNV_HMM.R:1191-1206), i3
+    {1, 2, 3} -> {0.5, 1, 1.5} (R/inferCNV_i3HMM.R:405-417); device and host flavours."""
+    from infercnv_amd import GeneOrder, InfercnvObject, hmm
+    rng = np.random.default_rng(0)
+    for K, table in ((3, [0.5, 1.0, 1.5]), (6, [0.0, 0.5, 1.0, 1.5, 2.0, 3.0])):
+        st = rng.integers(1, K + 1, size=(301, 17)).astype(np.uint8)
+        st[:K, 0] = np.arange(1, K + 1)
+        got = to_host(dev.states_to_proxy(torch.from_numpy(np.ascontiguousarray(st.T)).cuda(), K))
+        want = np.asarray(table)[st.astype(np.int64) - 1]
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(got, oc.states_to_proxy(st, K))
+        np.testing.assert_array_equal(got, (onp.i3HMM_assign_HMM_states_to_proxy_expr_vals if K == 3
+                                            else onp.assign_HMM_states_to_proxy_expr_vals)(st))
+        obj = InfercnvObject(expr_data=st.astype(np.float64), gene_order=GeneOrder(chr=np.array(["chr1"] * 301)))
+        f = hmm.i3HMM_assign_HMM_states_to_proxy_expr_vals if K == 3 else hmm.assign_HMM_states_to_proxy_expr_vals
+        np.testing.assert_array_equal(f(obj).expr_data, want)
+
+
+def test_i3_wrappers_and_sd_trend(dev):
+    """i3HMM_get_sd_trend (mu, sigma over all reference values, delta = |qnorm(p, 0, sigma)|: R/inferCNV_i3HMM.R:17-80,
+    435-445) against oracle_np.i3_params, and the three i3HMM_predict_CNV_via_HMM_on_* wrappers
+    (R/inferCNV_i3HMM.R:180-225, 249-308, 332-389) against the oracle on identical inputs."""
+    from infercnv_amd import GeneOrder, InfercnvObject, hmm, synth
+    G, C = 3000, 96
+    x, cs = synth.make_matrix_np(G, C)
+    refs, obs = synth.groups(C)
+    _, pre, _ = oc.smooth_chain(x, cs, refs, want_pre_denoise=True)
+    chr_names = np.repeat(np.arange(22), np.diff(cs)).astype(str)
+    sub = {"subclusters": {"t0": {"t0_s1": obs[0][:10], "t0_s2": obs[0][10:]}, "t1": {"t1_s1": obs[1]},
+                           "t2": {"t2_s1": obs[2]}, "t3": {"t3_s1": obs[3]},
+                           "r0": {"r0_s1": refs[0]}, "r1": {"r1_s1": refs[1]}}}
+    obj = InfercnvObject(expr_data=pre, gene_order=GeneOrder(chr=chr_names),
+                         reference_grouped_cell_indices={"r0": refs[0], "r1": refs[1]},
+                         observation_grouped_cell_indices={f"t{q}": obs[q] for q in range(4)}, tumor_subclusters=sub)
+    for p_val in (0.05, 0.01):
+        tr = hmm.i3HMM_get_sd_trend(obj, p_val)
+        mu, sigma, delta = onp.i3_params(pre, np.concatenate(refs), p_val)
+        assert abs(tr["mu"] - mu) < 1e-13 and abs(tr["sigma"] - sigma) < 1e-13 and abs(tr["mean_delta"] - delta) < 1e-12
+    tr = hmm.i3HMM_get_sd_trend(obj, 0.05)
+    m3 = np.array([tr["mu"] - tr["mean_delta"], tr["mu"], tr["mu"] + tr["mean_delta"]])
+    Pi, delta = onp.get_HMM_i3(1e-6)
+    assert abs(Pi[0].sum() - (1 - 3e-6)) < 1e-15                 # the reference's 1 - 5t diagonal with three states
+    # per cell
+    got = hmm.i3HMM_predict_CNV_via_HMM_on_indiv_cells(obj, 0.05)
+    want, _ = oc.viterbi_cells(pre, cs, m3, tr["sigma"], np.log(Pi), np.log(delta))
+    np.testing.assert_array_equal(got.expr_data, want)
+    assert set(np.unique(want)) == {1, 2, 3}
+    # subclusters and whole samples: Viterbi on the group means (the GPU's own means as the oracle's input), broadcast
+    xd = to_dev(pre)
+    for fn, groups in ((lambda: hmm.i3HMM_predict_CNV_via_HMM_on_tumor_subclusters(obj, 0.05),
+                        [np.asarray(v) for g in sub["subclusters"].values() for v in g.values()]),
+                       (lambda: hmm.i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples(obj, True, 0.05),
+                        [obs[q] for q in range(4)] + list(refs)),
+                       (lambda: hmm.i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples(obj, False, 0.05),
+                        [np.concatenate(obs)] + list(refs))):
+        got = fn().expr_data
+        gm = to_host(dev.group_means(xd, groups))
+        for q, g in enumerate(groups):
+            w, _ = oc.viterbi_cells(gm[:, q:q + 1], cs, m3, tr["sigma"], np.log(Pi), np.log(delta))
+            for c in (g[0], g[len(g) // 2], g[-1]):
+                np.testing.assert_array_equal(got[:, c], w[:, 0])
+        full = onp.predict_cnv_on_groups(pre, np.repeat(np.arange(22), np.diff(cs)), groups, m3,
+                                         [np.full(3, tr["sigma"])] * len(groups), Pi, delta)
+        assert (got == full).mean() > 0.9999
+    # no subclusters -> whole samples (R/inferCNV_i3HMM.R:262-266)
+    obj2 = obj.copy()
+    obj2.tumor_subclusters = None
+    np.testing.assert_array_equal(hmm.i3HMM_predict_CNV_via_HMM_on_tumor_subclusters(obj2, 0.05).expr_data,
+                                  hmm.i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples(obj, True, 0.05).expr_data)
+    # the KS-based delta draws from R's RNG stream (R/inferCNV_i3HMM.R:469-493): refused, not a TypeError
+    with pytest.raises(NotImplementedError, match="use_KS"):
+        hmm.i3HMM_predict_CNV_via_HMM_on_indiv_cells(obj, 0.05, use_KS=True)
+    # ... unless the caller brings the KS delta computed in R
+    tr_ks = dict(tr, KS_delta=0.07)
+    got = hmm.i3HMM_predict_CNV_via_HMM_on_indiv_cells(obj, 0.05, sd_trend=tr_ks, use_KS=True)
+    m3k = np.array([tr["mu"] - 0.07, tr["mu"], tr["mu"] + 0.07])
+    want, _ = oc.viterbi_cells(pre, cs, m3k, tr["sigma"], np.log(Pi), np.log(delta))
+    np.testing.assert_array_equal(got.expr_data, want)
