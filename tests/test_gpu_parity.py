@@ -241,6 +241,50 @@ def test_chain_median_edge_cases(dev):
         np.testing.assert_array_equal(to_host(out), want)
 
 
+def test_chain_fast_median_paths(dev):
+    """The full-chain kernels select the median in the chunk layout (histogram straight from LDS, the zero padding
+    counted and taken off the bin of 0.0 again) and fall back to a 64-step bisection on the value bits when the
+    selected bin holds more than 1 024 values or the cell carried a non-finite value.  Cells built to take each path:
+    thousands of exact zeros around the median (they also share the padding's bin), a constant cell, a step profile
+    whose two middle values lie in different bins, NaN / Inf cells (they must not disturb their neighbours)."""
+    from infercnv_amd import synth
+    G, C = 6000, 64
+    cs = synth.chr_layout(G)
+    rng = np.random.default_rng(21)
+    x = rng.normal(0.0, 0.3, size=(G, C))
+    x[:, :4] = 0.0                                            # reference cells: all zero -> steps 8 / 12 subtract 0
+    x[:, 4] = 0.0                                             # constant cell
+    x[:, 5] = np.concatenate([-np.ones(2000), np.zeros(2500), np.ones(1500)])          # > 1 024 exact zeros at the median
+    x[:, 6] = np.concatenate([-np.ones(1000), np.zeros(2000), rng.normal(2.0, 0.1, size=3000)])   # lower middle = last zero
+    x[:, 7] = np.where(rng.random(G) < 0.6, 0.0, rng.normal(size=G))                   # zeros mixed with noise
+    x[:, 8] = np.repeat(rng.normal(size=G // 200), 200)                                # plateaus: near-ties after smoothing
+    clean = x.copy()
+    x[17, 9] = np.nan
+    x[4000, 10] = np.inf
+    x[100, 11] = -np.inf
+    x[5999, 11] = np.nan
+    refs = [np.arange(4, dtype=np.int32)]
+    for mask in (0x7F, 0x3F):
+        out, pre = dev.smooth_chain(to_dev(x), cs, refs, stage_mask=mask, want_pre_denoise=True)
+        want_out, want_pre, _ = oc.smooth_chain(clean, cs, refs, want_pre_denoise=True, stage_mask=mask)
+        if mask == 0x3F:
+            want_pre = want_out                               # no denoise stage: the chain's output is the HMM input
+        got = to_host(pre)
+        ok = np.ones(C, dtype=bool)
+        ok[9:12] = False                                      # the non-finite cells: only required to terminate
+        assert np.abs(got[:, ok] - want_pre[:, ok]).max() < 1e-12
+        assert np.isfinite(got[:, ok]).all()
+        if mask == 0x7F:
+            assert (np.abs(to_host(out)[:, ok] - want_out[:, ok]) > 1e-10).mean() < 1e-4
+    # a few thousand ordinary cells, even G: the "upper middle beyond the ranked bin" branch occurs in ~3 % of them
+    G2, C2 = 10000, 3000
+    x2, cs2 = synth.make_matrix_np(G2, C2)
+    refs2, _ = synth.groups(C2)
+    _, pre2 = dev.smooth_chain(to_dev(x2), cs2, refs2, stage_mask=0x3F, want_pre_denoise=True)
+    _, want2, _ = oc.smooth_chain(x2, cs2, refs2, want_pre_denoise=True, stage_mask=0x3F)
+    assert np.abs(to_host(pre2) - want2).max() < 1e-11
+
+
 def test_subtract_ref_inv_log(dev):
     """subtract_ref_expr_from_obs(inv_log=TRUE): group means as log2(mean(2^x - 1) + 1) (R/inferCNV_ops.R:1714-1717),
     with and without bounds, several reference groups; only as the stand-alone step."""
@@ -686,6 +730,15 @@ def test_full_size_properties(dev, C):
     pre_h = pre[torch.as_tensor(pick, device="cuda")].cpu().numpy().T
     want_st, _ = oc.viterbi_cells(pre_h, cs, means, sd, logPi, logDelta)
     np.testing.assert_array_equal(st[torch.as_tensor(pick, device="cuda")].cpu().numpy().T, want_st)
+    # (1b) the certified fast path against the exact kernel over the WHOLE matrix: 1.1 M sequences, 5e8 state calls
+    stats = dev.viterbi_last_stats()
+    assert stats["path"] == "fast" and stats["sequences"] == 22 * C and not stats["fallback"]
+    dev.viterbi_set_mode(1)
+    st_exact, bad_exact = dev.viterbi_cells(pre, cs, means, sd, logPi, logDelta)
+    assert dev.viterbi_last_stats()["path"] == "exact"
+    dev.viterbi_set_mode(0)
+    assert torch.equal(st, st_exact) and int(bad_exact.item()) == 0
+    del st_exact
     # (2) cells are independent given the reference statistics: recomputing a slice that contains all
     #     reference cells reproduces those columns exactly
     n_ref = sum(len(r) for r in refs)
