@@ -23,13 +23,9 @@ plan.apply(x, out=out); torch.cuda.synchronize()
 L.icnv_debug_chain_profile(buf, 0)
 names = ["[A] steps 8,9 -> LDS", "[C] stores", "barrier before smoothing", "smoothing (init, slide, write-back)",
          "median: rest (after rank)", "centre + prefetch + steps 12,14", "median: get + min/max", "median: histogram", "median: scan",
-         "median: collect", "median: rank",
-         "  hist: issue (then barrier = 'median: histogram')", "  scan by wave 0 (thread 0's wave)", "  get_w + prefetch issue (then barrier = 'scan')",
-         "  collect: count pass", "  collect: atomic + write pass (then barrier = 'collect')", "  rank: partial counts", "  rank: barrier + pick (then barrier = 'rank')",
-         "  smoothing: init", "  smoothing: slide", "  smoothing: barrier after slide (then write-back = 'smoothing')"]
+         "median: collect", "median: rank"]
 ncell = (C + 255) // 256
 tot = sum(buf[i] for i in range(len(names)))
 for i, n in enumerate(names):
     print(f"{n:28s} {buf[i] / ncell:9.0f} ticks/cell  {100.0 * buf[i] / tot:5.1f}%")
-print(f"cells through the cold bisection: {buf[30]}, cells whose upper middle lay beyond the ranked bin: {buf[31]} (of {C})")
 print(f"total {tot / ncell:.0f} ticks/cell (s_memtime ticks: 100 MHz constant clock on gfx9 -> {tot / ncell * 10:.0f} ns)")

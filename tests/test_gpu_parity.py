@@ -241,12 +241,11 @@ def test_chain_median_edge_cases(dev):
         np.testing.assert_array_equal(to_host(out), want)
 
 
-def test_chain_fast_median_paths(dev):
-    """The full-chain kernels select the median in the chunk layout (histogram straight from LDS, the zero padding
-    counted and taken off the bin of 0.0 again) and fall back to a 64-step bisection on the value bits when the
-    selected bin holds more than 1 024 values or the cell carried a non-finite value.  Cells built to take each path:
-    thousands of exact zeros around the median (they also share the padding's bin), a constant cell, a step profile
-    whose two middle values lie in different bins, NaN / Inf cells (they must not disturb their neighbours)."""
+def test_chain_median_paths_full_chain(dev):
+    """The median select inside the full-chain kernels on cells built to take its rare paths after smoothing: thousands
+    of exact zeros around the median (far more than the 1 024 candidates ranked directly: the refinement levels and
+    the all-members-equal branch), a constant cell, a step profile whose two middle values lie in different bins, plateaus,
+    NaN / Inf cells (they must terminate and must not disturb their neighbours)."""
     from infercnv_amd import synth
     G, C = 6000, 64
     cs = synth.chr_layout(G)
