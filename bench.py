@@ -29,6 +29,27 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~63
 FP64_VECTOR_PEAK_TF = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 
 
+def effective_cores():
+    """CPU cores this process may actually use: the affinity mask capped by the container's CPU quota (cgroup v2
+    cpu.max, cgroup v1 cfs quota).  os.cpu_count() reports the node's logical CPUs, whatever the quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    eff = min(float(n), quota) if quota else float(n)
+    return max(1.0, eff), n, quota
+
+
 def cpu_baseline(G, target_seconds=12.0):
     """The plain-C oracle (oracle/icnv_oracle.c, OpenMP over cells) timed on this
     host's cores over a bounded sample of the same synthetic workload.  R is not
@@ -37,7 +58,8 @@ def cpu_baseline(G, target_seconds=12.0):
     import oracle_c as oc
     from infercnv_amd import synth
     oc.build()
-    cores = os.cpu_count() or 1
+    eff, affinity, quota = effective_cores()
+    cores = max(1, int(round(eff)))            # OpenMP threads = the cores the quota lets us keep busy
     oc.set_num_threads(cores)
     means, sd, logPi, logDelta = synth.hmm_params_i6()
 
@@ -58,7 +80,11 @@ def cpu_baseline(G, target_seconds=12.0):
     if t < 0.6 * target_seconds and C < 60000:     # the pilot under-estimated the parallel speed: one larger sample
         C = int(min(60000, C * target_seconds / max(t, 1e-3)))
         t = run(C)
-    res = {"value": C / t, "unit": "cells/s", "cores": oc.num_threads(), "kind": "port",
+    res = {"value": C / t, "unit": "cells/s", "cores": oc.num_threads(), "cores_note": (
+               f"{oc.num_threads()} OpenMP threads = the CPU quota of this container ({quota:.1f} cores) "
+               f"of {os.cpu_count()} logical CPUs on the node" if quota else
+               f"{oc.num_threads()} OpenMP threads = affinity mask ({affinity}) of {os.cpu_count()} logical CPUs, no CPU quota"),
+           "kind": "port",
            "sample": f"{G} genes x {C} cells of the same synthetic generator, smooth chain + i6 Viterbi, "
                      f"oracle/icnv_oracle.c with OpenMP over cells, {t:.1f} s"}
     # the reference's own structure is serial R: one core of the same port, a few seconds
@@ -68,7 +94,6 @@ def cpu_baseline(G, target_seconds=12.0):
     oc.set_num_threads(cores)
     res["single_thread"] = {"value": c1 / t1, "unit": "cells/s", "cores": 1,
                             "sample": f"{G} genes x {c1} cells, same code on one core, {t1:.1f} s"}
-    # os.cpu_count() counts the node's logical CPUs; a container's CPU quota can be far smaller
     res["parallel_speedup_over_one_core"] = res["value"] / res["single_thread"]["value"]
     return res
 
@@ -184,6 +209,18 @@ def main():
                                        "table-driven emission scores + max-plus recurrence, about 91 fp64/integer vector instructions and "
                                        "18 LDS gathers per gene and wavefront, every lane streaming its own column; "
                                        "issue/LDS/latency-bound, no MFMA-shaped work")
+        if "viterbi" in roof:
+            # second ceiling of the Viterbi (SURVEY.md 8d asks for HBM GB/s *and* the fp64 rate): its forward pass issues
+            # ~91 vector instructions per gene and wavefront (static count, scripts/vf_asm_stats.py), every one of them 4
+            # cycles of a 16-lane SIMD; 256 CUs x 4 SIMDs at the 2.4 GHz peak clock
+            instr = 91.0
+            ceil_ms = (G * C_local / 64.0) * instr * 4.0 / (256 * 4) / 2.4e9 * 1e3
+            roof["viterbi"]["fp64_issue"] = {"vector_instr_per_gene_wavefront": instr, "ceiling_ms": ceil_ms,
+                                             "frac": ceil_ms / kernels["viterbi"]["avg_ms"],
+                                             "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TF,
+                                             "note": "share of the launch the vector pipes would need at full issue rate; the rest is "
+                                                     "LDS coefficient gathers (15 x 16-byte reads per gene and lane, random intervals: "
+                                                     "the LDS pipe, not the vector pipe, paces the kernel) and the per-lane column streams"}
         dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
         traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(traffic_file) and G == 10000 and C_local == 50000:   # counters were collected on this shape
@@ -192,6 +229,8 @@ def main():
                 for k in roof:
                     if k in tr:
                         roof[k]["traffic"] = tr[k]
+                        roof[k]["traffic_source"] = ("profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE of separate rocprofv3 --pmc "
+                                                     "passes over this workload (scripts/pmc_traffic.sh), not measured in this run")
             except Exception:
                 pass
         res = {

@@ -73,6 +73,29 @@ int icnv_init(int device);
 /* Frees cached device workspaces. */
 void icnv_shutdown(void);
 
+/* Devices of the HOST-BUFFER entry points (the ones an R process reaches through the .Call shim).  n_devices = 0: every
+ * visible device, n: devices 0 .. n-1, 1 (the default): the calling thread's current device.  With more than one device
+ * icnv_smooth_chain and icnv_viterbi_cells split the cells into one contiguous block per device (one host thread, one
+ * stream per device); the chain's reference statistics (per-gene sums of the reference groups) are added
+ * on the host in device order.  The other host-buffer entry points run on the current device.  This is what lets a
+ * single R process (infercnv::run() is single-threaded) use the 8 GPUs of a node, each over its own PCIe link.
+ * The *_dev entry points are not affected: a device-resident caller (one process per GPU, infercnv_amd/sharded.py)
+ * shards by itself. */
+int icnv_set_devices(int n_devices);
+int icnv_get_devices(void);
+
+/* Residency of the host-buffer entry points.  run() hands every step the matrix the previous step returned
+ * (R/inferCNV_ops.R:771-1031, 1237-1309).  With icnv_residency(1) the library keeps the matrices it uploaded or
+ * produced on the device(s) -- up to 6 per device, ICNV_RESIDENT_MAX_GB (default 64) -- and recognises a host matrix
+ * by its address, its size and a fingerprint of ~16 000 values sampled at a fixed stride: a recognised matrix is not
+ * uploaded again.  The caller may free or reuse the host memory at any time (contents are fingerprinted at every
+ * call); a caller that edits a few elements of a matrix IN PLACE between two calls could go unnoticed -- such a
+ * caller leaves residency off (the default) or calls icnv_residency_drop().
+ *   icnv_residency_stats  out4 = {matrices recognised, matrices uploaded, resident bytes, resident matrices} */
+int icnv_residency(int on);
+void icnv_residency_drop(void);
+int icnv_residency_stats(int64_t *out4);
+
 /* ---- smoothing chain ---------------------------------------------------- */
 typedef struct icnv_chain_cfg {
     int64_t G;               /* genes                                              */

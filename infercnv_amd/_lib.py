@@ -60,6 +60,11 @@ PROTOTYPES = {
     "icnv_last_error": (ct.c_char_p, []),
     "icnv_init": (ct.c_int, [ct.c_int]),
     "icnv_shutdown": (None, []),
+    "icnv_set_devices": (ct.c_int, [ct.c_int]),
+    "icnv_get_devices": (ct.c_int, []),
+    "icnv_residency": (ct.c_int, [ct.c_int]),
+    "icnv_residency_drop": (None, []),
+    "icnv_residency_stats": (ct.c_int, [ct.POINTER(_i64)]),
     "icnv_smooth_chain": (ct.c_int, [_vp, _vp, _vp, ct.POINTER(ChainCfg)]),
     "icnv_smooth_chain_dev": (ct.c_int, [_vp, _vp, _vp, ct.POINTER(ChainCfg), _vp]),
     "icnv_chain_begin": (ct.c_int, [ct.POINTER(_vp), ct.POINTER(ChainCfg)]),

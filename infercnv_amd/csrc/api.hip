@@ -38,6 +38,18 @@ int num_cus() {
     return cus;
 }
 
+int ensure_dynamic_lds(const void *kernel, int bytes, DeviceOnce &once) {
+    static std::mutex mu;
+    int dev = 0;
+    ICNV_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    std::lock_guard<std::mutex> lk(mu);
+    if (once.done & bit) return ICNV_OK;
+    ICNV_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    once.done |= bit;
+    return ICNV_OK;
+}
+
 // ------------------------------------------------------------------ device memory pool
 // Grow-only caching allocator so that steady-state calls never hipMalloc/hipFree.
 namespace {
@@ -54,6 +66,16 @@ int current_device() {
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
     return dev;
 }
+// Worker threads of the in-library multi-device path that share ONE physical device (ICNV_FAKE_DEVICES, the
+// one-GPU test of that path) use one stream each: they get disjoint partitions of the device's pool.
+thread_local int g_pool_part = 0;
+}  // namespace
+int pool_domain() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    return dev * 256 + g_pool_part;
+}
+namespace {
 
 size_t round_size(size_t n) {
     if (n < 256) n = 256;
@@ -67,7 +89,7 @@ size_t round_size(size_t n) {
 
 int pool_alloc(void **p, size_t bytes) {
     const size_t sz = round_size(bytes);
-    const int dev = current_device();
+    const int dev = pool_domain();
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         auto it = g_free.lower_bound(PoolKey(dev, sz));
@@ -102,6 +124,8 @@ int pool_alloc(void **p, size_t bytes) {
     return ICNV_OK;
 }
 
+void set_pool_part(int part) { g_pool_part = part; }
+
 void pool_free(void *p) {
     if (!p) return;
     std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -111,12 +135,6 @@ void pool_free(void *p) {
     g_live.erase(it);
 }
 
-struct DevBuf {  // RAII over the pool
-    void *p = nullptr;
-    ~DevBuf() { pool_free(p); }
-    int alloc(size_t bytes) { pool_free(p); p = nullptr; return pool_alloc(&p, bytes); }
-    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
-};
 
 // ------------------------------------------------------------------ kernel timing
 namespace {
@@ -618,23 +636,6 @@ int icnv_smooth_chain_dev(const double *expr_in, double *expr_out, double *pre_d
     return rc;
 }
 
-int icnv_smooth_chain(const double *expr_in, double *expr_out, double *pre_denoise, const icnv_chain_cfg *cfg) {
-    if (!expr_in || !expr_out || !cfg) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
-    const size_t bytes = (size_t)cfg->G * (size_t)cfg->C * sizeof(double);
-    DevBuf din, dout, dpre;
-    int rc;
-    if ((rc = din.alloc(bytes))) return rc;
-    if ((rc = dout.alloc(bytes))) return rc;
-    if (pre_denoise && (rc = dpre.alloc(bytes))) return rc;
-    ICNV_HIP(hipMemcpy(din.p, expr_in, bytes, hipMemcpyHostToDevice));
-    rc = icnv_smooth_chain_dev(din.as<double>(), dout.as<double>(), pre_denoise ? dpre.as<double>() : nullptr, cfg,
-                               nullptr);
-    if (rc) return rc;
-    ICNV_HIP(hipMemcpy(expr_out, dout.p, bytes, hipMemcpyDeviceToHost));
-    if (pre_denoise) ICNV_HIP(hipMemcpy(pre_denoise, dpre.p, bytes, hipMemcpyDeviceToHost));
-    return ICNV_OK;
-}
-
 int icnv_average_bounds_dev(const double *expr, int64_t G, int64_t C, double *out2_host, void *stream) {
     if (!expr || !out2_host || G < 1 || C < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
     hipStream_t s = (hipStream_t)stream;
@@ -660,12 +661,10 @@ int icnv_average_bounds_dev(const double *expr, int64_t G, int64_t C, double *ou
 
 int icnv_average_bounds(const double *expr, int64_t G, int64_t C, double *out2) {
     if (!expr || !out2) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
-    DevBuf d;
-    const size_t bytes = (size_t)G * C * sizeof(double);
-    int rc = d.alloc(bytes);
+    MatrixLease in;
+    int rc = acquire_input(expr, G * C, nullptr, in);
     if (rc) return rc;
-    ICNV_HIP(hipMemcpy(d.p, expr, bytes, hipMemcpyHostToDevice));
-    return icnv_average_bounds_dev(d.as<double>(), G, C, out2, nullptr);
+    return icnv_average_bounds_dev(in.dev, G, C, out2, nullptr);
 }
 
 // ------------------------------------------------------------------ ingest (steps 3-4)
@@ -695,14 +694,14 @@ static double host_median(std::vector<double> v) {
 int icnv_normalize_log2(const double *expr_in, double *expr_out, int64_t G, int64_t C, double normalize_factor,
                         int32_t do_normalize, int32_t do_log2, double *factor_used) {
     if (!expr_in || !expr_out || G < 1 || C < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
-    DevBuf din, dout, dsum;
+    MatrixLease in;
+    DevBuf dout, dsum;
     int rc;
     const size_t bytes = (size_t)G * (size_t)C * sizeof(double);
-    if ((rc = din.alloc(bytes)) || (rc = dout.alloc(bytes)) || (rc = dsum.alloc((size_t)C * sizeof(double)))) return rc;
-    ICNV_HIP(hipMemcpy(din.p, expr_in, bytes, hipMemcpyHostToDevice));
+    if ((rc = acquire_input(expr_in, G * C, nullptr, in)) || (rc = dout.alloc(bytes)) || (rc = dsum.alloc((size_t)C * sizeof(double)))) return rc;
     double factor = normalize_factor;
     if (do_normalize) {
-        if ((rc = icnv_col_sums_dev(din.as<double>(), G, C, dsum.as<double>(), nullptr))) return rc;
+        if ((rc = icnv_col_sums_dev(in.dev, G, C, dsum.as<double>(), nullptr))) return rc;
         if (std::isnan(factor)) {   // median(colSums), R/inferCNV_ops.R:3096
             std::vector<double> cs((size_t)C);
             ICNV_HIP(hipMemcpy(cs.data(), dsum.p, (size_t)C * sizeof(double), hipMemcpyDeviceToHost));
@@ -711,10 +710,11 @@ int icnv_normalize_log2(const double *expr_in, double *expr_out, int64_t G, int6
         if (std::isnan(factor)) ICNV_FAIL(ICNV_ERR_ARG, "normalize factor not estimated");   // :3105
     }
     if (factor_used) *factor_used = factor;
-    if ((rc = icnv_normalize_log2_dev(din.as<double>(), dout.as<double>(), G, C, dsum.as<double>(), factor, do_normalize,
+    if ((rc = icnv_normalize_log2_dev(in.dev, dout.as<double>(), G, C, dsum.as<double>(), factor, do_normalize,
                                       do_log2, nullptr)))
         return rc;
     ICNV_HIP(hipMemcpy(expr_out, dout.p, bytes, hipMemcpyDeviceToHost));
+    publish_output(expr_out, G * C, std::move(dout));
     return ICNV_OK;
 }
 
@@ -738,13 +738,12 @@ int icnv_gene_stats_dev(const double *expr, int64_t G, int64_t C, double *gene_s
 
 int icnv_gene_stats(const double *expr, int64_t G, int64_t C, double *gene_sums, int32_t *gene_nnz) {
     if (!expr || !gene_sums || !gene_nnz || G < 1 || C < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
-    DevBuf din, ds, dn;
+    MatrixLease in;
+    DevBuf ds, dn;
     int rc;
-    const size_t bytes = (size_t)G * (size_t)C * sizeof(double);
-    if ((rc = din.alloc(bytes)) || (rc = ds.alloc((size_t)G * sizeof(double))) || (rc = dn.alloc((size_t)G * sizeof(int32_t))))
+    if ((rc = acquire_input(expr, G * C, nullptr, in)) || (rc = ds.alloc((size_t)G * sizeof(double))) || (rc = dn.alloc((size_t)G * sizeof(int32_t))))
         return rc;
-    ICNV_HIP(hipMemcpy(din.p, expr, bytes, hipMemcpyHostToDevice));
-    if ((rc = icnv_gene_stats_dev(din.as<double>(), G, C, ds.as<double>(), dn.as<int32_t>(), nullptr))) return rc;
+    if ((rc = icnv_gene_stats_dev(in.dev, G, C, ds.as<double>(), dn.as<int32_t>(), nullptr))) return rc;
     ICNV_HIP(hipMemcpy(gene_sums, ds.p, (size_t)G * sizeof(double), hipMemcpyDeviceToHost));
     ICNV_HIP(hipMemcpy(gene_nnz, dn.p, (size_t)G * sizeof(int32_t), hipMemcpyDeviceToHost));
     return ICNV_OK;
@@ -774,12 +773,13 @@ int icnv_select_genes_dev(const double *expr_in, int64_t G_in, int64_t C, const 
 int icnv_select_genes(const double *expr_in, int64_t G_in, int64_t C, const int32_t *keep_idx, int64_t G_out,
                       double *expr_out) {
     if (!expr_in || !expr_out || G_in < 1 || C < 1 || G_out < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
-    DevBuf din, dout;
+    MatrixLease in;
+    DevBuf dout;
     int rc;
-    if ((rc = din.alloc((size_t)G_in * C * sizeof(double))) || (rc = dout.alloc((size_t)G_out * C * sizeof(double)))) return rc;
-    ICNV_HIP(hipMemcpy(din.p, expr_in, (size_t)G_in * C * sizeof(double), hipMemcpyHostToDevice));
-    if ((rc = icnv_select_genes_dev(din.as<double>(), G_in, C, keep_idx, G_out, dout.as<double>(), nullptr))) return rc;
+    if ((rc = acquire_input(expr_in, G_in * C, nullptr, in)) || (rc = dout.alloc((size_t)G_out * C * sizeof(double)))) return rc;
+    if ((rc = icnv_select_genes_dev(in.dev, G_in, C, keep_idx, G_out, dout.as<double>(), nullptr))) return rc;
     ICNV_HIP(hipMemcpy(expr_out, dout.p, (size_t)G_out * C * sizeof(double), hipMemcpyDeviceToHost));
+    publish_output(expr_out, G_out * C, std::move(dout));
     return ICNV_OK;
 }
 
@@ -818,11 +818,10 @@ int icnv_block_mean_sd_dev(const double *expr, int64_t G, int64_t C, const int32
 int icnv_block_mean_sd(const double *expr, int64_t G, int64_t C, const int32_t *gene_idx, int64_t n_genes,
                        const int32_t *cell_idx, int64_t n_cells, double *out2) {
     if (!expr || G < 1 || C < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
-    DevBuf din;
+    MatrixLease in;
     int rc;
-    if ((rc = din.alloc((size_t)G * C * sizeof(double)))) return rc;
-    ICNV_HIP(hipMemcpy(din.p, expr, (size_t)G * C * sizeof(double), hipMemcpyHostToDevice));
-    return icnv_block_mean_sd_dev(din.as<double>(), G, C, gene_idx, n_genes, cell_idx, n_cells, out2, nullptr);
+    if ((rc = acquire_input(expr, G * C, nullptr, in))) return rc;
+    return icnv_block_mean_sd_dev(in.dev, G, C, gene_idx, n_genes, cell_idx, n_cells, out2, nullptr);
 }
 
 // ------------------------------------------------------------------ HMM
@@ -1134,27 +1133,6 @@ int icnv_viterbi_cells_dev(const double *expr, uint8_t *states, int64_t G, int64
                            (hipStream_t)stream);
 }
 
-int icnv_viterbi_cells(const double *expr, uint8_t *states, int64_t G, int64_t C, const int32_t *chr_start,
-                       int32_t n_chr, int32_t K, const double *mean, double sd_shared, const double *logPi,
-                       const double *logDelta) {
-    if (!expr || !states) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
-    DevBuf dx, ds, dn;
-    int rc;
-    const size_t n = (size_t)G * (size_t)C;
-    if ((rc = dx.alloc(n * sizeof(double))) || (rc = ds.alloc(std::max<size_t>(n, 1))) || (rc = dn.alloc(sizeof(int32_t))))
-        return rc;
-    ICNV_HIP(hipMemcpy(dx.p, expr, n * sizeof(double), hipMemcpyHostToDevice));
-    ICNV_HIP(hipMemset(dn.p, 0, sizeof(int32_t)));
-    rc = icnv_viterbi_cells_dev(dx.as<double>(), ds.as<uint8_t>(), G, C, chr_start, n_chr, K, mean, sd_shared, logPi,
-                                logDelta, dn.as<int32_t>(), nullptr);
-    if (rc) return rc;
-    int32_t bad = 0;
-    ICNV_HIP(hipMemcpy(states, ds.p, n, hipMemcpyDeviceToHost));
-    ICNV_HIP(hipMemcpy(&bad, dn.p, sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (bad) ICNV_FAIL(ICNV_ERR_UNDERFLOW, "Problems With Underflow in " + std::to_string(bad) + " sequences");
-    return ICNV_OK;
-}
-
 int icnv_group_means_dev(const double *expr, int64_t G, int64_t C, const int32_t *grp_idx, const int32_t *grp_off,
                          int32_t n_grp, double *out, void *stream) {
     if (!expr || !out || G < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
@@ -1200,11 +1178,11 @@ int icnv_cell_distances_dev(const double *expr, int64_t G, int64_t C, const int3
 
 int icnv_cell_distances(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx, int64_t n, double *dist_out) {
     if (!expr || !dist_out || G < 1 || C < 1 || n < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
-    DevBuf din, dout;
+    MatrixLease in;
+    DevBuf dout;
     int rc;
-    if ((rc = din.alloc((size_t)G * C * sizeof(double))) || (rc = dout.alloc((size_t)n * n * sizeof(double)))) return rc;
-    ICNV_HIP(hipMemcpy(din.p, expr, (size_t)G * C * sizeof(double), hipMemcpyHostToDevice));
-    if ((rc = icnv_cell_distances_dev(din.as<double>(), G, C, cell_idx, n, dout.as<double>(), nullptr))) return rc;
+    if ((rc = acquire_input(expr, G * C, nullptr, in)) || (rc = dout.alloc((size_t)n * n * sizeof(double)))) return rc;
+    if ((rc = icnv_cell_distances_dev(in.dev, G, C, cell_idx, n, dout.as<double>(), nullptr))) return rc;
     ICNV_HIP(hipMemcpy(dist_out, dout.p, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost));
     return ICNV_OK;
 }
@@ -1245,14 +1223,14 @@ int icnv_viterbi_groups(const double *expr, uint8_t *states, int64_t G, int64_t 
                         const double *mean, const double *sd_shared_per_grp, const double *logPi,
                         const double *logDelta) {
     if (!expr || !states) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
-    DevBuf dx, ds, dn;
+    MatrixLease in;
+    DevBuf ds, dn;
     int rc;
     const size_t n = (size_t)G * (size_t)C;
-    if ((rc = dx.alloc(n * sizeof(double))) || (rc = ds.alloc(std::max<size_t>(n, 1))) || (rc = dn.alloc(sizeof(int32_t))))
+    if ((rc = acquire_input(expr, G * C, nullptr, in)) || (rc = ds.alloc(std::max<size_t>(n, 1))) || (rc = dn.alloc(sizeof(int32_t))))
         return rc;
-    ICNV_HIP(hipMemcpy(dx.p, expr, n * sizeof(double), hipMemcpyHostToDevice));
     ICNV_HIP(hipMemset(dn.p, 0, sizeof(int32_t)));
-    rc = icnv_viterbi_groups_dev(dx.as<double>(), ds.as<uint8_t>(), G, C, chr_start, n_chr, grp_idx, grp_off, n_grp, K,
+    rc = icnv_viterbi_groups_dev(in.dev, ds.as<uint8_t>(), G, C, chr_start, n_chr, grp_idx, grp_off, n_grp, K,
                                  mean, sd_shared_per_grp, logPi, logDelta, dn.as<int32_t>(), nullptr);
     if (rc) return rc;
     int32_t bad = 0;
@@ -1450,15 +1428,16 @@ int icnv_median_filter(const double *expr_in, double *expr_out, int64_t G, int64
                        int32_t n_chr, const int32_t *tile_idx, const int32_t *tile_off, int32_t n_tiles,
                        int32_t window_size) {
     if (!expr_in || !expr_out) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
-    DevBuf din, dout;
+    MatrixLease in;
+    DevBuf dout;
     int rc;
     const size_t bytes = (size_t)G * (size_t)C * sizeof(double);
-    if ((rc = din.alloc(bytes)) || (rc = dout.alloc(bytes))) return rc;
-    ICNV_HIP(hipMemcpy(din.p, expr_in, bytes, hipMemcpyHostToDevice));
-    rc = icnv_median_filter_dev(din.as<double>(), dout.as<double>(), G, C, chr_start, n_chr, tile_idx, tile_off, n_tiles,
+    if ((rc = acquire_input(expr_in, G * C, nullptr, in)) || (rc = dout.alloc(bytes))) return rc;
+    rc = icnv_median_filter_dev(in.dev, dout.as<double>(), G, C, chr_start, n_chr, tile_idx, tile_off, n_tiles,
                                 window_size, nullptr);
     if (rc) return rc;
     ICNV_HIP(hipMemcpy(expr_out, dout.p, bytes, hipMemcpyDeviceToHost));
+    publish_output(expr_out, G * C, std::move(dout));
     return ICNV_OK;
 }
 

@@ -277,12 +277,8 @@ int launch_chain_large_smooth(const LargeChainArgs &a, int32_t max_chr_len, hipS
     if (a.n_rows <= 0) return ICNV_OK;
     const size_t lds = chain_large_lds_bytes(max_chr_len, a.T);
     if (lds > 152 * 1024) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "a single chromosome does not fit the 160 KiB LDS (more than ~19 000 genes)");
-    static bool attr = false;
-    if (!attr) {
-        ICNV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(large_smooth_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     152 * 1024));
-        attr = true;
-    }
+    static DeviceOnce once;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(large_smooth_kernel), 152 * 1024, once)) return rc;
     int gy = a.n_rows < 4096 ? a.n_rows : 4096;
     KernelTimer kt("chain_large_smooth", stream);
     hipLaunchKernelGGL(large_smooth_kernel, dim3(a.n_chr, gy), dim3(256), lds, stream, a);

@@ -167,12 +167,8 @@ int launch_cell_distances(const double *x, int32_t G, const int32_t *idx_dev, in
         KernelTimer kt("cell_distances_gram", stream);
         const size_t lds = (size_t)2 * DT * LDR * sizeof(double);
         if (big) {
-            static bool attr = false;
-            if (!attr) {
-                ICNV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gram_tiles_kernel<4>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-                attr = true;
-            }
+            static DeviceOnce once;
+            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(gram_tiles_kernel<4>), 80 * 1024, once)) return rc;
             hipLaunchKernelGGL(gram_tiles_kernel<4>, dim3((unsigned)tiles), dim3(256), lds, stream, x, G, idx_dev, n, mean_dev, out);
         } else {
             hipLaunchKernelGGL(gram_tiles_kernel<2>, dim3((unsigned)tiles), dim3(256), lds, stream, x, G, idx_dev, n, mean_dev, out);

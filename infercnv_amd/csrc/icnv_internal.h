@@ -25,6 +25,36 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
         return (code);              \
     } while (0)
 
+// Device workspace pool (api.hip): grow-only, per device (and per pool partition of the calling thread).
+int pool_alloc(void **p, size_t bytes);
+void pool_free(void *p);
+void set_pool_part(int part);
+struct DevBuf {  // RAII over the pool
+    void *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p) { o.p = nullptr; }
+    DevBuf &operator=(DevBuf &&o) noexcept { if (this != &o) { pool_free(p); p = o.p; o.p = nullptr; } return *this; }
+    ~DevBuf() { pool_free(p); }
+    int alloc(size_t bytes) { pool_free(p); p = nullptr; return pool_alloc(&p, bytes); }
+    void release() { pool_free(p); p = nullptr; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Host-buffer path (host_path.hip): a device copy of a host matrix, either recognised as resident (icnv_residency) or
+// uploaded on `s`; and the registration of a freshly downloaded result.
+struct MatrixLease {
+    const double *dev = nullptr;
+    DevBuf own;               // the upload when the matrix is not kept resident
+    void *entry = nullptr;    // the resident entry pinned by this lease
+    MatrixLease() = default;
+    MatrixLease(const MatrixLease &) = delete;
+    ~MatrixLease();
+};
+int acquire_input(const double *host, int64_t n_doubles, hipStream_t s, MatrixLease &lease);
+void publish_output(const double *host, int64_t n_doubles, DevBuf &&buf);
+
 // Optional per-kernel timing with hipEvents recorded on the launch stream.
 struct KernelTimer {
     KernelTimer(const char *name, hipStream_t s);
@@ -36,6 +66,10 @@ struct KernelTimer {
 };
 
 int num_cus();
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: set it once for every device the
+// calling thread's launches go to (`done` = one bit per device ordinal, owned by the launch site)
+struct DeviceOnce { unsigned long long done = 0; };
+int ensure_dynamic_lds(const void *kernel, int bytes, DeviceOnce &once);
 
 // ---- smoothing chain ------------------------------------------------------
 enum ChainMode { MODE_APPLY = 0, MODE_GENE_SUMS = 1, MODE_CELL_STATS = 2 };

@@ -372,12 +372,8 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
         if (n_patches > 0) {
             const size_t lds = ((size_t)2 * (MF_TG + 8) * (MF9_TC + 8) + (size_t)(MF9_TC + 8) * MF_TG * 9) * sizeof(double) +
                                3 * (MF9_TC + 8) * sizeof(int32_t);
-            static bool attr = false;
-            if (!attr) {
-                ICNV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(median_filter9_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-                attr = true;
-            }
+            static DeviceOnce once;
+            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(median_filter9_kernel), 80 * 1024, once)) return rc;
             int64_t grid = (int64_t)num_cus() * 2;   // two resident workgroups per CU (70 KB of LDS, 256 registers)
             if (grid > n_patches) grid = n_patches;
             hipLaunchKernelGGL(median_filter9_kernel, dim3((unsigned)grid), dim3(MF_TG * MF_TC), lds, stream, in, out, G,

@@ -452,20 +452,12 @@ int launch_viterbi_fast(const FastViterbiArgs &a, int K, hipStream_t stream) {
     if (grid > need) grid = (int)need;
     KernelTimer kt("viterbi", stream);
     if (K == 6) {
-        static bool set6 = false;
-        if (!set6) {
-            ICNV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_fast_kernel<6>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            set6 = true;
-        }
+        static DeviceOnce once6;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(viterbi_fast_kernel<6>), 160 * 1024, once6)) return rc;
         hipLaunchKernelGGL(viterbi_fast_kernel<6>, dim3(grid), dim3(FAST_NT), lds, stream, a);
     } else if (K == 3) {
-        static bool set3 = false;
-        if (!set3) {
-            ICNV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_fast_kernel<3>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            set3 = true;
-        }
+        static DeviceOnce once3;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(viterbi_fast_kernel<3>), 160 * 1024, once3)) return rc;
         hipLaunchKernelGGL(viterbi_fast_kernel<3>, dim3(grid), dim3(FAST_NT), lds, stream, a);
     } else {
         ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "fast Viterbi is built for K = 6 and K = 3");

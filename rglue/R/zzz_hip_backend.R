@@ -32,17 +32,27 @@
     else list(proxyNormal = unlist(infercnv_obj@observation_grouped_cell_indices))
 }
 
+## expr.data in per-chromosome contiguous gene order.  After .order_reduce (R/inferCNV.R:407) the permutation is the
+## identity: the matrix is then handed over AS IS (no copy), which also lets the library recognise the matrix it
+## returned from the previous step and skip the upload (icnv_residency, include/icnv.h).
+.icnv_matrix <- function(infercnv_obj, lay) {
+    x <- infercnv_obj@expr.data
+    if (!is.matrix(x)) x <- as.matrix(x)                 # dgCMatrix -> dense, like R/inferCNV_ops.R:1924-1926
+    if (is.unsorted(lay$perm)) x <- x[lay$perm, , drop = FALSE]
+    if (storage.mode(x) != "double") storage.mode(x) <- "double"
+    x
+}
+.icnv_unpermute <- function(m, lay) if (is.null(m) || !is.unsorted(lay$perm)) m else m[order(lay$perm), , drop = FALSE]
+
 .icnv_chain <- function(infercnv_obj, mask, window_length = 101L, max_thresh = NA_real_, use_bounds = TRUE,
                         sd_amplifier = 1.5, noise_filter = NA_real_, want_pre = FALSE, inv_log = FALSE) {
     lay <- .icnv_chr_layout(infercnv_obj)
     ref <- .icnv_pack(.icnv_ref_groups(infercnv_obj))
-    x <- as.matrix(infercnv_obj@expr.data)[lay$perm, , drop = FALSE]
-    storage.mode(x) <- "double"
+    x <- .icnv_matrix(infercnv_obj, lay)
     res <- .Call("icnv_R_smooth_chain", x, lay$chr_start, ref$idx, ref$off, as.integer(window_length),
                  as.numeric(max_thresh), as.logical(use_bounds), as.numeric(sd_amplifier),
                  as.numeric(noise_filter), as.integer(sum(mask)), as.logical(want_pre), as.logical(inv_log))
-    inv <- order(lay$perm)
-    lapply(res, function(m) if (is.null(m)) NULL else m[inv, , drop = FALSE])
+    lapply(res, .icnv_unpermute, lay = lay)
 }
 
 hip_subtract_ref_expr_from_obs <- function(infercnv_obj, inv_log = FALSE, use_bounds = TRUE) {
@@ -52,7 +62,18 @@ hip_subtract_ref_expr_from_obs <- function(infercnv_obj, inv_log = FALSE, use_bo
     infercnv_obj
 }
 
+## get_average_bounds (R/inferCNV_ops.R:2723-2742): c(mean over cells of the per-cell minimum, ... maximum); run()
+## takes mean(abs(.)) of it for max_centered_threshold = "auto" (:802-806)
+hip_get_average_bounds <- function(infercnv_obj) {
+    x <- infercnv_obj@expr.data
+    if (!is.matrix(x)) x <- as.matrix(x)
+    if (storage.mode(x) != "double") storage.mode(x) <- "double"
+    .Call("icnv_R_average_bounds", x)
+}
+
 hip_apply_max_threshold_bounds <- function(infercnv_obj, threshold) {
+    if (is.character(threshold) && threshold == "auto")       # run() resolves "auto" itself; accepted here as well
+        threshold <- mean(abs(hip_get_average_bounds(infercnv_obj)))
     infercnv_obj@expr.data <- .icnv_chain(infercnv_obj, .icnv_ST["thresh"], max_thresh = threshold)[[1]]
     if (!is.null(infercnv_obj@.hspike))
         infercnv_obj@.hspike <- hip_apply_max_threshold_bounds(infercnv_obj@.hspike, threshold)
@@ -107,8 +128,7 @@ hip_smooth_chain <- function(infercnv_obj, window_length = 101, max_centered_thr
 
 .icnv_hmm_states <- function(infercnv_obj, HMM_info, sd, groups = NULL) {
     lay <- .icnv_chr_layout(infercnv_obj)
-    x <- as.matrix(infercnv_obj@expr.data)[lay$perm, , drop = FALSE]
-    storage.mode(x) <- "double"
+    x <- .icnv_matrix(infercnv_obj, lay)
     pm <- HMM_info[["state_emission_params"]]
     logPi <- log(HMM_info[["state_transitions"]]); logDelta <- log(HMM_info[["delta"]])
     st <- if (is.null(groups)) {
@@ -118,7 +138,7 @@ hip_smooth_chain <- function(infercnv_obj, window_length = 101, max_centered_thr
         .Call("icnv_R_viterbi_groups", x, lay$chr_start, g$idx, g$off, as.numeric(pm$mean), as.numeric(sd),
               logPi, logDelta)
     }
-    infercnv_obj@expr.data <- st[order(lay$perm), , drop = FALSE]
+    infercnv_obj@expr.data <- .icnv_unpermute(st, lay)
     infercnv_obj
 }
 
@@ -128,15 +148,110 @@ hip_predict_CNV_via_HMM_on_indiv_cells <- function(infercnv_obj,
     .icnv_hmm_states(infercnv_obj, HMM_info, median(HMM_info[["state_emission_params"]]$sd))   # :1122
 }
 
-hip_predict_CNV_via_HMM_on_tumor_subclusters <- function(infercnv_obj,
+.icnv_i6_group_sd <- function(groups, cnv_mean_sd, cnv_level_to_mean_sd_fit)       # .get_state_emission_params + median(sd), :586-614, :1122
+    vapply(groups, function(g) median(.get_state_emission_params(length(g), cnv_mean_sd, cnv_level_to_mean_sd_fit)$sd),
+           numeric(1))
+
+## tumor_samples of predict_CNV_via_HMM_on_whole_tumor_samples (R/inferCNV_HMM.R:529-533)
+.icnv_whole_sample_groups <- function(infercnv_obj, cluster_by_groups) {
+    if (isTRUE(cluster_by_groups)) c(infercnv_obj@observation_grouped_cell_indices, infercnv_obj@reference_grouped_cell_indices)
+    else c(list(all_observations = unlist(infercnv_obj@observation_grouped_cell_indices)),
+           infercnv_obj@reference_grouped_cell_indices)
+}
+
+hip_predict_CNV_via_HMM_on_whole_tumor_samples <- function(infercnv_obj, cluster_by_groups,
         cnv_mean_sd = get_spike_dists(infercnv_obj@.hspike),
         cnv_level_to_mean_sd_fit = get_hspike_cnv_mean_sd_trend_by_num_cells_fit(infercnv_obj@.hspike), t = 1e-6) {
     HMM_info <- .get_HMM(cnv_mean_sd, t)
-    groups <- unlist(infercnv_obj@tumor_subclusters[["subclusters"]], recursive = FALSE)
-    sd <- vapply(groups, function(g) median(.get_state_emission_params(length(g), cnv_mean_sd,
-                                                                        cnv_level_to_mean_sd_fit)$sd), numeric(1))
-    .icnv_hmm_states(infercnv_obj, HMM_info, sd, groups)
+    groups <- .icnv_whole_sample_groups(infercnv_obj, cluster_by_groups)
+    .icnv_hmm_states(infercnv_obj, HMM_info, .icnv_i6_group_sd(groups, cnv_mean_sd, cnv_level_to_mean_sd_fit), groups)
 }
+
+hip_predict_CNV_via_HMM_on_tumor_subclusters <- function(infercnv_obj,
+        cnv_mean_sd = get_spike_dists(infercnv_obj@.hspike),
+        cnv_level_to_mean_sd_fit = get_hspike_cnv_mean_sd_trend_by_num_cells_fit(infercnv_obj@.hspike), t = 1e-6) {
+    if (is.null(infercnv_obj@tumor_subclusters)) {
+        ## R/inferCNV_HMM.R:358-361 reroutes to the whole-sample predictor (passing cnv_mean_sd in the position of
+        ## cluster_by_groups); the groups it means are the annotation groups, i.e. cluster_by_groups = TRUE
+        flog.warn("No subclusters defined, so instead running on whole samples")
+        return(hip_predict_CNV_via_HMM_on_whole_tumor_samples(infercnv_obj, TRUE, cnv_mean_sd, cnv_level_to_mean_sd_fit, t))
+    }
+    HMM_info <- .get_HMM(cnv_mean_sd, t)
+    groups <- unlist(infercnv_obj@tumor_subclusters[["subclusters"]], recursive = FALSE)
+    .icnv_hmm_states(infercnv_obj, HMM_info, .icnv_i6_group_sd(groups, cnv_mean_sd, cnv_level_to_mean_sd_fit), groups)
+}
+
+## R/inferCNV_HMM.R:412-487: per chromosome its own list of subclusters (one device call per chromosome on that
+## chromosome's rows), then every global subcluster receives its per-gene consensus state (:473-483: the
+## get_predicted_CNV_regions(by = "subcluster") overwrite, done on the device by icnv_state_consensus)
+hip_predict_CNV_via_HMM_on_tumor_subclusters_per_chr <- function(infercnv_obj, subclusters_per_chr,
+        cnv_mean_sd = get_spike_dists(infercnv_obj@.hspike),
+        cnv_level_to_mean_sd_fit = get_hspike_cnv_mean_sd_trend_by_num_cells_fit(infercnv_obj@.hspike), t = 1e-6) {
+    if (is.null(subclusters_per_chr)) {
+        flog.warn("No subclusters defined, so instead running on whole samples")
+        return(hip_predict_CNV_via_HMM_on_whole_tumor_samples(infercnv_obj, TRUE, cnv_mean_sd, cnv_level_to_mean_sd_fit, t))
+    }
+    HMM_info <- .get_HMM(cnv_mean_sd, t)
+    pm <- HMM_info[["state_emission_params"]]
+    logPi <- log(HMM_info[["state_transitions"]]); logDelta <- log(HMM_info[["delta"]])
+    x <- infercnv_obj@expr.data
+    if (!is.matrix(x)) x <- as.matrix(x)
+    hmm.data <- x
+    hmm.data[, ] <- -1
+    for (chr in unique(infercnv_obj@gene_order[[C_CHR]])) {
+        rows <- which(infercnv_obj@gene_order[[C_CHR]] == chr)
+        groups <- subclusters_per_chr[[chr]]
+        if (length(rows) == 0 || length(groups) == 0) next
+        g <- .icnv_pack(groups)
+        xc <- x[rows, , drop = FALSE]
+        storage.mode(xc) <- "double"
+        st <- .Call("icnv_R_viterbi_groups", xc, c(0L, length(rows)), g$idx, g$off, as.numeric(pm$mean),
+                    as.numeric(.icnv_i6_group_sd(groups, cnv_mean_sd, cnv_level_to_mean_sd_fit)), logPi, logDelta)
+        covered <- st != -1
+        hmm.data[rows, ][covered] <- st[covered]
+    }
+    sub <- .icnv_pack(unlist(infercnv_obj@tumor_subclusters[["subclusters"]], recursive = FALSE))
+    infercnv_obj@expr.data <- .Call("icnv_R_state_consensus_overwrite", hmm.data, sub$idx, sub$off)
+    infercnv_obj
+}
+
+## ---- i3 (R/inferCNV_i3HMM.R).  Parameters exactly as the reference prepares them in R -- including the KS-based delta,
+## which draws from R's RNG (get_HoneyBADGER_setGexpDev, :469-493) -- the Viterbi on the device.
+.icnv_i3_states <- function(infercnv_obj, sd_trend, t, i3_p_val, use_KS, groups = NULL) {
+    HMM_info <- .i3HMM_get_HMM(sd_trend, t = t, i3_p_val = i3_p_val, use_KS = use_KS)
+    sd <- median(HMM_info[["state_emission_params"]]$sd)
+    .icnv_hmm_states(infercnv_obj, HMM_info, if (is.null(groups)) sd else rep(sd, length(groups)), groups)
+}
+
+hip_i3HMM_predict_CNV_via_HMM_on_indiv_cells <- function(infercnv_obj, i3_p_val = 0.05,
+        sd_trend = .i3HMM_get_sd_trend_by_num_cells_fit(infercnv_obj, i3_p_val), t = 1e-6, use_KS = TRUE)
+    .icnv_i3_states(infercnv_obj, sd_trend, t, i3_p_val, use_KS)
+
+hip_i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples <- function(infercnv_obj, cluster_by_groups, i3_p_val = 0.05,
+        sd_trend = .i3HMM_get_sd_trend_by_num_cells_fit(infercnv_obj, i3_p_val), t = 1e-6, use_KS = TRUE)
+    .icnv_i3_states(infercnv_obj, sd_trend, t, i3_p_val, use_KS, .icnv_whole_sample_groups(infercnv_obj, cluster_by_groups))
+
+hip_i3HMM_predict_CNV_via_HMM_on_tumor_subclusters <- function(infercnv_obj, i3_p_val = 0.05,
+        sd_trend = .i3HMM_get_sd_trend_by_num_cells_fit(infercnv_obj, i3_p_val), t = 1e-6, use_KS = TRUE) {
+    if (is.null(infercnv_obj@tumor_subclusters)) {          # R/inferCNV_i3HMM.R:259-262 (same positional quirk as the i6 one)
+        flog.warn("No subclusters defined, so instead running on whole samples")
+        return(hip_i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples(infercnv_obj, TRUE, i3_p_val, sd_trend, t, use_KS))
+    }
+    .icnv_i3_states(infercnv_obj, sd_trend, t, i3_p_val, use_KS,
+                    unlist(infercnv_obj@tumor_subclusters[["subclusters"]], recursive = FALSE))
+}
+
+## state -> proxy expression value (R/inferCNV_HMM.R:1191-1206, R/inferCNV_i3HMM.R:405-417); entries that are not a
+## state of the model (e.g. -1) stay as they are, like the reference's masked assignments
+.icnv_proxy <- function(infercnv_obj, K) {
+    x <- infercnv_obj@expr.data
+    if (!is.matrix(x)) x <- as.matrix(x)
+    if (storage.mode(x) != "double") storage.mode(x) <- "double"
+    infercnv_obj@expr.data <- .Call("icnv_R_states_to_proxy", x, as.integer(K))
+    infercnv_obj
+}
+hip_assign_HMM_states_to_proxy_expr_vals <- function(infercnv_obj) .icnv_proxy(infercnv_obj, 6L)
+hip_i3HMM_assign_HMM_states_to_proxy_expr_vals <- function(infercnv_obj) .icnv_proxy(infercnv_obj, 3L)
 
 hip_apply_median_filtering <- function(infercnv_obj, window_size = 7, on_observations = TRUE, on_references = TRUE) {
     tiles <- list()
@@ -145,10 +260,9 @@ hip_apply_median_filtering <- function(infercnv_obj, window_size = 7, on_observa
     if (on_references) tiles <- c(tiles, infercnv_obj@reference_grouped_cell_indices)
     lay <- .icnv_chr_layout(infercnv_obj)
     tl <- .icnv_pack(tiles)
-    x <- as.matrix(infercnv_obj@expr.data)[lay$perm, , drop = FALSE]
-    storage.mode(x) <- "double"
+    x <- .icnv_matrix(infercnv_obj, lay)
     out <- .Call("icnv_R_median_filter", x, lay$chr_start, tl$idx, tl$off, as.integer(window_size))
-    infercnv_obj@expr.data <- out[order(lay$perm), , drop = FALSE]
+    infercnv_obj@expr.data <- .icnv_unpermute(out, lay)
     infercnv_obj
 }
 
@@ -162,11 +276,17 @@ hip_cell_dist <- function(tumor_expr_data) {
     stats::as.dist(d)
 }
 
-## Swap the package's step functions for the hip ones (called from .onLoad when the option is set).
-.icnv_enable_hip_backend <- function(device = -1L) {
-    .Call("icnv_R_init", as.integer(device))
+## Swap the package's step functions for the hip ones.  devices: 0 = every visible MI355X (cells are split into one
+## contiguous block per GPU inside the library, one host thread per GPU), n = the first n, -1 = the current one only.
+## residency: keep the last results on the device(s) so that the next step skips the upload of the matrix it was
+## handed back (a matrix is recognised by its address, its dimensions and a strided sample of its values; turn it
+## off if your code edits expr.data in place between steps).
+.icnv_enable_hip_backend <- function(devices = getOption("infercnv.hip.devices", 0L),
+                                     residency = getOption("infercnv.hip.residency", TRUE)) {
+    .Call("icnv_R_init", as.integer(devices), as.logical(residency))
     ns <- asNamespace("infercnv")
     swap <- c(subtract_ref_expr_from_obs = "hip_subtract_ref_expr_from_obs",
+              get_average_bounds = "hip_get_average_bounds",
               apply_max_threshold_bounds = "hip_apply_max_threshold_bounds",
               smooth_by_chromosome = "hip_smooth_by_chromosome",
               center_cell_expr_across_chromosome = "hip_center_cell_expr_across_chromosome",
@@ -175,6 +295,13 @@ hip_cell_dist <- function(tumor_expr_data) {
               clear_noise = "hip_clear_noise",
               predict_CNV_via_HMM_on_indiv_cells = "hip_predict_CNV_via_HMM_on_indiv_cells",
               predict_CNV_via_HMM_on_tumor_subclusters = "hip_predict_CNV_via_HMM_on_tumor_subclusters",
+              predict_CNV_via_HMM_on_tumor_subclusters_per_chr = "hip_predict_CNV_via_HMM_on_tumor_subclusters_per_chr",
+              predict_CNV_via_HMM_on_whole_tumor_samples = "hip_predict_CNV_via_HMM_on_whole_tumor_samples",
+              i3HMM_predict_CNV_via_HMM_on_indiv_cells = "hip_i3HMM_predict_CNV_via_HMM_on_indiv_cells",
+              i3HMM_predict_CNV_via_HMM_on_tumor_subclusters = "hip_i3HMM_predict_CNV_via_HMM_on_tumor_subclusters",
+              i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples = "hip_i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples",
+              assign_HMM_states_to_proxy_expr_vals = "hip_assign_HMM_states_to_proxy_expr_vals",
+              i3HMM_assign_HMM_states_to_proxy_expr_vals = "hip_i3HMM_assign_HMM_states_to_proxy_expr_vals",
               apply_median_filtering = "hip_apply_median_filtering")
     for (nm in names(swap)) {
         unlockBinding(nm, ns)
@@ -184,6 +311,10 @@ hip_cell_dist <- function(tumor_expr_data) {
     invisible(TRUE)
 }
 
-.onLoad <- function(libname, pkgname) {
+## The package may already have an .onLoad: do not define a second one here.  Add ONE line to the existing hook (or
+## create R/zzz.R with it):
+##     .onLoad <- function(libname, pkgname) { ...existing body...; .icnv_onLoad_hook() }
+.icnv_onLoad_hook <- function() {
     if (.icnv_use_hip()) .icnv_enable_hip_backend()
+    invisible(NULL)
 }

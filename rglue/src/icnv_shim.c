@@ -127,8 +127,44 @@ SEXP icnv_R_cell_distances(SEXP expr, SEXP cell_idx) {
     return out;
 }
 
-SEXP icnv_R_init(SEXP device) {
-    int rc = icnv_init(Rf_asInteger(device));
+/* .Call("icnv_R_states_to_proxy", states, K): states as the reference stores them (numeric, -1 = untouched); entries that
+ * are not a state 1..K keep their value, like the reference's masked assignments (R/inferCNV_HMM.R:1195-1200) */
+SEXP icnv_R_states_to_proxy(SEXP states, SEXP K) {
+    const R_xlen_t n = XLENGTH(states);
+    const double *x = REAL(states);
+    uint8_t *st = (uint8_t *)R_alloc((size_t)n, 1);
+    for (R_xlen_t i = 0; i < n; i++) st[i] = (x[i] >= 1.0 && x[i] <= 6.0 && x[i] == (double)(int)x[i]) ? (uint8_t)x[i] : 0xFF;
+    SEXP out = PROTECT(Rf_allocMatrix(REALSXP, Rf_nrows(states), Rf_ncols(states)));
+    int rc = icnv_states_to_proxy(st, REAL(out), (int64_t)n, Rf_asInteger(K));
+    if (rc) { UNPROTECT(1); fail(rc); }
+    double *o = REAL(out);
+    for (R_xlen_t i = 0; i < n; i++)
+        if (ISNAN(o[i])) o[i] = x[i];
+    Rf_setAttrib(out, R_DimNamesSymbol, Rf_getAttrib(states, R_DimNamesSymbol));
+    UNPROTECT(1);
+    return out;
+}
+
+/* .Call("icnv_R_state_consensus_overwrite", states, grp_idx, grp_off): every member cell of a group receives the group's
+ * per-gene consensus state (.get_state_consensus, R/inferCNV_HMM.R:977-987; the overwrite of :473-483) */
+SEXP icnv_R_state_consensus_overwrite(SEXP states, SEXP grp_idx, SEXP grp_off) {
+    const R_xlen_t n = XLENGTH(states);
+    const double *x = REAL(states);
+    uint8_t *st = (uint8_t *)R_alloc((size_t)n, 1);
+    uint8_t *so = (uint8_t *)R_alloc((size_t)n, 1);
+    for (R_xlen_t i = 0; i < n; i++) st[i] = (x[i] >= 0.0 && x[i] < 255.0) ? (uint8_t)x[i] : 0xFF;
+    int rc = icnv_state_consensus(st, Rf_nrows(states), Rf_ncols(states), (const int32_t *)INTEGER(grp_idx),
+                                  (const int32_t *)INTEGER(grp_off), (int32_t)(XLENGTH(grp_off) - 1), NULL, so);
+    if (rc) fail(rc);
+    return widen_states(so, states);
+}
+
+/* .Call("icnv_R_init", devices, residency): devices 0 = all visible GPUs, n = the first n, -1 = the current one only */
+SEXP icnv_R_init(SEXP devices, SEXP residency) {
+    const int nd = Rf_asInteger(devices);
+    int rc = icnv_init(nd < 0 ? -1 : 0);
+    if (!rc) rc = icnv_set_devices(nd < 0 ? 1 : nd);
+    if (!rc) rc = icnv_residency(Rf_asLogical(residency) == TRUE);
     if (rc) fail(rc);
     return R_NilValue;
 }
@@ -140,7 +176,9 @@ static const R_CallMethodDef call_methods[] = {
     {"icnv_R_viterbi_groups", (DL_FUNC)&icnv_R_viterbi_groups, 8},
     {"icnv_R_median_filter", (DL_FUNC)&icnv_R_median_filter, 5},
     {"icnv_R_cell_distances", (DL_FUNC)&icnv_R_cell_distances, 2},
-    {"icnv_R_init", (DL_FUNC)&icnv_R_init, 1},
+    {"icnv_R_states_to_proxy", (DL_FUNC)&icnv_R_states_to_proxy, 2},
+    {"icnv_R_state_consensus_overwrite", (DL_FUNC)&icnv_R_state_consensus_overwrite, 3},
+    {"icnv_R_init", (DL_FUNC)&icnv_R_init, 2},
     {NULL, NULL, 0}};
 
 void R_init_infercnv(DllInfo *dll) {

@@ -228,3 +228,139 @@ def test_i3_wrappers_and_sd_trend(dev):
     m3k = np.array([tr["mu"] - 0.07, tr["mu"], tr["mu"] + 0.07])
     want, _ = oc.viterbi_cells(pre, cs, m3k, tr["sigma"], np.log(Pi), np.log(delta))
     np.testing.assert_array_equal(got.expr_data, want)
+
+
+# ------------------------------------------------------------------ host-buffer path: residency, several devices
+def _host_chain_and_hmm(L, x, cs, refs, hmm):
+    import ctypes as ct
+    from infercnv_amd._lib import Cfg, check, f64, i32
+    G, C = x.shape
+    out = np.empty_like(x, order="F")
+    pre = np.empty_like(x, order="F")
+    st = np.empty((G, C), dtype=np.uint8, order="F")
+    cfg = Cfg(G, C, cs, refs)
+    vp = lambda a: a.ctypes.data_as(ct.c_void_p)
+    check(L.icnv_smooth_chain(vp(x), vp(out), vp(pre), cfg.ptr()))
+    means, sd, logPi, logDelta = hmm
+    m, mp = f64(means)
+    lp = np.asfortranarray(logPi)
+    ld, ldp = f64(logDelta)
+    csa, csp = i32(cs)
+    check(L.icnv_viterbi_cells(vp(pre), vp(st), G, C, csp, csa.size - 1, len(means), mp, float(sd),
+                               lp.ctypes.data_as(ct.POINTER(ct.c_double)), ldp))
+    return out, pre, st
+
+
+def test_residency_skips_uploads_and_notices_changes(dev):
+    """icnv_residency(1): a host matrix the library produced (or uploaded) is recognised when it comes back -- address,
+    size, fingerprint of a strided sample -- and not uploaded again; same results as without; a matrix whose sampled
+    values changed is uploaded again; freeing / reusing host memory is harmless."""
+    import ctypes as ct
+    from infercnv_amd import _lib, synth
+    from infercnv_amd._lib import Cfg, check
+    L = _lib.load()
+    G, C = 3000, 257
+    x, cs = synth.make_matrix_np(G, C)
+    x = np.asfortranarray(x)
+    refs, _ = synth.groups(C)
+    hmm = synth.hmm_params_i6()
+    stats = lambda: list((lambda b: (check(L.icnv_residency_stats(b)), b)[1])((ct.c_int64 * 4)()))
+    base = _host_chain_and_hmm(L, x, cs, refs, hmm)
+    try:
+        check(L.icnv_residency(1))
+        s0 = stats()
+        got = _host_chain_and_hmm(L, x, cs, refs, hmm)          # x uploaded; out, pre published; pre recognised by the Viterbi
+        s1 = stats()
+        assert s1[0] - s0[0] == 1 and s1[1] - s0[1] == 1 and s1[3] >= 3
+        for a, b in zip(base, got):
+            np.testing.assert_array_equal(a, b)
+        got2 = _host_chain_and_hmm(L, x, cs, refs, hmm)         # now x is recognised as well
+        s2 = stats()
+        assert s2[0] - s1[0] == 2 and s2[1] == s1[1]
+        for a, b in zip(base, got2):
+            np.testing.assert_array_equal(a, b)
+        # run()'s stand-alone steps, each fed the previous step's result: only the first matrix is uploaded
+        vp = lambda a: a.ctypes.data_as(ct.c_void_p)
+        bufs = [np.empty_like(x, order="F") for _ in range(2)]
+        cur = x
+        for i, mask in enumerate((0x01, 0x02, 0x04, 0x08, 0x10, 0x20)):
+            check(L.icnv_smooth_chain(vp(cur), vp(bufs[i & 1]), None, Cfg(G, C, cs, refs, stage_mask=mask).ptr()))
+            cur = bufs[i & 1]
+        s3 = stats()
+        assert s3[0] - s2[0] == 6 and s3[1] == s2[1]
+        assert np.abs(cur - base[1]).max() < 1e-12              # six steps == the fused chain's pre-denoise output
+        # a change at a sampled position (element 0 is always sampled) is noticed: uploaded again, result follows the data
+        x2 = x.copy(order="F")
+        ref2 = _host_chain_and_hmm(L, x2, cs, refs, hmm)
+        x2[0, 0] += 0.5
+        s4 = stats()
+        got3 = _host_chain_and_hmm(L, x2, cs, refs, hmm)
+        assert stats()[1] - s4[1] >= 1
+        assert got3[1][0, 0] != ref2[1][0, 0]
+        want3 = oc.smooth_chain(x2, cs, refs, want_pre_denoise=True)[1]
+        assert np.abs(got3[1] - want3).max() < 1e-12
+    finally:
+        check(L.icnv_residency(0))
+    assert stats()[3] == 0
+
+
+def test_in_library_multi_device_on_one_gpu(dev, tmp_path):
+    """icnv_set_devices(n): one host thread per device, cells in contiguous blocks, the chain's reference statistics added on
+    the host in device order.  Without an 8-GPU node the path runs with ICNV_FAKE_DEVICES=3 (three logical devices on this
+    GPU, separate streams and pool partitions) in a child process and is compared with the one-device result: the
+    chain within rounding of the differently ordered reference sums, the Viterbi -- same input -- bit for bit; with and
+    without residency; an empty reference share on one device; an error raised on every device."""
+    import inspect
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as ct, os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from infercnv_amd import _lib, synth
+from infercnv_amd._lib import Cfg, check
+%s
+L = _lib.load()
+check(L.icnv_init(0))
+G, C = 4000, 331
+x, cs = synth.make_matrix_np(G, C); x = np.asfortranarray(x)
+refs, _ = synth.groups(C)                      # reference cells first: all of them land on device 0
+hmm = synth.hmm_params_i6()
+check(L.icnv_set_devices(1))
+one = _host_chain_and_hmm(L, x, cs, refs, hmm)
+assert L.icnv_set_devices(4) != 0              # only 3 logical devices
+for resident in (0, 1, 1):
+    check(L.icnv_residency(resident))
+    check(L.icnv_set_devices(0)); assert L.icnv_get_devices() == 3
+    many = _host_chain_and_hmm(L, x, cs, refs, hmm)
+    assert np.abs(many[1] - one[1]).max() < 1e-12, np.abs(many[1] - one[1]).max()
+    assert (np.abs(many[0] - one[0]) > 1e-10).mean() < 1e-4
+    # the Viterbi on ONE input: the three blocks together == the single device
+    st3 = np.empty((G, C), dtype=np.uint8, order="F"); st1 = np.empty_like(st3)
+    from infercnv_amd._lib import f64, i32
+    m, mp = f64(hmm[0]); lp = np.asfortranarray(hmm[2]); ld, ldp = f64(hmm[3]); csa, csp = i32(cs)
+    vp = lambda a: a.ctypes.data_as(ct.c_void_p)
+    args = (G, C, csp, csa.size - 1, 6, mp, float(hmm[1]), lp.ctypes.data_as(ct.POINTER(ct.c_double)), ldp)
+    check(L.icnv_viterbi_cells(vp(one[1]), vp(st3), *args))
+    check(L.icnv_set_devices(1))
+    check(L.icnv_viterbi_cells(vp(one[1]), vp(st1), *args))
+    assert np.array_equal(st1, st3) and np.array_equal(st1, one[2])
+check(L.icnv_residency(0))
+# errors surface from the workers: an empty reference group, an even window
+check(L.icnv_set_devices(3))
+out = np.empty_like(x)
+bad = Cfg(G, C, cs, [refs[0], np.zeros(0, dtype=np.int32)])
+assert L.icnv_smooth_chain(vp(x), vp(out), None, bad.ptr()) == 1 and b"empty reference group" in L.icnv_last_error()
+bad = Cfg(G, C, cs, refs, window_length=100)
+assert L.icnv_smooth_chain(vp(x), vp(out), None, bad.ptr()) == 1
+# fewer cells than devices
+xs = np.asfortranarray(x[:, :2]); o2 = np.empty_like(xs)
+check(L.icnv_smooth_chain(vp(xs), vp(o2), None, Cfg(G, 2, cs, [np.array([0], dtype=np.int32)], stage_mask=0x0F).ptr()))
+check(L.icnv_set_devices(1)); o1 = np.empty_like(xs)
+check(L.icnv_smooth_chain(vp(xs), vp(o1), None, Cfg(G, 2, cs, [np.array([0], dtype=np.int32)], stage_mask=0x0F).ptr()))
+assert np.abs(o1 - o2).max() < 1e-12
+print("MULTI_OK")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), inspect.getsource(_host_chain_and_hmm))
+    env = dict(os.environ, ICNV_FAKE_DEVICES="3")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "MULTI_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
