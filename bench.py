@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--cells", type=int, default=50000, help="cells per GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--checksum", type=int, default=0, metavar="PARTS",
+                    help="also print checksums of the outputs: per rank (N > 1), or -- on one rank -- per residue class of the cell "
+                         "index modulo PARTS, i.e. the cells rank r of a PARTS-rank run holds (tests/test_gpu_entrypoints.py)")
     args = ap.parse_args()
 
     import numpy as np
@@ -174,6 +177,21 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
+
+    checksums = None
+    if args.checksum:
+        pre_last = step()
+        torch.cuda.synchronize()
+        def sums(sel):
+            return [float(out[sel].sum(dtype=torch.float64)), float(pre_last[sel].sum(dtype=torch.float64)),
+                    int(states[sel].sum(dtype=torch.int64))]
+        if world > 1:
+            mine = torch.tensor(sums(slice(None)), dtype=torch.float64, device="cuda")
+            allv = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allv, mine)
+            checksums = [[float(v[0]), float(v[1]), int(v[2])] for v in allv]
+        else:
+            checksums = [sums(slice(r, None, args.checksum)) for r in range(args.checksum)]
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -246,6 +264,8 @@ def main():
             "roofline_by_kernel": roof,
             "kernels": kernels,
         }
+        if checksums is not None:
+            res["checksums"] = {"per_part": checksums, "meaning": "[sum(denoised), sum(hmm_input), sum(states)] of the cells of rank r"}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(G)
         elif not args.no_cpu_baseline:
