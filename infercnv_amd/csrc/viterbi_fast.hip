@@ -40,10 +40,6 @@
 
 #pragma clang fp contract(off)
 
-#ifndef ICNV_VF_EXP
-#define ICNV_VF_EXP 0
-#endif
-
 namespace icnv {
 
 namespace {
@@ -193,14 +189,9 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             sc[0] = 0.0;   // the table holds s_k - s_1: a term common to all states changes no decision
 #pragma unroll
             for (int k = 1; k < K; ++k) {
-#if ICNV_VF_EXP & 16
-                const double2 c01 = make_double2(tn + k, tn * 2), c23 = make_double2(tn + 3, tn + 4 * k), c45 = make_double2(0.1 * tn, tn + 7);
-                (void)c;
-#else
                 const double2 c01 = *reinterpret_cast<const double2 *>(c + (k - 1) * NCF);
                 const double2 c23 = *reinterpret_cast<const double2 *>(c + (k - 1) * NCF + 2);
                 const double2 c45 = *reinterpret_cast<const double2 *>(c + (k - 1) * NCF + 4);
-#endif
                 double p = __builtin_fma(c45.y, tn, c45.x);
                 p = __builtin_fma(p, tn, c23.y);
                 p = __builtin_fma(p, tn, c23.x);
@@ -226,9 +217,6 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             double e[K];
 #pragma unroll
             for (int k = K - 1; k >= 0; --k) {
-#if ICNV_VF_EXP & 4
-                nu[k] += sc[k]; e[k] = 0.0; continue;
-#endif
                 e[k] = nu[k] - c;
                 sb = __builtin_amdgcn_alignbit(sb, (uint32_t)__double2hiint(e[k]), 31);   // (sb << 1) | sign(e_k)
                 band |= __builtin_amdgcn_ballot_w64(!(__builtin_fabs(e[k]) > thr));
@@ -263,9 +251,6 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             locate(xv, idx, tn);
             poly(idx, tn, sc);
             const uint32_t word = step(sc);
-#if ICNV_VF_EXP & 2
-            if (word == 0xdeadbeefu)
-#endif
 #if ICNV_VF_POLICY & 2
             __builtin_nontemporal_store((uint16_t)word, bpc + i * 64);
 #else
@@ -289,11 +274,6 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         // small unaligned pieces of a DRAM burst arrive as separate requests long after the burst was evicted.
         constexpr int CH = ICNV_VF_CH;
         auto load_chunk = [&](const double *p, double (&v)[CH]) {
-#if ICNV_VF_EXP & 8
-#pragma unroll
-            for (int j = 0; j < CH; ++j) v[j] = 1.0 + 1e-3 * lane + 0.01 * j;
-            return;
-#endif
 #pragma unroll
             for (int j = 0; j < CH; j += 2) {
 #if ICNV_VF_POLICY & 1
@@ -374,9 +354,6 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         // the traceback follows the decisions of ONE path: only an uncertain decision ON that path (or an
         // uncertain final arg-max) can make the exact arithmetic trace a different one
         uint32_t unsure = (((seqflag >> lane) & 1u) || !(m1 - m2 > thr)) ? 1u : 0u;
-#if ICNV_VF_EXP & 1
-        if (m1 == 12345.678) 
-#endif
         {
             // OR of the words shifted by the traced state: bit 9 collects the "inside the band" bits of the path's rows
             uint32_t uacc = 0;
