@@ -294,6 +294,7 @@ int icnv_states_to_proxy_dev(const uint8_t *states, double *out, int64_t n, int3
  * R/inferCNV_i3HMM.R:17-80; also clear_noise's centre).  out2_host = {mu, sigma}. */
 int icnv_cells_mean_sd_dev(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx,
                            int64_t n_cells, double *out2_host, void *stream);
+int icnv_cells_mean_sd(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx, int64_t n_cells, double *out2);
 
 /* ---- 2-D median denoise -------------------------------------------------- */
 /* apply_median_filtering / .median_filter (R/noise_reduction.R:43-113): for

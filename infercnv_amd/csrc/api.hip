@@ -1345,6 +1345,15 @@ int icnv_cells_mean_sd_dev(const double *expr, int64_t G, int64_t C, const int32
     return ICNV_OK;
 }
 
+int icnv_cells_mean_sd(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx, int64_t n_cells, double *out2) {
+    if (!expr || !out2 || G < 1 || C < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    int rc = validate_index_list(cell_idx, n_cells, C, "cell");
+    if (rc) return rc;
+    MatrixLease in;
+    if ((rc = acquire_input(expr, G * C, nullptr, in))) return rc;
+    return icnv_cells_mean_sd_dev(in.dev, G, C, cell_idx, n_cells, out2, nullptr);
+}
+
 // ------------------------------------------------------------------ median filter
 int icnv_median_filter_dev(const double *expr_in, double *expr_out, int64_t G, int64_t C, const int32_t *chr_start,
                            int32_t n_chr, const int32_t *tile_idx, const int32_t *tile_off, int32_t n_tiles,

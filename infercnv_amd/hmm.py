@@ -263,9 +263,12 @@ def i3HMM_get_sd_trend(infercnv_obj: InfercnvObject, i3_p_val=0.05):
     (R/inferCNV_i3HMM.R:17-80; the KS delta is RNG-driven and stays host-side)."""
     idx = (infercnv_obj.get_reference_grouped_cell_indices() if infercnv_obj.has_reference_cells()
            else np.concatenate([np.asarray(v) for v in infercnv_obj.observation_grouped_cell_indices.values()]))
-    vals = np.asarray(infercnv_obj.expr_data)[:, idx].astype(np.float64).ravel()
-    mu = float(np.mean(vals))
-    sigma = float(np.std(vals, ddof=1))
+    L = _lib.load()
+    x = np.asfortranarray(infercnv_obj.expr_data, dtype=np.float64)
+    ci, cp = i32(idx)
+    buf = (ct.c_double * 2)()
+    check(L.icnv_cells_mean_sd(x.ctypes.data_as(ct.c_void_p), x.shape[0], x.shape[1], cp, ci.size, buf))   # mean / sd on the device
+    mu, sigma = float(buf[0]), float(buf[1])
     return {"mu": mu, "sigma": sigma, "mean_delta": determine_mean_delta_via_Z(sigma, i3_p_val), "KS_delta": None}
 
 
