@@ -269,7 +269,7 @@ def main():
             roof["viterbi"]["note"] = (f"certified fast path ({st['path']}; {st['flagged']} of {st['sequences']} sequences redone exactly): "
                                        "table-driven emission scores + max-plus recurrence, about 91 fp64/integer vector instructions and "
                                        "18 LDS gathers per gene and wavefront, every lane streaming its own column; "
-                                       "issue/LDS/latency-bound, no MFMA-shaped work")
+                                       "issue / LDS / latency share the time, no MFMA-shaped work")
         if "viterbi" in roof:
             # second ceiling of the Viterbi (SURVEY.md 8d asks for HBM GB/s *and* the fp64 rate): its forward pass issues
             # ~91 vector instructions per gene and wavefront (static count, scripts/vf_asm_stats.py), every one of them 4
@@ -279,9 +279,10 @@ def main():
             roof["viterbi"]["fp64_issue"] = {"vector_instr_per_gene_wavefront": instr, "ceiling_ms": ceil_ms,
                                              "frac": ceil_ms / kernels["viterbi"]["avg_ms"],
                                              "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TF,
-                                             "note": "share of the launch the vector pipes would need at full issue rate; the rest is "
-                                                     "LDS coefficient gathers (15 x 16-byte reads per gene and lane, random intervals: "
-                                                     "the LDS pipe, not the vector pipe, paces the kernel) and the per-lane column streams"}
+                                             "note": "share of the launch the vector pipes would need at full issue rate; the rest is the "
+                                                     "dependent chain per gene (two LDS lookups, 15 coefficient gathers at random intervals, "
+                                                     "Horner chains, max-plus step) behind two wavefronts per SIMD, and the per-lane column "
+                                                     "streams -- no single pipe paces it (DESIGN.md K4b)"}
         dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
         traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(traffic_file) and G == 10000 and C_local == 50000:   # counters were collected on this shape
