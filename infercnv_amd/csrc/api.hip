@@ -879,7 +879,9 @@ struct ViterbiCtx {
 std::mutex g_vctx_mu;
 std::map<int, ViterbiCtx *> g_vctx;
 ViterbiCtx *viterbi_ctx_ptr() {
-    const int dev = current_device();
+    // per device AND pool partition: the workers of the one-GPU test of the multi-device path (ICNV_FAKE_DEVICES) run
+    // concurrently on one device and must not share task / flag counters any more than workers on different GPUs do
+    const int dev = pool_domain();
     std::lock_guard<std::mutex> lk(g_vctx_mu);
     ViterbiCtx *&c = g_vctx[dev];
     if (!c) c = new ViterbiCtx();
