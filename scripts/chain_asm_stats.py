@@ -4,7 +4,8 @@ Inserts `; MARK <phase>` comments at the phase boundaries of chain_kernel.inc, c
 assembly and counts VALU / LDS / VMEM / SALU / v_readlane instructions between the markers."""
 import collections, os, re, subprocess, sys, tempfile
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "infercnv_amd", "csrc")
-variant = sys.argv[1] if len(sys.argv) > 1 else "Li768ELi15ELi2ELi0ELi127E"
+variant = sys.argv[1] if len(sys.argv) > 1 else "Li768ELi15ELi2ELi0ELi127ELi7ELi50E"
+launch = sys.argv[2] if len(sys.argv) > 2 else "launch_chain_m<768, 15, 2, 7, 50>"   # e.g. "launch_chain_v<768, 15>" with Li768ELi15ELi2ELi0ELi127ELi0ELi0E
 src = open(os.path.join(root, "chain_kernel.inc")).read()
 marks = [("        // ---------------- [A] steps 8, 9", "A"), ("        // ---------------- [C] step 22", "C"),
          ("        // ---------------- [D] steps 10, 11", "D_smooth_init"),
@@ -25,7 +26,7 @@ for m, name in marks:
     src = src.replace(m, 'asm volatile("; MARK %s");\n' % name + m, 1)
 tmp = tempfile.mkdtemp()
 open(os.path.join(tmp, "chain_mark.inc"), "w").write(src)
-open(os.path.join(tmp, "m15.hip"), "w").write('#include "%s/chain_mark.inc"\nnamespace icnv { int launch_chain_m15(const ChainArgs &a, int mode, hipStream_t s) { return launch_chain_v<768, 15>(a, mode, s); } }\n' % tmp)
+open(os.path.join(tmp, "m15.hip"), "w").write('#include "%s/chain_mark.inc"\nnamespace icnv { int launch_chain_m15(const ChainArgs &a, int mode, hipStream_t s) { return %s(a, mode, s); } }\n' % (tmp, launch))
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + root, "-I" + os.path.join(root, "..", "..", "include"),
                 "-S", "--cuda-device-only", "-o", os.path.join(tmp, "o.s"), os.path.join(tmp, "m15.hip")], check=True, stderr=subprocess.DEVNULL)
 s = open(os.path.join(tmp, "o.s")).read()

@@ -101,6 +101,30 @@ def test_chain_fused_vs_oracle(dev, G, C, nref):
     assert np.isin(got[flips], [mu]).all() or np.isin(ref_out[flips], [mu]).all()
 
 
+# (genes, window, kernel variant the geometry rules of chain_kernels.hip pick): the run-time-window and the
+# compile-time-window (101) forms of 1024 x 11 / five slots and 768 x 15 / seven slots, and 768 x 15 / eight slots
+@pytest.mark.parametrize("G,window,variant", [(9000, 61, "w11"), (10060, 101, "w11t"), (10400, 41, "m15s"),
+                                              (10300, 101, "m15t"), (10900, 21, "m15")])
+def test_chain_geometries_and_windows(dev, G, window, variant):
+    """Every (threads x chunk length, slots, window form) variant of the fused kernel against the oracle: the full chain,
+    the chain without denoise, and stage subsets that run the generic (run-time mask) kernels of the same geometry."""
+    from infercnv_amd import synth
+    C = 300                                                  # more cells than workgroups
+    x, cs = synth.make_matrix_np(G, C)
+    refs = [np.arange(0, 17, dtype=np.int32), np.arange(17, 40, dtype=np.int32)]
+    xd = to_dev(x)
+    for mask in (0x7F, 0x3F):
+        out, pre = dev.smooth_chain(xd, cs, refs, window_length=window, stage_mask=mask, want_pre_denoise=True)
+        want_out, want_pre, _ = oc.smooth_chain(x, cs, refs, window_length=window, stage_mask=mask, want_pre_denoise=True)
+        if mask == 0x3F:
+            want_pre = want_out
+        assert np.abs(to_host(pre) - want_pre).max() < 1e-11, (variant, hex(mask))
+        assert (np.abs(to_host(out) - want_out) > 1e-11).mean() < 1e-4, (variant, hex(mask))
+    got = to_host(dev.smooth_chain(xd, cs, refs, window_length=window, stage_mask=0x0C)[0])   # smooth + centre only
+    want = oc.center_columns(oc.smooth_by_chromosome(x, cs, window), "median")
+    assert np.abs(got - want).max() < 1e-11, variant
+
+
 STAGES = {"st8": 0x01, "st9": 0x02, "st10": 0x04, "st11": 0x08, "st12": 0x10, "st14": 0x20, "st22": 0x40,
           "st11mean": 0x88}
 
@@ -239,6 +263,29 @@ def test_chain_median_edge_cases(dev):
         out, _ = dev.smooth_chain(to_dev(x), cs, [np.array([0], dtype=np.int32)], stage_mask=0x08)
         want = onp.center_columns(x, "median")
         np.testing.assert_array_equal(to_host(out), want)
+
+
+def test_chain_median_borrowed_range(dev):
+    """The median select bins a cell with the value range of the last cell its workgroup measured and measures again
+    only when the middle rank falls into the lowest bin.  Many cells per workgroup whose ranges have nothing to do with
+    each other: shifted far below / above the previous cell, six orders of magnitude narrower or wider, constant cells,
+    ties at the median, values piled up at one end -- the medians must be exact whatever range was borrowed."""
+    rng = np.random.default_rng(11)
+    for G in (1001, 4096):
+        C = 4096
+        shift = rng.choice([-1e6, -50.0, -1.0, 0.0, 0.0, 1.0, 50.0, 1e6], size=C) * rng.random(C)
+        scale = 10.0 ** rng.integers(-6, 4, size=C)
+        x = rng.normal(size=(G, C)) * scale + shift
+        kinds = rng.integers(0, 8, size=C)
+        x[:, kinds == 0] = np.round(x[:, kinds == 0], 0)                          # heavy ties
+        x[:, kinds == 1] = shift[kinds == 1]                                      # constant cells
+        m2 = kinds == 2                                                           # most values piled at the lower end
+        x[:, m2] = np.where(rng.random((G, int(m2.sum()))) < 0.8, x[:, m2].min(axis=0), x[:, m2])
+        m3 = kinds == 3                                                           # ... at the upper end
+        x[:, m3] = np.where(rng.random((G, int(m3.sum()))) < 0.8, x[:, m3].max(axis=0), x[:, m3])
+        cs = np.array([0, G // 3, G], dtype=np.int32)
+        out, _ = dev.smooth_chain(to_dev(x), cs, [np.array([0], dtype=np.int32)], stage_mask=0x08)
+        np.testing.assert_array_equal(to_host(out), onp.center_columns(x, "median"))
 
 
 def test_chain_median_paths_full_chain(dev):
