@@ -959,7 +959,12 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
     // the certified fast path needs a shared sd, the .get_HMM transition structure and a table that met its accuracy target
     bool fast = false;
     double a = 0, b = 0;
-    if (g_viterbi_mode.load() == 0 && !sd_per_col_dev && ncols >= 64 && structured_pi(p, a, b)) {
+    // ... and initial log probabilities the recurrence can start from: no NaN / +Inf, at least one finite (a state with
+    // probability 0 -- -Inf -- is fine: it takes the off-diagonal candidate at the first step)
+    bool delta_ok = false;
+    for (int k = 0; k < p.K; ++k) delta_ok = delta_ok || std::isfinite(p.logDelta[k]);
+    for (int k = 0; k < p.K; ++k) delta_ok = delta_ok && !(std::isnan(p.logDelta[k]) || p.logDelta[k] == INFINITY);
+    if (g_viterbi_mode.load() == 0 && !sd_per_col_dev && ncols >= 64 && delta_ok && structured_pi(p, a, b)) {
         if ((rc = fast_table_for(vc, p, sd_shared, s, fast))) return rc;
     }
     vc.stats[0] = fast ? 1 : 0;

@@ -100,26 +100,51 @@ __device__ inline double max_raw_s(double x, double y) {
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "s"(y));
     return r;
 }
-// "Near the top" masks of three states and the state number of the lanes' near-top state in one block:
-//   m_j = lanes with e_j >= t2;  i1 = m_j ? KA - j : i1   (j = 0, 1, 2: states KA, KA - 1, KA - 2).
-// Written out because (a) the compiler recomputes a comparison with the opposite sense when its mask feeds both a
-// ballot and a select, and (b) gfx950 wants two wait states between a vector instruction that writes a scalar
-// register and a vector instruction that reads it -- the compiler pads its own code with s_nop, but it does not
-// look inside an asm statement.  Three comparisons, then three selects: every select is two instructions behind
-// its comparison.
-template <int KA>
-__device__ inline void near_top3(double e0, double e1, double e2, double t2, uint32_t &i1, uint64_t &m0, uint64_t &m1,
-                                 uint64_t &m2) {
+// Which states are "near the top" (e_k >= t2, i.e. nu_k >= m1 - thr): bit k of the result, per lane.  The K comparisons
+// leave wave masks in scalar registers, K v_addc_co_u32 (2 b + carry) shift them into the lane's word -- the best
+// predecessor is then the lowest set bit, "more than one state near the top" a population count: two instructions per
+// state and three per gene, where selects into i1 plus the scalar and / or tree over the masks took two per state and
+// fifteen per gene.  One block: the compiler does not look inside asm for the wait states gfx950 wants between a vector
+// instruction that writes a scalar register and a vector instruction that reads it -- every add is K instructions
+// behind its comparison.
+template <int K>
+__device__ inline uint32_t near_top_bits(const double (&e)[K], double t2);
+template <>
+__device__ inline uint32_t near_top_bits<6>(const double (&e)[6], double t2) {
+    uint32_t b = 0;
+    uint64_t m0, m1, m2, m3, m4, m5;
+    asm("v_cmp_ge_f64_e64 %1, %7, %13\n\t"
+        "v_cmp_ge_f64_e64 %2, %8, %13\n\t"
+        "v_cmp_ge_f64_e64 %3, %9, %13\n\t"
+        "v_cmp_ge_f64_e64 %4, %10, %13\n\t"
+        "v_cmp_ge_f64_e64 %5, %11, %13\n\t"
+        "v_cmp_ge_f64_e64 %6, %12, %13\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %1\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %2\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %3\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %4\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %5\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %6"
+        : "+v"(b), "=&s"(m5), "=&s"(m4), "=&s"(m3), "=&s"(m2), "=&s"(m1), "=&s"(m0)
+        : "v"(e[5]), "v"(e[4]), "v"(e[3]), "v"(e[2]), "v"(e[1]), "v"(e[0]), "s"(t2)
+        : "vcc");
+    return b;
+}
+template <>
+__device__ inline uint32_t near_top_bits<3>(const double (&e)[3], double t2) {
+    uint32_t b = 0;
+    uint64_t m0, m1, m2;
     asm("v_cmp_ge_f64_e64 %1, %4, %7\n\t"
         "v_cmp_ge_f64_e64 %2, %5, %7\n\t"
         "v_cmp_ge_f64_e64 %3, %6, %7\n\t"
-        "v_cndmask_b32_e64 %0, %0, %8, %1\n\t"
-        "v_cndmask_b32_e64 %0, %0, %9, %2\n\t"
-        "v_cndmask_b32_e64 %0, %0, %10, %3"
-        : "+v"(i1), "=&s"(m0), "=&s"(m1), "=&s"(m2)
-        : "v"(e0), "v"(e1), "v"(e2), "s"(t2), "n"(KA), "n"(KA - 1), "n"(KA - 2));
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %1\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %2\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %3"
+        : "+v"(b), "=&s"(m2), "=&s"(m1), "=&s"(m0)
+        : "v"(e[2]), "v"(e[1]), "v"(e[0]), "s"(t2)
+        : "vcc");
+    return b;
 }
-
 template <int K>
 __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbiArgs A) {
     extern __shared__ __attribute__((aligned(16))) double tab[];
@@ -212,26 +237,24 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
 #pragma unroll
             for (int k = 1; k < K; ++k) m1 = max_raw(m1, nu[k]);
             const double c = m1 + ab;
-            uint32_t sb = 0, i1 = 0;   // i1: the one state near the top (when there are two, the rows that need it are flagged)
-            uint64_t band = 0;
+            uint32_t sb = 0;
             double e[K];
+            double amin = 0.0;   // min_k |e_k|: one comparison for "some row's decision lies inside the band"
 #pragma unroll
             for (int k = K - 1; k >= 0; --k) {
                 e[k] = nu[k] - c;
                 sb = __builtin_amdgcn_alignbit(sb, (uint32_t)__double2hiint(e[k]), 31);   // (sb << 1) | sign(e_k)
-                band |= __builtin_amdgcn_ballot_w64(!(__builtin_fabs(e[k]) > thr));
+                amin = (k == K - 1) ? __builtin_fabs(e[k]) : __builtin_fmin(amin, __builtin_fabs(e[k]));   // (differences: no canonicalisation)
                 nu[k] = max_raw(nu[k], c);
                 if (k > 0) nu[k] += sc[k];
             }
-            static_assert(K == 3 || K == 6, "near_top3 blocks");
-            uint64_t n0, n1, n2;
-            near_top3<K - 1>(e[K - 1], e[K - 2], e[K - 3], t2, i1, n0, n1, n2);
-            uint64_t two_near = (n0 & n1) | ((n0 | n1) & n2);
-            if (K == 6) {
-                const uint64_t seen = n0 | n1 | n2;
-                near_top3<2>(e[2], e[1], e[0], t2, i1, n0, n1, n2);
-                two_near |= (seen & (n0 | n1 | n2)) | (n0 & n1) | ((n0 | n1) & n2);
-            }
+            // (e_k is never NaN: the launch requires a finite initial log probability, so m1 and c are finite, and a row
+            // at -Inf gives e_k = -Inf)
+            const uint64_t band = __builtin_amdgcn_ballot_w64(!(amin > thr));
+            static_assert(K == 3 || K == 6, "near_top_bits blocks");
+            const uint32_t near = near_top_bits<K>(e, t2);
+            const uint32_t i1 = (uint32_t)__builtin_ctz(near | 0x80u);   // the one state near the top (when there are two, the rows that need it are flagged)
+            const uint64_t two_near = __builtin_amdgcn_ballot_w64(__builtin_popcount(near) != 1);   // (none: cannot happen with finite values; flagged all the same)
             uint32_t word = sb | (i1 << 6);
             // the "inside the band" bits are needed by almost no gene: one scalar branch for the whole wavefront
             if (__builtin_expect((band | two_near) != 0, 0)) {
