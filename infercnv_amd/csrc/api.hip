@@ -520,6 +520,15 @@ int icnv_chain_round_partial_dev(icnv_chain_t *ch, int round, const double *expr
         return ICNV_OK;
     }
     double *sums = ch->d_sums.as<double>();
+    if (a.mask == 0 && !ch->cfg.inv_log && ng <= 256) {
+        // no stage in front of this round (run()'s first one): the raw sums of every group in one streaming launch
+        if ((rc = launch_group_gene_sums(expr_in, (int32_t)G, ch->d_ref.as<int32_t>(), ch->d_ref_off.as<int32_t>(), ng,
+                                         ch->d_partial.as<double>(), 256, sums, s)))
+            return rc;
+        if (partial_dev) *partial_dev = sums;
+        if (n) *n = G * ng + ng;
+        return ICNV_OK;
+    }
     const bool fill_cache = ch->cache_enabled && (a.mask & (ICNV_ST_SMOOTH | ICNV_ST_CENTER));
     if (fill_cache) ch->cache_in = nullptr;
     for (int q = 0; q < ng; ++q) {

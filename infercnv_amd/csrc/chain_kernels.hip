@@ -58,24 +58,80 @@ __device__ inline double wave_max(double v) {
     return v;
 }
 
-// sums[g] = sum_b partial[b*G + g] in a fixed order (four interleaved partial sums combined at the
-// end, so the loads pipeline); also stores the cell count.
-__global__ void reduce_partials_kernel(const double *partial, int nblk, int G, double *out, double count,
-                                       double *count_out) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+// sums[g] = sum_b partial[b*G + g] in a fixed order; also stores the cell count.  64 genes per workgroup, the rows dealt
+// to four wavefronts (row b to wavefront b mod 4, four interleaved partial sums each so that the loads pipeline), the four
+// wavefront sums combined in LDS in wavefront order: 16 accumulators per gene, always added in the same order.
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const double *partial, int nblk, int G, double *out, double count,
+                                                              double *count_out) {
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g = blockIdx.x * 64 + lane;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (g < G) {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int b = 0;
-        for (; b + 4 <= nblk; b += 4) {
+        int b = w;
+        for (; b + 12 < nblk; b += 16) {
             s0 += partial[(int64_t)(b + 0) * G + g];
-            s1 += partial[(int64_t)(b + 1) * G + g];
-            s2 += partial[(int64_t)(b + 2) * G + g];
-            s3 += partial[(int64_t)(b + 3) * G + g];
+            s1 += partial[(int64_t)(b + 4) * G + g];
+            s2 += partial[(int64_t)(b + 8) * G + g];
+            s3 += partial[(int64_t)(b + 12) * G + g];
         }
-        for (; b < nblk; ++b) s0 += partial[(int64_t)b * G + g];
-        out[g] = (s0 + s1) + (s2 + s3);
+        for (; b < nblk; b += 4) s0 += partial[(int64_t)b * G + g];
     }
-    if (g == 0 && count_out) *count_out = count;
+    red[w][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (w == 0 && g < G) out[g] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && count_out) *count_out = count;
+}
+
+// Raw per-gene sums of the reference groups -- the first reference round when no stage precedes step 8 (run()'s case:
+// R/inferCNV_ops.R:1708-1735 takes rowMeans of the step-7 matrix): a plain streaming reduction, every group in one
+// launch.  Workgroup (tile, split, group): 256 threads x the split's share of the group's cells, four interleaved sums per
+// gene; partial[(group * S + split) * G + g].  Fixed assignment and order -> deterministic.
+template <int VEC>   // VEC = 2: G even, every thread adds 16-byte pieces (two adjacent genes); VEC = 1: any G
+__global__ void __launch_bounds__(256) group_gene_sums_kernel(const double *x, int G, const int32_t *cells, const int32_t *off,
+                                                              int S, double *partial) {
+    typedef double dv2 __attribute__((ext_vector_type(2)));
+    const int q = blockIdx.z, sp = blockIdx.y;
+    const int b = off[q], e = off[q + 1];
+    const int per = (e - b + S - 1) / S;
+    const int lo = b + sp * per, hi = min(e, lo + per);
+    const int g = (blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (g >= G) return;
+    double *dst = partial + ((int64_t)q * S + sp) * G + g;
+    int i = lo;
+    if constexpr (VEC == 2) {
+        dv2 a0 = {0.0, 0.0}, a1 = a0, a2 = a0, a3 = a0;
+        for (; i + 4 <= hi; i += 4) {
+            a0 += __builtin_nontemporal_load(reinterpret_cast<const dv2 *>(x + (int64_t)cells[i] * G + g));
+            a1 += __builtin_nontemporal_load(reinterpret_cast<const dv2 *>(x + (int64_t)cells[i + 1] * G + g));
+            a2 += __builtin_nontemporal_load(reinterpret_cast<const dv2 *>(x + (int64_t)cells[i + 2] * G + g));
+            a3 += __builtin_nontemporal_load(reinterpret_cast<const dv2 *>(x + (int64_t)cells[i + 3] * G + g));
+        }
+        for (; i < hi; ++i) a0 += __builtin_nontemporal_load(reinterpret_cast<const dv2 *>(x + (int64_t)cells[i] * G + g));
+        *reinterpret_cast<dv2 *>(dst) = (a0 + a1) + (a2 + a3);
+    } else {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (; i + 4 <= hi; i += 4) {
+            a0 += __builtin_nontemporal_load(x + (int64_t)cells[i] * G + g);
+            a1 += __builtin_nontemporal_load(x + (int64_t)cells[i + 1] * G + g);
+            a2 += __builtin_nontemporal_load(x + (int64_t)cells[i + 2] * G + g);
+            a3 += __builtin_nontemporal_load(x + (int64_t)cells[i + 3] * G + g);
+        }
+        for (; i < hi; ++i) a0 += __builtin_nontemporal_load(x + (int64_t)cells[i] * G + g);
+        *dst = (a0 + a1) + (a2 + a3);
+    }
+}
+// sums[q*G + g] = sum over the S splits (in split order), counts[q] = cells of the group
+__global__ void __launch_bounds__(256) reduce_group_partials_kernel(const double *partial, int S, int G, int n_grp,
+                                                                    const int32_t *off, double *sums) {
+    const int g = blockIdx.x * 256 + threadIdx.x, q = blockIdx.y;
+    if (g < G) {
+        const double *p = partial + (int64_t)q * S * G + g;
+        double s = 0.0;
+        for (int k = 0; k < S; ++k) s += p[(int64_t)k * G];
+        sums[(int64_t)q * G + g] = s;
+    }
+    if (g == 0) sums[(int64_t)n_grp * G + q] = (double)(off[q + 1] - off[q]);
 }
 
 // .get_normal_gene_mean_bounds + the min/max / mean-of-means of .subtract_expr
@@ -322,8 +378,30 @@ int launch_chain(const ChainArgs &a0, int mode, hipStream_t stream) {
 int launch_reduce_partials(const double *partial, int nblk, int32_t G, double *out, double count,
                            double *count_out, hipStream_t stream) {
     KernelTimer kt("reduce_partials", stream);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((G + 63) / 64), dim3(64), 0, stream, partial, nblk, G, out,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((G + 63) / 64), dim3(256), 0, stream, partial, nblk, G, out,
                        count, count_out);
+    ICNV_HIP(hipGetLastError());
+    return ICNV_OK;
+}
+
+int launch_group_gene_sums(const double *x, int32_t G, const int32_t *cells_dev, const int32_t *off_dev, int32_t n_grp,
+                           double *partial, int32_t partial_rows, double *sums_counts, hipStream_t stream) {
+    if (n_grp <= 0) return ICNV_OK;
+    if (n_grp > partial_rows) ICNV_FAIL(ICNV_ERR_ARG, "more reference groups than rows of the partial-sum buffer");
+    const int S = std::max(1, std::min(32, partial_rows / n_grp));
+    {
+        KernelTimer kt("chain_gene_sums", stream);
+        if ((G & 1) == 0)
+            hipLaunchKernelGGL(group_gene_sums_kernel<2>, dim3((G / 2 + 255) / 256, S, n_grp), dim3(256), 0, stream, x, G, cells_dev,
+                               off_dev, S, partial);
+        else
+            hipLaunchKernelGGL(group_gene_sums_kernel<1>, dim3((G + 255) / 256, S, n_grp), dim3(256), 0, stream, x, G, cells_dev,
+                               off_dev, S, partial);
+        ICNV_HIP(hipGetLastError());
+    }
+    KernelTimer kt("reduce_partials", stream);
+    hipLaunchKernelGGL(reduce_group_partials_kernel, dim3((G + 255) / 256, n_grp), dim3(256), 0, stream, partial, S, G, n_grp,
+                       off_dev, sums_counts);
     ICNV_HIP(hipGetLastError());
     return ICNV_OK;
 }

@@ -136,6 +136,9 @@ int chain_build_inv_table(const int32_t *chr_start, int32_t n_chr, int32_t G, in
                           std::vector<uint32_t> &codes, std::vector<double> &dict, bool &coded);
 int launch_reduce_partials(const double *partial, int nblk, int32_t G, double *out, double count,
                            double *count_out, hipStream_t stream);
+// raw per-gene sums of all reference groups in one launch (+ the reduction over its splits): sums_counts = [G*n_grp | n_grp]
+int launch_group_gene_sums(const double *x, int32_t G, const int32_t *cells_dev, const int32_t *off_dev, int32_t n_grp,
+                           double *partial, int32_t partial_rows, double *sums_counts, hipStream_t stream);
 int launch_bounds_from_sums(const double *sums_counts, int32_t G, int32_t n_grp, int32_t use_bounds, int32_t inv_log,
                             double *bounds, hipStream_t stream);
 int launch_reduce_cell_stats(const double *cell_stats, int32_t n_cells, int32_t G, double *out4,
