@@ -26,6 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy ceiling
+STREAM_1R2W_GBS = 5300.0     # what a plain grid-stride kernel gets for the fused pass's traffic mix (one matrix read, two
+                             # written; scripts/ubench/stream_1r2w.hip on MI355X: 5.2-5.3 TB/s with or without nt hints)
 FP64_VECTOR_PEAK_TF = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 
 
@@ -261,20 +263,22 @@ def main():
         if "chain_apply" in roof:
             roof["chain_apply"]["note"] = (
                 f"fused smooth pass (steps 8-14 + 22) over the {n_main} non-reference cells of this rank: reads each cell once, writes "
-                "the denoised matrix and -- not counted in the algorithmic bytes -- the pre-denoise HMM input (+8 B/gene*cell); paced by "
-                "its barrier-separated phases (one workgroup per CU walks a cell through ~10 barriers: vector issue, LDS round trips and "
-                "the L2 latency of the bound vectors are exposed in lock-step), not by HBM -- DESIGN.md section 4 has the ablation")
+                "the denoised matrix and -- not counted in the algorithmic bytes -- the pre-denoise HMM input (+8 B/gene*cell, the "
+                "Viterbi's observations): 24 B of HBM traffic per gene*cell.  `frac` prices the 16 algorithmic bytes against the 8 TB/s "
+                "spec; `hbm_traffic` prices what the pass really moves, also against what a plain 1-read : 2-write stream reaches on "
+                "this GPU -- the pass is paced by the memory system (DESIGN.md section 4: ablations, phase profile)")
         if "viterbi" in roof:
             st = device.viterbi_last_stats()
             roof["viterbi"]["note"] = (f"certified fast path ({st['path']}; {st['flagged']} of {st['sequences']} sequences redone exactly): "
-                                       "table-driven emission scores + max-plus recurrence, about 91 fp64/integer vector instructions and "
-                                       "18 LDS gathers per gene and wavefront, every lane streaming its own column; "
-                                       "issue / LDS / latency share the time, no MFMA-shaped work")
+                                       "table-driven emission scores + max-plus recurrence, about 99 vector and 37 other instructions "
+                                       "(18 of them LDS gathers) per gene and wavefront, every lane streaming its own column; paced by the "
+                                       "dependent chain of a gene step behind two wavefronts per SIMD (hardware counters: vector pipes busy "
+                                       "~60 % of the launch, the wavefronts stalled ~55 % of their life), no MFMA-shaped work")
         if "viterbi" in roof:
             # second ceiling of the Viterbi (SURVEY.md 8d asks for HBM GB/s *and* the fp64 rate): its forward pass issues
-            # ~91 vector instructions per gene and wavefront (static count, scripts/vf_asm_stats.py), every one of them 4
+            # ~99 vector instructions per gene and wavefront (static count, scripts/vf_asm_stats.py), every one of them 4
             # cycles of a 16-lane SIMD; 256 CUs x 4 SIMDs at the 2.4 GHz peak clock
-            instr = 91.0
+            instr = 99.0
             ceil_ms = (G * C_local / 64.0) * instr * 4.0 / (256 * 4) / 2.4e9 * 1e3
             roof["viterbi"]["fp64_issue"] = {"vector_instr_per_gene_wavefront": instr, "ceiling_ms": ceil_ms,
                                              "frac": ceil_ms / kernels["viterbi"]["avg_ms"],
@@ -284,6 +288,14 @@ def main():
                                                      "Horner chains, max-plus step) behind two wavefronts per SIMD, and the per-lane column "
                                                      "streams -- no single pipe paces it (DESIGN.md K4b)"}
         dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
+        if "chain_apply" in roof:
+            moved = 3 * 8 * G * n_main            # one matrix read, two written (refined below by the counters when present)
+            t = kernels["chain_apply"]["avg_ms"] * 1e-3
+            roof["chain_apply"]["hbm_traffic"] = {"bytes_per_launch": moved, "source": "3 x 8 B per gene*cell",
+                                                  "achieved": moved / t / 1e9, "unit": "GB/s",
+                                                  "frac_of_peak": moved / t / 1e9 / HBM_PEAK_GBS,
+                                                  "stream_1r2w": STREAM_1R2W_GBS,
+                                                  "frac_of_stream_1r2w": moved / t / 1e9 / STREAM_1R2W_GBS}
         traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(traffic_file) and G == 10000 and C_local == 50000:   # counters were collected on this shape
             try:
@@ -291,6 +303,11 @@ def main():
                 for k in roof:
                     if k in tr:
                         roof[k]["traffic"] = tr[k]
+                        if k == "chain_apply":
+                            ht, t = roof[k]["hbm_traffic"], kernels[k]["avg_ms"] * 1e-3
+                            ht.update({"bytes_per_launch": tr[k], "source": "FETCH_SIZE (x2) + WRITE_SIZE counters, see traffic_source",
+                                       "achieved": tr[k] / t / 1e9, "frac_of_peak": tr[k] / t / 1e9 / HBM_PEAK_GBS,
+                                       "frac_of_stream_1r2w": tr[k] / t / 1e9 / STREAM_1R2W_GBS})
                         roof[k]["traffic_source"] = ("profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE of separate rocprofv3 --pmc "
                                                      "passes over this workload (scripts/pmc_traffic.sh), not measured in this run")
             except Exception:

@@ -22,7 +22,7 @@ for t in ("copy", "bench"):
         fb, wb = f[t][k] * 2 * 1024, w[t].get(k, 0.0) * 1024
         lines.append(f"{t}:{k}  {f[t][k]:.0f}  {fb:.4g}  {w[t].get(k, 0):.0f}  {wb:.4g}  {fb + wb:.4g}")
         if t == "bench":
-            if k.startswith("chain_kernel") and k.endswith(", 0, 127>"): out["chain_apply"] = fb + wb
+            if re.match(r"chain_kernel<\d+, \d+, \d+, 0, 127[,>]", k): out["chain_apply"] = fb + wb   # MODE_APPLY, full mask
             if k.startswith("viterbi_fast_kernel"): out["viterbi"] = fb + wb
             elif k.startswith("viterbi_kernel") and "viterbi" not in out: out["viterbi"] = fb + wb
         else:
