@@ -101,7 +101,10 @@ int build_emission_table(int K, const double *mean, double sd, int max_intervals
     out = EmisTable();
     out.K = K;
     out.n_seg = K + 1;
-    out.width_sigma = 1.0 / 16.0;
+    // interval width sd / 12: eps_tab 4e-14 for the i6 model (sd / 16: 9e-15, sd / 8: 4e-13 -- all far inside the 2e-12
+    // budget); the wider the intervals, the more lanes of a wavefront share a record (LDS broadcast instead of a bank
+    // conflict): 2.5 % on the launch against sd / 16, nothing more at sd / 8
+    out.width_sigma = 1.0 / 12.0;
     const double w_target = out.width_sigma * sd;
 
     // inner segments [mean_k, mean_{k+1}): whole numbers of intervals
