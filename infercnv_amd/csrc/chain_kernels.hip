@@ -12,8 +12,9 @@
 //           (A += R - L; box sums R, L slide) with a direct 2T+1-tap init at
 //           the chunk start / chromosome starts, edge-renormalised
 //           denominators in closed form; step 11 exact per-cell median by a
-//           value-binned histogram select in LDS (2048 bins between the
-//           cell's min and max, refined until <= 1024 candidates, then ranked)
+//           value-binned histogram select in LDS (2048 bins over the value
+//           range of the last cell the workgroup measured -- any range gives
+//           an exact selection --, refined until <= 1024 candidates, then ranked)
 //   phase 3 (S layout again, via LDS): step 12, step 14 (2^x), step 22 denoise,
 //           coalesced 16-B stores -- or, in the statistics modes used by the
 //           reference rounds, per-gene sums / per-cell (sum, sd).
@@ -258,7 +259,7 @@ int launch_normalize_log2(const double *in, double *out, int32_t G, int64_t C, c
 int chain_max_genes() { return 512 * 35; }
 
 // Geometry of the LDS-resident cell vector: threads x chunk length, chosen by the padded position count.
-// 768 threads = 3 wavefronts per SIMD = 168 VGPRs per lane: measured fastest (no spills, 12 waves).
+// (768 threads = 3 wavefronts per SIMD = 168 VGPRs per lane; 1024 = 4 per SIMD, 128 VGPRs: the fastest where it fits.)
 struct ChainGeom { int nt, lmax, pad; };
 static bool chain_geom(int64_t G, int n_chr, int T, ChainGeom &g) {
     g.pad = T >= 1 ? ((T + 3) & ~1) : 0;  // even(T+2)
