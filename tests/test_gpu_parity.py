@@ -350,6 +350,26 @@ def test_subtract_ref_inv_log(dev):
         dev.smooth_chain(to_dev(x), cs, refs, stage_mask=_lib.ST_ALL, inv_log=True)
 
 
+def test_chain_many_reference_groups(dev):
+    """The first reference round sums every group in one launch (workgroup = gene tile x one of S cell splits of a group,
+    S = 256 / n_groups capped at 32): many groups of very different sizes, single-cell groups, odd and even gene counts."""
+    from infercnv_amd import synth
+    rng = np.random.default_rng(5)
+    for G, C, ng in ((2000, 700, 37), (1501, 400, 9), (3000, 900, 130)):
+        x, cs = synth.make_matrix_np(G, C)
+        perm = rng.permutation(C)[: C // 2]
+        cuts = np.sort(rng.choice(np.arange(1, perm.size), size=ng - 1, replace=False))
+        refs = [g.astype(np.int32) for g in np.split(perm, cuts)]
+        assert min(len(r) for r in refs) >= 1 and len(refs) == ng
+        for kw in ({"stage_mask": 0x01}, {"stage_mask": 0x01, "use_bounds": False}):
+            got = to_host(dev.smooth_chain(to_dev(x), cs, refs, **kw)[0])
+            want = oc.subtract_ref_expr_from_obs(x, refs, use_bounds=kw.get("use_bounds", True))
+            assert np.abs(got - want).max() < 1e-12, (G, ng, kw)
+    out, pre = dev.smooth_chain(to_dev(x), cs, refs, want_pre_denoise=True)          # the whole chain behind it
+    _, want_pre, _ = oc.smooth_chain(x, cs, refs, want_pre_denoise=True)
+    assert np.abs(to_host(pre) - want_pre).max() < 1e-11
+
+
 def test_chain_no_reference_cells_uses_all_observations(dev):
     """R/inferCNV_ops.R:1686-1688: without references all cells form one proxy group (host mirror)."""
     from infercnv_amd import GeneOrder, InfercnvObject, ops, synth
