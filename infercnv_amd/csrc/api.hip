@@ -1163,7 +1163,7 @@ int icnv_group_means_dev(const double *expr, int64_t G, int64_t C, const int32_t
     if ((rc = upload(d_idx, grp_idx, (size_t)grp_off[n_grp], s))) return rc;
     if ((rc = upload(d_off, grp_off, (size_t)n_grp + 1, s))) return rc;
     const int ns = group_means_nsplit((int32_t)G, n_grp);
-    if ((rc = d_part.alloc((size_t)n_grp * ns * G * sizeof(double)))) return rc;
+    if ((rc = d_part.alloc((size_t)n_grp * ns * 3 * G * sizeof(double)))) return rc;
     return launch_group_means_ws(expr, (int32_t)G, d_idx.as<int32_t>(), d_off.as<int32_t>(), n_grp, ns,
                                  d_part.as<double>(), out, s);
 }
@@ -1182,7 +1182,7 @@ int icnv_cell_distances_dev(const double *expr, int64_t G, int64_t C, const int3
     if ((rc = upload(d_idx, cell_idx, (size_t)n, s))) return rc;
     if ((rc = upload(d_off, off, 2, s))) return rc;
     const int ns = group_means_nsplit((int32_t)G, 1);
-    if ((rc = d_part.alloc((size_t)ns * G * sizeof(double))) || (rc = d_mean.alloc((size_t)G * sizeof(double))) ||
+    if ((rc = d_part.alloc((size_t)ns * 3 * G * sizeof(double))) || (rc = d_mean.alloc((size_t)G * sizeof(double))) ||
         (rc = d_diag.alloc((size_t)n * sizeof(double))))
         return rc;
     if ((rc = launch_group_means_ws(expr, (int32_t)G, d_idx.as<int32_t>(), d_off.as<int32_t>(), 1, ns, d_part.as<double>(),

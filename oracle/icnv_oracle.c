@@ -75,6 +75,17 @@ static double r_mean_idx(const double *x, const int32_t *idx, int64_t n, int64_t
     return (double)s;
 }
 
+/* base::rowMeans on doubles (base R src/main/array.c, do_colsum, OP == 3, na.rm = FALSE; outside /root/reference):
+ * one LDOUBLE accumulator per row, the columns added in order, divided by the column count in LDOUBLE, then cast.
+ * No refinement pass (that is mean()).  On x86-64 LDOUBLE is the 80-bit x87 format: the last bit of the result is
+ * platform-dependent in R itself ("group means"). */
+static double r_rowmean_idx(const double *x, const int32_t *idx, int64_t n, int64_t stride) {
+    ld_t s = 0;
+    for (int64_t i = 0; i < n; i++) s += x[(int64_t)idx[i] * stride];
+    s /= (ld_t)n;
+    return (double)s;
+}
+
 /* k-th smallest (0-based) by quickselect on a scratch copy; also returns the
  * (k+1)-th through *next when want_next (min of the upper partition). */
 static double select_kth(double *a, int64_t n, int64_t k) {
@@ -597,7 +608,7 @@ void orc_group_means(const double *x, int64_t G, int64_t C, const int32_t *grp_i
         const int32_t *idx = grp_idx + grp_off[q];
         int64_t n = grp_off[q + 1] - grp_off[q];
 #pragma omp parallel for schedule(static)
-        for (int64_t g = 0; g < G; g++) out[g + G * q] = r_mean_idx(x + g, idx, n, G);
+        for (int64_t g = 0; g < G; g++) out[g + G * q] = r_rowmean_idx(x + g, idx, n, G);
     }
 }
 

@@ -41,6 +41,17 @@ def r_mean(x, axis=None):
     return np.asarray(s + t, dtype=np.float64)
 
 
+def r_row_means(x):
+    """base::rowMeans on a double matrix (base R src/main/array.c, do_colsum with OP == 3): one LDOUBLE accumulator
+    per row, columns added in order, divided by the column count in LDOUBLE, cast to double -- no refinement pass
+    (that is mean()).  LD is numpy's longdouble: the 80-bit x87 format on x86-64, like R there."""
+    x = np.asarray(x, dtype=np.float64)
+    acc = np.zeros(x.shape[0], dtype=LD)
+    for j in range(x.shape[1]):
+        acc += x[:, j]
+    return np.asarray(acc / LD(x.shape[1]), dtype=np.float64)
+
+
 def r_sum(x, axis=None):
     return np.asarray(np.asarray(x, dtype=np.float64).astype(LD).sum(axis=axis), dtype=np.float64)
 
@@ -508,7 +519,7 @@ def predict_cnv_on_indiv_cells(expr, chr_codes, means, sd_vec, Pi, delta, log=ic
 
 def group_means(expr, groups):
     """rowMeans(expr.data[chr_gene_idx, group_cells]) -- R/inferCNV_HMM.R:383."""
-    return np.stack([r_mean(expr[:, np.asarray(g, dtype=np.int64)], axis=1) for g in groups], axis=1)
+    return np.stack([r_row_means(expr[:, np.asarray(g, dtype=np.int64)]) for g in groups], axis=1)
 
 
 def predict_cnv_on_groups(expr, chr_codes, groups, means, sd_vec_per_group, Pi, delta, log=icnv_log):

@@ -108,3 +108,53 @@ def test_hmm_states_rda_reproduced_to_the_pinned_count(golden_dir):
     for sd in (0.22, 0.265):
         st, _ = oc.viterbi_groups(pre, cs, groups, hs["mu"], [sd, sd], np.log(Pi), np.log(delta))
         assert (st[:, groups[0][0]] != gold[:, groups[0][0]]).sum() > 84
+
+
+def _dd_row_means(x):
+    """The library's group-mean arithmetic (csrc/viterbi_kernels.hip: double-double accumulation, quotient from the
+    pair) in NumPy, vectorised over the rows: the correctly rounded mean."""
+    hi = np.zeros(x.shape[0])
+    lo = np.zeros(x.shape[0])
+    for j in range(x.shape[1]):
+        v = x[:, j]
+        s = hi + v
+        bb = s - hi
+        lo += (hi - (s - bb)) + (v - bb)
+        hi = s
+    n = float(x.shape[1])
+    s = hi + lo
+    e = lo - (s - hi)
+    q0 = s / n
+    r = np.asarray(onp._fma(-q0, np.full_like(q0, n), s), dtype=np.float64).reshape(q0.shape)
+    return q0 + (r + e) / n
+
+
+@pytest.mark.skipif(np.finfo(np.longdouble).nmant < 63, reason="needs an 80-bit long double (x86)")
+def test_group_means_last_bit_does_not_move_a_state_call():
+    """Group modes run the Viterbi on rowMeans(expr.data[, group_cells]) (R/inferCNV_HMM.R:383).  R accumulates that
+    in LDOUBLE -- its last bit depends on the platform -- and the library returns the correctly rounded mean
+    (double-double).  Shown here: (1) the double-double arithmetic IS the correctly rounded mean (exact rationals);
+    (2) it differs from the x87 rowMeans by at most 1 ulp, in a small share of the values; (3) the state calls of the
+    two mean matrices are identical, and the smallest decision margin of the recurrence on these profiles is orders of
+    magnitude above what a 1-ulp change of an observation moves a score by (|ds/dx| < 1e3, 1 ulp <= 2.3e-16)."""
+    from fractions import Fraction
+    G, C = 2000, 1800
+    x, cs = synth.make_matrix_np(G, C)
+    refs, obs = synth.groups(C)
+    _, pre, _ = oc.smooth_chain(x, cs, refs, want_pre_denoise=True)
+    groups = [g[i:i + 50] for g in list(obs) + list(refs) for i in range(0, len(g), 50)]
+    x87 = onp.group_means(pre, groups)
+    np.testing.assert_array_equal(x87, oc.group_means(pre, groups))
+    dd = np.stack([_dd_row_means(pre[:, g]) for g in groups], axis=1)
+    rng = np.random.default_rng(5)
+    for gene, q in zip(rng.integers(0, G, size=300), rng.integers(0, len(groups), size=300)):
+        exact = sum((Fraction(float(v)) for v in pre[gene, groups[q]]), Fraction(0)) / len(groups[q])
+        assert dd[gene, q] == float(exact)
+    assert (np.abs(dd - x87) <= np.spacing(np.abs(x87))).all()
+    share = (dd != x87).mean()
+    assert share < 0.05, share
+    means, sd, logPi, logDelta = synth.hmm_params_i6()
+    a, _, margin = _states_both_ways(x87, cs, means, sd, logPi, logDelta)
+    b, _, _ = _states_both_ways(dd, cs, means, sd, logPi, logDelta)
+    assert np.array_equal(a, b), f"{(a != b).sum()} state calls moved by the last bit of the group means ({share:.3%} differ)"
+    assert margin > 1e-9, margin
