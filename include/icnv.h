@@ -86,11 +86,12 @@ int icnv_get_devices(void);
 
 /* Residency of the host-buffer entry points.  run() hands every step the matrix the previous step returned
  * (R/inferCNV_ops.R:771-1031, 1237-1309).  With icnv_residency(1) the library keeps the matrices it uploaded or
- * produced on the device(s) -- up to 6 per device, ICNV_RESIDENT_MAX_GB (default 64) -- and recognises a host matrix
- * by its address, its size and a fingerprint of ~16 000 values sampled at a fixed stride: a recognised matrix is not
- * uploaded again.  The caller may free or reuse the host memory at any time (contents are fingerprinted at every
- * call); a caller that edits a few elements of a matrix IN PLACE between two calls could go unnoticed -- such a
- * caller leaves residency off (the default) or calls icnv_residency_drop().
+ * produced on the device(s) -- up to 6 per device, ICNV_RESIDENT_MAX_GB (default 64), given back under memory
+ * pressure -- and recognises a host matrix BY CONTENT: its length, a strided sample of ~16 000 values as the quick
+ * reject, then a 64-bit hash of every value (the host's cores hash the incoming matrix at memory speed, several times
+ * faster than the upload it saves; a device reduction hashes what the library produced).  A recognised matrix is not
+ * uploaded again.  Addresses play no part: the caller may free, reuse or edit host memory at any time -- one changed
+ * element changes the hash (collision odds 2^-64) and the matrix is uploaded.  Off by default.
  *   icnv_residency_stats  out4 = {matrices recognised, matrices uploaded, resident bytes, resident matrices} */
 int icnv_residency(int on);
 void icnv_residency_drop(void);

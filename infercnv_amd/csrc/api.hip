@@ -103,7 +103,9 @@ int pool_alloc(void **p, size_t bytes) {
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, sz);
     if (e != hipSuccess) {
-        // release this device's cached blocks and retry once
+        // release the idle resident matrices (icnv_residency) and this device's cached blocks, retry once
+        (void)hipGetLastError();
+        (void)residency_release_idle();
         {
             std::lock_guard<std::mutex> lk(g_pool_mu);
             for (auto it = g_free.begin(); it != g_free.end();) {
@@ -260,6 +262,8 @@ int icnv_init(int device) {
 
 void icnv_shutdown(void) {
     drain_timers();
+    icnv_residency_drop();
+    viterbi_release_contexts();
     std::lock_guard<std::mutex> lk(g_pool_mu);
     for (auto &kv : g_free) (void)hipFree(kv.second);
     g_free.clear();
@@ -911,6 +915,28 @@ bool structured_pi(const HmmParams &p, double &a, double &b) {
 }
 }  // namespace
 
+extern "C++" {
+namespace icnv {
+void viterbi_release_contexts() {
+    int home = 0;
+    if (hipGetDevice(&home) != hipSuccess) { (void)hipGetLastError(); return; }
+    std::lock_guard<std::mutex> lk(g_vctx_mu);
+    for (auto &kv : g_vctx) {
+        ViterbiCtx &c = *kv.second;
+        std::lock_guard<std::mutex> lk2(c.mu);
+        if (hipSetDevice(kv.first / 256) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (c.dev) (void)hipFree(c.dev);
+        if (c.counters) (void)hipFree(c.counters);
+        if (c.host_flag) (void)hipHostFree(c.host_flag);
+        if (c.flag_ev) (void)hipEventDestroy(c.flag_ev);
+        c.dev = nullptr; c.dev_bytes = 0; c.counters = nullptr; c.host_flag = nullptr; c.flag_ev = nullptr;
+        c.valid = false;
+    }
+    (void)hipSetDevice(home);
+}
+}  // namespace icnv
+}  // extern "C++"
+
 // caller holds c.mu
 static int fast_table_for(ViterbiCtx &c, const HmmParams &p, double sd, hipStream_t s, bool &eligible) {
     eligible = false;
@@ -1155,7 +1181,6 @@ int icnv_group_means_dev(const double *expr, int64_t G, int64_t C, const int32_t
     int rc = validate_groups(grp_idx, grp_off, n_grp, C, "groups");
     if (rc) return rc;
     if (n_grp == 0) return ICNV_OK;
-    if (n_grp > 65535) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "more than 65535 groups");
     for (int q = 0; q < n_grp; ++q)
         if (grp_off[q + 1] == grp_off[q]) ICNV_FAIL(ICNV_ERR_ARG, "empty group");
     hipStream_t s = (hipStream_t)stream;

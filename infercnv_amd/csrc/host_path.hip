@@ -2,8 +2,10 @@
 //
 //  * Residency.  run() calls the step functions back to back (R/inferCNV_ops.R:771, 817, 865, 911, 952, 1031,
 //    1237-1309), each one handing over the matrix the previous one returned.  With icnv_residency(1) the library keeps
-//    the matrices it uploaded or produced on the device(s) and recognises them when they come back -- by host address,
-//    dimensions and a fingerprint of a strided sample of the values -- so that a step skips its upload.
+//    the matrices it uploaded or produced on the device(s) and recognises them when they come back -- by CONTENT: the
+//    length, a strided sample as the quick reject, and then a 64-bit hash of EVERY value (computed by the host's cores
+//    for the incoming matrix, by a device reduction for a matrix the library produced) -- so that a step skips its
+//    upload.  Addresses play no part: R's allocator reuses them, and an edit of a single element changes the hash.
 //  * Several GPUs from one process.  icnv_set_devices(n) makes the host-buffer smoothing chain and per-cell Viterbi
 //    split the cells into one contiguous block per device; one host thread per device uploads its block, runs the
 //    *_dev path on its own stream and downloads.  The chain's reference statistics (per-gene sums of the
@@ -31,12 +33,14 @@ int pool_domain();   // api.hip: device ordinal * 256 + pool partition of the ca
 // ------------------------------------------------------------------ residency
 namespace {
 struct ResidentEntry {
-    const void *host;
+    const void *host;  // where the content was last seen (statistics / debugging only: identity is by content)
     int64_t n;         // doubles
-    uint64_t fp;
+    uint64_t fp;       // strided sample: quick reject
     DevBuf buf;
     uint64_t stamp;
     int busy;
+    uint64_t hash = 0; // content hash of all n values
+    bool hash_valid = false;
 };
 struct ResidentDomain {
     std::mutex mu;
@@ -80,6 +84,70 @@ uint64_t fingerprint(const double *x, int64_t n) {
     mix(w[n - 1]);
     return h;
 }
+// ---- content hash: H = fmix64( n ^ sum_i fmix64(w_i + (i + 1) * PHI) ) over the 64-bit words of the matrix.  The sum is
+// commutative, so any partition of the words (host threads, device workgroups) yields the same value.
+inline __host__ __device__ uint64_t fmix64(uint64_t k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return k;
+}
+constexpr uint64_t HASH_PHI = 0x9E3779B97F4A7C15ull;
+__global__ void __launch_bounds__(256) content_hash_kernel(const uint64_t *__restrict__ w, int64_t n, unsigned long long *out) {
+    uint64_t acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        acc += fmix64(w[i] + (uint64_t)(i + 1) * HASH_PHI);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor((unsigned long long)acc, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, (unsigned long long)acc);
+}
+uint64_t content_hash_host(const double *x, int64_t n) {
+    if (n <= 0) return fmix64(0);
+    const uint64_t *w = reinterpret_cast<const uint64_t *>(x);
+    int nt = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), 32);
+    if (const char *e = std::getenv("ICNV_HASH_THREADS")) nt = std::max(1, std::atoi(e));
+    nt = (int)std::min<int64_t>(nt, (n + (1 << 20) - 1) >> 20);   // at least 8 MiB per thread
+    std::vector<uint64_t> part((size_t)nt, 0);
+    auto work = [&](int t) {
+        const int64_t b = n * t / nt, e = n * (t + 1) / nt;
+        uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        int64_t i = b;
+        for (; i + 4 <= e; i += 4) {
+            a0 += fmix64(w[i] + (uint64_t)(i + 1) * HASH_PHI);
+            a1 += fmix64(w[i + 1] + (uint64_t)(i + 2) * HASH_PHI);
+            a2 += fmix64(w[i + 2] + (uint64_t)(i + 3) * HASH_PHI);
+            a3 += fmix64(w[i + 3] + (uint64_t)(i + 4) * HASH_PHI);
+        }
+        for (; i < e; ++i) a0 += fmix64(w[i] + (uint64_t)(i + 1) * HASH_PHI);
+        part[(size_t)t] = (a0 + a1) + (a2 + a3);
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &t : th) t.join();
+    uint64_t sum = 0;
+    for (uint64_t v : part) sum += v;
+    return fmix64(sum ^ (uint64_t)n);
+}
+// the same value from the device copy (synchronous; the entry's content is complete: every host-buffer call ends with a
+// synchronisation of the stream it used)
+int content_hash_device(const double *dev, int64_t n, uint64_t *out) {
+    if (n <= 0) { *out = fmix64(0); return ICNV_OK; }
+    DevBuf acc;
+    int rc = acc.alloc(sizeof(unsigned long long));
+    if (rc) return rc;
+    ICNV_HIP(hipMemsetAsync(acc.p, 0, sizeof(unsigned long long), nullptr));
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)num_cus() * 8);
+    hipLaunchKernelGGL(content_hash_kernel, dim3(grid), dim3(256), 0, nullptr, reinterpret_cast<const uint64_t *>(dev), n,
+                       acc.as<unsigned long long>());
+    ICNV_HIP(hipGetLastError());
+    unsigned long long sum = 0;
+    ICNV_HIP(hipMemcpy(&sum, acc.p, sizeof(sum), hipMemcpyDeviceToHost));
+    *out = fmix64((uint64_t)sum ^ (uint64_t)n);
+    return ICNV_OK;
+}
 void res_evict(ResidentDomain &d, size_t budget, size_t max_entries) {   // caller holds d.mu
     while (d.bytes > budget || d.entries.size() > max_entries) {
         auto victim = d.entries.end();
@@ -104,29 +172,43 @@ int acquire_input(const double *host, int64_t n, hipStream_t s, MatrixLease &lea
     if (g_res_on.load()) {
         const uint64_t fp = fingerprint(host, n);
         ResidentDomain &d = res_domain();
+        uint64_t h = 0;
+        bool have_h = false;
         {
             std::lock_guard<std::mutex> lk(d.mu);
+            bool candidate = false;
             for (auto &e : d.entries)
-                if (e.host == host && e.n == n && e.fp == fp) {
+                if (e.n == n && e.fp == fp) candidate = true;
+            if (candidate) {
+                // the sample agrees with a resident matrix: identity is decided by the hash of EVERY value
+                h = content_hash_host(host, n);
+                have_h = true;
+                for (auto &e : d.entries) {
+                    if (e.n != n || e.fp != fp) continue;
+                    if (!e.hash_valid) {
+                        if (int rc = content_hash_device(e.buf.as<double>(), e.n, &e.hash)) return rc;
+                        e.hash_valid = true;
+                    }
+                    if (e.hash != h) continue;
                     ++e.busy;
                     e.stamp = g_res_clock++;
+                    e.host = host;
                     lease.entry = &e;
                     lease.dev = e.buf.as<double>();
                     ++g_res_hits;
                     return ICNV_OK;
                 }
+            }
         }
         ++g_res_misses;
         DevBuf b;
         int rc = b.alloc((size_t)std::max<int64_t>(n, 1) * sizeof(double));
         if (rc) return rc;
         if (n) ICNV_HIP(hipMemcpyAsync(b.p, host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
-        // the uploaded matrix stays resident too (the HMM input is read by the Viterbi and again by the median filter)
+        // the uploaded matrix stays resident too (the HMM input is read by the Viterbi and again by the median filter);
+        // its hash is taken from the device copy the first time a look-alike arrives
         std::lock_guard<std::mutex> lk(d.mu);
-        for (auto it = d.entries.begin(); it != d.entries.end();)   // the address now holds other data
-            if (it->host == host && it->busy == 0) { d.bytes -= (size_t)it->n * sizeof(double); it = d.entries.erase(it); }
-            else ++it;
-        d.entries.push_back(ResidentEntry{host, n, fp, std::move(b), g_res_clock++, 1});
+        d.entries.push_back(ResidentEntry{host, n, fp, std::move(b), g_res_clock++, 1, h, have_h});
         d.bytes += (size_t)n * sizeof(double);
         lease.entry = &d.entries.back();
         lease.dev = d.entries.back().buf.as<double>();
@@ -146,12 +228,19 @@ void publish_output(const double *host, int64_t n, DevBuf &&buf) {
     const uint64_t fp = fingerprint(host, n);
     ResidentDomain &d = res_domain();
     std::lock_guard<std::mutex> lk(d.mu);
-    for (auto it = d.entries.begin(); it != d.entries.end();)
-        if (it->host == host && it->busy == 0) { d.bytes -= (size_t)it->n * sizeof(double); it = d.entries.erase(it); }
-        else ++it;
-    d.entries.push_back(ResidentEntry{host, n, fp, std::move(buf), g_res_clock++, 0});
+    d.entries.push_back(ResidentEntry{host, n, fp, std::move(buf), g_res_clock++, 0, 0, false});
     d.bytes += (size_t)n * sizeof(double);
     res_evict(d, res_budget_bytes(), 6);
+}
+
+// Under memory pressure (pool_alloc failed): give the idle resident matrices of the calling thread's pool domain back
+bool residency_release_idle() {
+    if (!g_res_on.load()) return false;
+    ResidentDomain &d = res_domain();
+    std::lock_guard<std::mutex> lk(d.mu);
+    const size_t before = d.entries.size();
+    res_evict(d, 0, 0);
+    return d.entries.size() != before;
 }
 
 // ------------------------------------------------------------------ devices of the host-buffer path

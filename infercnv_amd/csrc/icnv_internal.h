@@ -54,6 +54,8 @@ struct MatrixLease {
 };
 int acquire_input(const double *host, int64_t n_doubles, hipStream_t s, MatrixLease &lease);
 void publish_output(const double *host, int64_t n_doubles, DevBuf &&buf);
+bool residency_release_idle();   // host_path.hip: hand the idle resident matrices of this pool domain back to the pool
+void viterbi_release_contexts();  // api.hip: device tables / pinned words / events of the per-device Viterbi state
 
 // Optional per-kernel timing with hipEvents recorded on the launch stream.
 struct KernelTimer {

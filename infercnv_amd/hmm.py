@@ -198,11 +198,15 @@ def _flatten_subclusters(obj):
 
 
 def _whole_sample_groups(obj, cluster_by_groups):
-    """R/inferCNV_HMM.R:529-533."""
+    """`tumor_samples` of R/inferCNV_HMM.R:528-533 (i3: R/inferCNV_i3HMM.R:351-356).  With cluster_by_groups = FALSE the
+    reference writes `c(all_observations = unlist(obs_indices), reference_grouped_cell_indices)`: c() of an integer
+    VECTOR with a list yields a list with one element per vector entry, so every observation cell becomes a "sample"
+    of its own (num_cells = 1: the sd of one cell, the Viterbi on the cell's own profile) next to the reference groups.
+    Reference behaviour, kept (SURVEY.md appendix A.7 lists the others)."""
     if cluster_by_groups:
         groups = list(obj.observation_grouped_cell_indices.values())
     else:
-        groups = [np.concatenate([np.asarray(v) for v in obj.observation_grouped_cell_indices.values()])]
+        groups = [np.asarray([c]) for v in obj.observation_grouped_cell_indices.values() for c in np.asarray(v).ravel()]
     groups += list(obj.reference_grouped_cell_indices.values())
     return [np.asarray(g, dtype=np.int32) for g in groups]
 

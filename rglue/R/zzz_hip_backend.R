@@ -33,8 +33,8 @@
 }
 
 ## expr.data in per-chromosome contiguous gene order.  After .order_reduce (R/inferCNV.R:407) the permutation is the
-## identity: the matrix is then handed over AS IS (no copy), which also lets the library recognise the matrix it
-## returned from the previous step and skip the upload (icnv_residency, include/icnv.h).
+## identity: the matrix is then handed over AS IS (no copy).  The library recognises the matrix it returned from the
+## previous step by its content and skips the upload (icnv_residency, include/icnv.h).
 .icnv_matrix <- function(infercnv_obj, lay) {
     x <- infercnv_obj@expr.data
     if (!is.matrix(x)) x <- as.matrix(x)                 # dgCMatrix -> dense, like R/inferCNV_ops.R:1924-1926
@@ -152,11 +152,13 @@ hip_predict_CNV_via_HMM_on_indiv_cells <- function(infercnv_obj,
     vapply(groups, function(g) median(.get_state_emission_params(length(g), cnv_mean_sd, cnv_level_to_mean_sd_fit)$sd),
            numeric(1))
 
-## tumor_samples of predict_CNV_via_HMM_on_whole_tumor_samples (R/inferCNV_HMM.R:529-533)
+## tumor_samples of predict_CNV_via_HMM_on_whole_tumor_samples (R/inferCNV_HMM.R:528-533), the reference's own two
+## expressions.  Note what the second one does: c() of an integer VECTOR with a list gives a list with one element per
+## vector entry, i.e. with cluster_by_groups = FALSE every observation cell is a "sample" of its own (num_cells = 1)
+## next to the reference groups.  Reference behaviour, kept.
 .icnv_whole_sample_groups <- function(infercnv_obj, cluster_by_groups) {
-    if (isTRUE(cluster_by_groups)) c(infercnv_obj@observation_grouped_cell_indices, infercnv_obj@reference_grouped_cell_indices)
-    else c(list(all_observations = unlist(infercnv_obj@observation_grouped_cell_indices)),
-           infercnv_obj@reference_grouped_cell_indices)
+    if (cluster_by_groups == TRUE) c(infercnv_obj@observation_grouped_cell_indices, infercnv_obj@reference_grouped_cell_indices)
+    else c(all_observations = unlist(infercnv_obj@observation_grouped_cell_indices), infercnv_obj@reference_grouped_cell_indices)
 }
 
 hip_predict_CNV_via_HMM_on_whole_tumor_samples <- function(infercnv_obj, cluster_by_groups,
@@ -279,8 +281,9 @@ hip_cell_dist <- function(tumor_expr_data) {
 ## Swap the package's step functions for the hip ones.  devices: 0 = every visible MI355X (cells are split into one
 ## contiguous block per GPU inside the library, one host thread per GPU), n = the first n, -1 = the current one only.
 ## residency: keep the last results on the device(s) so that the next step skips the upload of the matrix it was
-## handed back (a matrix is recognised by its address, its dimensions and a strided sample of its values; turn it
-## off if your code edits expr.data in place between steps).
+## handed back.  A matrix is recognised by CONTENT (length, strided sample, then a 64-bit hash of every value computed
+## on the host at memory speed): editing expr.data between steps, or R reusing a freed address, cannot serve stale
+## device data -- a changed matrix hashes differently and is uploaded.
 .icnv_enable_hip_backend <- function(devices = getOption("infercnv.hip.devices", 0L),
                                      residency = getOption("infercnv.hip.residency", TRUE)) {
     .Call("icnv_R_init", as.integer(devices), as.logical(residency))

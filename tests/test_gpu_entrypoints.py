@@ -204,8 +204,10 @@ def test_i3_wrappers_and_sd_trend(dev):
                         [np.asarray(v) for g in sub["subclusters"].values() for v in g.values()]),
                        (lambda: hmm.i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples(obj, True, 0.05),
                         [obs[q] for q in range(4)] + list(refs)),
+                       # cluster_by_groups = FALSE: the reference's c(all_observations = unlist(.), refs) makes every
+                       # observation cell a sample of its own (R/inferCNV_i3HMM.R:355) -- its own profile, not a mean
                        (lambda: hmm.i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples(obj, False, 0.05),
-                        [np.concatenate(obs)] + list(refs))):
+                        [np.array([c]) for c in np.concatenate(obs)] + list(refs))):
         got = fn().expr_data
         gm = to_host(dev.group_means(xd, groups))
         for q, g in enumerate(groups):
@@ -255,9 +257,10 @@ def _host_chain_and_hmm(L, x, cs, refs, hmm):
 
 
 def test_residency_skips_uploads_and_notices_changes(dev):
-    """icnv_residency(1): a host matrix the library produced (or uploaded) is recognised when it comes back -- address,
-    size, fingerprint of a strided sample -- and not uploaded again; same results as without; a matrix whose sampled
-    values changed is uploaded again; freeing / reusing host memory is harmless."""
+    """icnv_residency(1): a host matrix the library produced (or uploaded) is recognised when it comes back -- by content:
+    length, a strided sample as the quick reject, then a 64-bit hash of every value -- and not uploaded again; same
+    results as without; a matrix that differs in ONE element the sample does not see, at the same address and of the same
+    shape (what an in-place edit or R's allocator reusing a freed address produce), is uploaded again."""
     import ctypes as ct
     from infercnv_amd import _lib, synth
     from infercnv_amd._lib import Cfg, check
@@ -292,16 +295,24 @@ def test_residency_skips_uploads_and_notices_changes(dev):
         s3 = stats()
         assert s3[0] - s2[0] == 6 and s3[1] == s2[1]
         assert np.abs(cur - base[1]).max() < 1e-12              # six steps == the fused chain's pre-denoise output
-        # a change at a sampled position (element 0 is always sampled) is noticed: uploaded again, result follows the data
+        # identity is by content, not by address: a copy of x elsewhere in memory is recognised ...
         x2 = x.copy(order="F")
-        ref2 = _host_chain_and_hmm(L, x2, cs, refs, hmm)
-        x2[0, 0] += 0.5
         s4 = stats()
-        got3 = _host_chain_and_hmm(L, x2, cs, refs, hmm)
-        assert stats()[1] - s4[1] >= 1
-        assert got3[1][0, 0] != ref2[1][0, 0]
-        want3 = oc.smooth_chain(x2, cs, refs, want_pre_denoise=True)[1]
-        assert np.abs(got3[1] - want3).max() < 1e-12
+        ref2 = _host_chain_and_hmm(L, x2, cs, refs, hmm)
+        assert stats()[1] == s4[1]
+        # ... and ONE element changed in place -- same address, same shape, a position the strided sample skips (the
+        # sample takes every 47th value of this matrix) -- is noticed: uploaded again, the result follows the data
+        assert (G * C) // 16384 == 47
+        for pos, delta in (((1, 0), 0.5), ((G // 2 + 1, C // 2), 1e-9), ((0, 0), 0.25)):
+            assert pos == (0, 0) or (pos[0] + G * pos[1]) % 47 != 0
+            x2[pos] += delta
+            s5 = stats()
+            got3 = _host_chain_and_hmm(L, x2, cs, refs, hmm)
+            assert stats()[1] - s5[1] == 1, pos                 # x2 uploaded; its outputs are new content as well
+            want3 = oc.smooth_chain(x2, cs, refs, want_pre_denoise=True)[1]
+            assert np.abs(got3[1] - want3).max() < 1e-12
+            assert not np.array_equal(got3[1], ref2[1])
+            ref2 = got3
     finally:
         check(L.icnv_residency(0))
     assert stats()[3] == 0
@@ -399,3 +410,29 @@ def test_bench_two_ranks_equal_one_rank(dev):
         assert abs(p2 - p1) <= 1e-9 * abs(p1)          # reference sums are added in a different order: rounding only
         assert abs(o2 - o1) <= 1e-6 * abs(o1)          # (a denoise select within rounding of its bound may flip)
         assert abs(s2 - s1) <= 50, (s2, s1)            # state calls: identical but for a decision within 1e-16 of a tie
+
+
+def test_i6_whole_samples_without_cluster_by_groups_is_one_sample_per_observation_cell(dev):
+    """predict_CNV_via_HMM_on_whole_tumor_samples(cluster_by_groups = FALSE): the reference's
+    `c(all_observations = unlist(obs), reference_grouped_cell_indices)` (R/inferCNV_HMM.R:532) is a list with one element
+    per observation CELL (c() of a vector with a list), so each of them is decoded on its own profile with the sd the
+    fit predicts for num_cells = 1, the reference groups on their mean profiles with their own sd."""
+    from infercnv_amd import GeneOrder, InfercnvObject, hmm, synth
+    G, C = 2000, 60
+    x, cs = synth.make_matrix_np(G, C)
+    refs, obs = synth.groups(C)
+    _, pre, _ = oc.smooth_chain(x, cs, refs, want_pre_denoise=True)
+    obj = InfercnvObject(expr_data=pre, gene_order=GeneOrder(chr=np.repeat(np.arange(22), np.diff(cs)).astype(str)),
+                         reference_grouped_cell_indices={"r0": refs[0], "r1": refs[1]},
+                         observation_grouped_cell_indices={f"t{q}": obs[q] for q in range(4)})
+    means, _, logPi, logDelta = synth.hmm_params_i6()
+    cnv = {k: {"mean": m, "sd": 0.2} for k, m in zip(hmm.CNV_LEVELS, means)}
+    fit = {k: (np.log(0.3) + 0.01 * i, -0.45) for i, k in enumerate(hmm.CNV_LEVELS)}      # log(sd) = b0 + b1 log(n)
+    got = hmm.predict_CNV_via_HMM_on_whole_tumor_samples(obj, False, cnv, fit).expr_data
+    sd_of = lambda n: float(onp.r_median(np.array([np.exp(b0 + b1 * np.log(n)) for b0, b1 in fit.values()])))
+    obs_cells = np.concatenate(obs)
+    want_cells, _ = oc.viterbi_cells(pre[:, obs_cells], cs, means, sd_of(1), logPi, logDelta)
+    np.testing.assert_array_equal(got[:, obs_cells], want_cells)
+    want_refs, _ = oc.viterbi_groups(pre, cs, list(refs), means, [sd_of(len(r)) for r in refs], logPi, logDelta)
+    ref_cells = np.concatenate(refs)
+    np.testing.assert_array_equal(got[:, ref_cells], want_refs[:, ref_cells])
