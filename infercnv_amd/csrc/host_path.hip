@@ -388,16 +388,18 @@ int icnv_smooth_chain(const double *expr_in, double *expr_out, double *pre_denoi
         return ICNV_OK;
     }
     // ---- one contiguous block of cells per device
+    int total_rounds = 0;
     {   // argument checks once, with the caller's error reporting (a plan on the whole matrix, nothing is launched)
         icnv_chain_t *probe = nullptr;
         int rc = icnv_chain_begin(&probe, cfg);
         if (rc) return rc;
-        const int rounds = icnv_chain_num_rounds(probe);
+        total_rounds = icnv_chain_num_rounds(probe);   // the meeting points of every worker: the probe's count, not a re-derivation
         icnv_chain_end(probe);
-        if (rounds > 0)
+        if (total_rounds > 0)
             for (int q = 0; q < cfg->n_ref_grp; ++q)
                 if (cfg->ref_off[q + 1] == cfg->ref_off[q]) ICNV_FAIL(ICNV_ERR_ARG, "empty reference group");
     }
+    const bool needs_ref = total_rounds > 0;   // only then are cfg->ref_idx / ref_off read (they may be NULL otherwise)
     std::vector<std::vector<std::vector<double>>> part(4, std::vector<std::vector<double>>((size_t)nd));   // [round][worker]
     Rendezvous meet(nd);
     return on_devices(nd, [&](int w, hipStream_t s, int rc0) -> int {
@@ -407,15 +409,17 @@ int icnv_smooth_chain(const double *expr_in, double *expr_out, double *pre_denoi
         const int64_t n = G * (c1 - c0);
         // this block's reference cells, local indices, order kept
         std::vector<int32_t> ridx, roff(1, 0);
-        for (int q = 0; q < cfg->n_ref_grp; ++q) {
+        for (int q = 0; needs_ref && q < cfg->n_ref_grp; ++q) {
             for (int32_t i = cfg->ref_off[q]; i < cfg->ref_off[q + 1]; ++i)
                 if (cfg->ref_idx[i] >= c0 && cfg->ref_idx[i] < c1) ridx.push_back((int32_t)(cfg->ref_idx[i] - c0));
             roff.push_back((int32_t)ridx.size());
         }
         icnv_chain_cfg lc = *cfg;
         lc.C = c1 - c0;
-        lc.ref_idx = ridx.data();
-        lc.ref_off = roff.data();
+        if (needs_ref) {
+            lc.ref_idx = ridx.data();
+            lc.ref_off = roff.data();
+        }
         icnv_chain_t *ch = nullptr;
         MatrixLease in;
         DevBuf dout, dpre;
@@ -423,16 +427,8 @@ int icnv_smooth_chain(const double *expr_in, double *expr_out, double *pre_denoi
         if (!rc) rc = acquire_input(expr_in + c0 * G, n, s, in);
         if (!rc) rc = dout.alloc((size_t)std::max<int64_t>(n, 1) * sizeof(double));
         if (!rc && pre_denoise) rc = dpre.alloc((size_t)std::max<int64_t>(n, 1) * sizeof(double));
-        const int rounds = ch ? icnv_chain_num_rounds(ch) : 0;
-        // every worker walks through the same number of meeting points, failed or not
-        int total_rounds = 0;
-        {
-            icnv_chain_cfg tmp = *cfg;
-            const uint32_t m = tmp.stage_mask;
-            total_rounds = ((m & ICNV_ST_SUBTRACT_REF_1) ? 1 : 0) + ((m & ICNV_ST_SUBTRACT_REF_2) ? 1 : 0) + ((m & ICNV_ST_DENOISE) ? 1 : 0);
-            if ((m & ICNV_ST_DENOISE) && tmp.noise_filter == 0.0) --total_rounds;   // clear_noise(threshold = 0): no stage (icnv_chain_begin)
-        }
-        (void)rounds;
+        // every worker walks through the same number of meeting points (the probe chain's), failed or not
+        if (!rc && icnv_chain_num_rounds(ch) != total_rounds) { set_error("worker chain disagrees with the probe about the reference rounds"); rc = ICNV_ERR_ARG; }
         for (int r = 0; r < total_rounds; ++r) {
             double *pd = nullptr;
             int64_t pn = 0;

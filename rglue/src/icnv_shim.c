@@ -1,8 +1,13 @@
 /*
  * icnv_shim.c -- .Call shim between the infercnv R package and libicnv_hip.so.
  *
- * WRITTEN BLIND: R is not installed in the build image, so this file has never
- * been compiled against Rinternals.h.  It contains no logic: it unpacks SEXPs
+ * R is not installed in the build image, so this file has never been compiled
+ * against the real Rinternals.h; it IS compiled (-Wall -Wextra -Werror) and
+ * driven from C against a mock of the R API subset it uses (rglue/mock/,
+ * tests/test_host.py::test_r_shim_compiles_and_registers,
+ * tests/test_gpu_entrypoints.py::test_r_shim_driven_from_c): types, arities,
+ * PROTECT balance, error path and results are checked, R's own semantics of
+ * those calls are not.  It contains no logic: it unpacks SEXPs
  * into the plain pointers/sizes of include/icnv.h, allocates the result under
  * PROTECT, and converts error codes to Rf_error() only AFTER the library has
  * returned (the library never longjmps and owns/frees its device memory).
@@ -132,10 +137,12 @@ SEXP icnv_R_cell_distances(SEXP expr, SEXP cell_idx) {
 SEXP icnv_R_states_to_proxy(SEXP states, SEXP K) {
     const R_xlen_t n = XLENGTH(states);
     const double *x = REAL(states);
+    const int k = Rf_asInteger(K);
+    const double kmax = (double)k;   /* a value above the model's last state is not a state: it keeps its value */
     uint8_t *st = (uint8_t *)R_alloc((size_t)n, 1);
-    for (R_xlen_t i = 0; i < n; i++) st[i] = (x[i] >= 1.0 && x[i] <= 6.0 && x[i] == (double)(int)x[i]) ? (uint8_t)x[i] : 0xFF;
+    for (R_xlen_t i = 0; i < n; i++) st[i] = (x[i] >= 1.0 && x[i] <= kmax && x[i] == (double)(int)x[i]) ? (uint8_t)x[i] : 0xFF;
     SEXP out = PROTECT(Rf_allocMatrix(REALSXP, Rf_nrows(states), Rf_ncols(states)));
-    int rc = icnv_states_to_proxy(st, REAL(out), (int64_t)n, Rf_asInteger(K));
+    int rc = icnv_states_to_proxy(st, REAL(out), (int64_t)n, k);
     if (rc) { UNPROTECT(1); fail(rc); }
     double *o = REAL(out);
     for (R_xlen_t i = 0; i < n; i++)

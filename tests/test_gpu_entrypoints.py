@@ -436,3 +436,17 @@ def test_i6_whole_samples_without_cluster_by_groups_is_one_sample_per_observatio
     want_refs, _ = oc.viterbi_groups(pre, cs, list(refs), means, [sd_of(len(r)) for r in refs], logPi, logDelta)
     ref_cells = np.concatenate(refs)
     np.testing.assert_array_equal(got[:, ref_cells], want_refs[:, ref_cells])
+
+
+def test_r_shim_driven_from_c(dev):
+    """The R .Call shim (rglue/src/icnv_shim.c) compiled against the mock R API and driven from C on the GPU: smooth chain
+    (+ pre-denoise matrix, dimnames), per-cell and group Viterbi, median filter, proxy tables (K = 3 leaves 4..6
+    untouched), average bounds -- every result identical to the direct C-ABI call, PROTECT balance zero, the library's
+    error for an even window raised through Rf_error (rglue/mock/test_shim.c)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mock = os.path.join(root, "rglue", "mock")
+    res = subprocess.run(["make", "-C", mock, "all"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    res = subprocess.run([os.path.join(mock, "test_shim"), "gpu"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "SHIM_GPU_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]

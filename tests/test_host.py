@@ -207,3 +207,25 @@ def test_median_network_header_is_generated_and_verified():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "up to date" in r.stdout
+
+
+def _build_shim_driver():
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mock = os.path.join(root, "rglue", "mock")
+    res = subprocess.run(["make", "-C", mock, "syntax", "all"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    return os.path.join(mock, "test_shim")
+
+
+def test_r_shim_compiles_and_registers():
+    """rglue/src/icnv_shim.c (the .Call shim a maintainer drops into the package; R itself is not in the image) goes
+    through gcc -Wall -Wextra -Werror against a mock of the R API subset it uses, its registration table is checked
+    against the routines' real arities (function types at compile time, numArgs at run time), and the error path --
+    the library has no device here, returns a code, the shim raises Rf_error after the library returned -- is driven
+    from C (rglue/mock/test_shim.c).  The routines' results are checked on the GPU (tests/test_gpu_entrypoints.py)."""
+    import subprocess
+    exe = _build_shim_driver()
+    res = subprocess.run([exe, "cpu"], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1"))
+    assert res.returncode == 0 and "SHIM_CPU_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
