@@ -44,29 +44,14 @@ namespace icnv {
 
 namespace {
 
-#ifndef ICNV_VF_NT
-#define ICNV_VF_NT 512    // 2 wavefronts per SIMD measured fastest (256: 5.2 ms, 384: 4.2, 512: 3.65, 640: 4.6, 768: 4.6, 1024: 6.7):
-                          // half as many column streams per XCD (their lines survive in the 4 MiB L2) and no register spills
-#endif
-#ifndef ICNV_VF_TG
-#define ICNV_VF_TG 32   // traceback group: 2 x 32 back-pointer lines in flight per wavefront
-#endif
-#ifndef ICNV_VF_TB
-#define ICNV_VF_TB 16   // genes per block of the uniform-alignment traceback (= back-pointer lines in flight); 16: 2.54 ms, 32: 2.58, 64: 2.61
-#endif
-#ifndef ICNV_VF_SB
-#define ICNV_VF_SB 0   // 1: a scheduling barrier behind every gene (measured 5 % slower: neighbouring genes of a chunk overlap a little)
-#endif
-#ifndef ICNV_VF_CH
-#define ICNV_VF_CH 8
-#endif
-#ifndef ICNV_VF_PIPE
-#define ICNV_VF_PIPE 0     // 1: score gene j + 1 from the table while gene j's recurrence step runs (measured: no gain, 3.28 vs 3.25 ms -- the SIMDs already issue 90 % of the time)
-#endif
-#ifndef ICNV_VF_POLICY
-#define ICNV_VF_POLICY 1   // bit 0: observations with the default cache policy (else non-temporal); bit 1: back-pointer / state traffic non-temporal
-#endif
-constexpr int FAST_NT = ICNV_VF_NT;
+// Launch geometry and chunk sizes (measured choices; experiments with other values are built as replacement translation
+// units by scripts/build_variant.sh, never by -D switches on this file):
+//   512 threads = 2 wavefronts per SIMD measured fastest (256: 5.2 ms, 384: 4.2, 512: 3.65, 640: 4.6, 768: 4.6, 1024: 6.7):
+//   fewer column streams per XCD (their lines survive in the 4 MiB L2) and no register spills
+constexpr int FAST_NT = 512;
+constexpr int FAST_TG = 32;   // traceback group: 2 x 32 back-pointer lines in flight per wavefront
+constexpr int FAST_TB = 16;   // genes per block of the uniform-alignment traceback (16: 2.54 ms, 32: 2.58, 64: 2.61)
+constexpr int FAST_CH = 8;    // genes per observation chunk: 64 bytes per lane and request
 constexpr int NCF = EMIS_DEG + 1;
 constexpr int SEG_DOUBLES = EMIS_MAX_SEG * 4 + EMIS_MAX_CELLS * 2;   // segment records + lookup cells at the start of the LDS image
 constexpr int CELL_OFF = EMIS_MAX_SEG * 4;
@@ -274,14 +259,7 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             locate(xv, idx, tn);
             poly(idx, tn, sc);
             const uint32_t word = step(sc);
-#if ICNV_VF_POLICY & 2
-            __builtin_nontemporal_store((uint16_t)word, bpc + i * 64);
-#else
-            bpc[i * 64] = (uint16_t)word;
-#endif
-#if ICNV_VF_SB
-            __builtin_amdgcn_sched_barrier(0);   // one gene at a time: interleaving the unrolled genes only spills
-#endif
+            bpc[i * 64] = (uint16_t)word;   // (no scheduling barrier between the genes of a chunk: neighbours overlap a little)
         };
         {
             double sc[K], tn0;
@@ -295,15 +273,13 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         // lane and request: every lane walks its own column, so the memory system sees 64 streams per wavefront;
         // 8-byte requests would fetch each line sixteen times through an L1 that cannot hold 1024 of them, and
         // small unaligned pieces of a DRAM burst arrive as separate requests long after the burst was evicted.
-        constexpr int CH = ICNV_VF_CH;
+        constexpr int CH = FAST_CH;
         auto load_chunk = [&](const double *p, double (&v)[CH]) {
 #pragma unroll
             for (int j = 0; j < CH; j += 2) {
-#if ICNV_VF_POLICY & 1
+                // default cache policy: the other half of the 128-byte line is this lane's next chunk (non-temporal
+                // loads measured 17 % slower)
                 const dbl2_t a0 = *reinterpret_cast<const dbl2_t *>(p + j);
-#else
-                const dbl2_t a0 = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t *>(p + j));
-#endif
                 v[j] = a0.x;
                 v[j + 1] = a0.y;
             }
@@ -319,44 +295,11 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         if (i + CH <= n) {
             double xcur[CH], xnext[CH];
             load_chunk(xc + i, xcur);
-#if ICNV_VF_PIPE
-            // software pipeline over genes: the table scores of gene j + 1 (two dependent LDS lookups, then the
-            // coefficient gathers) are requested before the recurrence step of gene j, whose arithmetic hides them
-            double sc[K];
-            {
-                double tn0;
-                int idx0;
-                locate(xcur[0], idx0, tn0);
-                poly(idx0, tn0, sc);
-            }
-#endif
             for (; i + CH <= n; i += CH) {
                 const bool more = i + 2 * CH <= n;
                 if (more) load_chunk(xc + i + CH, xnext);
-#if ICNV_VF_PIPE
-#pragma unroll
-                for (int j = 0; j < CH; ++j) {
-                    double scn[K], tn1;
-                    int idx1;
-                    const bool have = (j + 1 < CH) || more;
-                    if (have) {
-                        locate(j + 1 < CH ? xcur[(j + 1) % CH] : xnext[0], idx1, tn1);
-                        poly(idx1, tn1, scn);
-                    }
-                    const uint32_t word = step(sc);
-                    bpc[(i + j) * 64] = (uint16_t)word;
-                    if (have) {
-#pragma unroll
-                        for (int k = 0; k < K; ++k) sc[k] = scn[k];
-                    }
-#if ICNV_VF_SB
-                    __builtin_amdgcn_sched_barrier(0);
-#endif
-                }
-#else
 #pragma unroll
                 for (int j = 0; j < CH; ++j) gene(xcur[j], i + j);
-#endif
                 if (more) {
 #pragma unroll
                     for (int j = 0; j < CH; ++j) xcur[j] = xnext[j];
@@ -380,13 +323,7 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         {
             // OR of the words shifted by the traced state: bit 9 collects the "inside the band" bits of the path's rows
             uint32_t uacc = 0;
-            auto load_bp = [&](int i) {
-#if ICNV_VF_POLICY & 2
-                return (uint32_t)__builtin_nontemporal_load(bpc + i * 64);
-#else
-                return (uint32_t)bpc[i * 64];
-#endif
-            };
+            auto load_bp = [&](int i) { return (uint32_t)bpc[i * 64]; };
             auto step_bp = [&](uint32_t w, int c) {
                 const uint32_t tsh = w >> c;
                 uacc |= tsh;
@@ -394,8 +331,8 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             };
             const int a0 = (int)((uintptr_t)st & 15u);
             const int a0u = __builtin_amdgcn_readfirstlane(a0);
-            if (__builtin_amdgcn_ballot_w64(a0 != a0u) == 0) viterbi_traceback_uniform<ICNV_VF_TB>(st, n, cur, a0u, load_bp, step_bp);
-            else viterbi_traceback<ICNV_VF_TG>(st, n, cur, load_bp, step_bp);
+            if (__builtin_amdgcn_ballot_w64(a0 != a0u) == 0) viterbi_traceback_uniform<FAST_TB>(st, n, cur, a0u, load_bp, step_bp);
+            else viterbi_traceback<FAST_TG>(st, n, cur, load_bp, step_bp);
             unsure |= (uacc >> 9) & 1u;
         }
         if (unsure) {
