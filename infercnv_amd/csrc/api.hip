@@ -218,6 +218,9 @@ struct icnv_chain {
     int T = 0;
     uint32_t mask = 0;
     DevBuf d_chr, d_ref, d_b1, d_b2, d_den, d_partial, d_sums, d_cellstats, d_stats, d_inv, d_inv_codes, d_inv_dict;
+    DevBuf d_plan2, d_dict2;            // sub-block plan of the chain2 kernels (empty: layout not covered)
+    std::vector<uint32_t> plan2;
+    std::vector<double> dict2;
     std::vector<double> inv_tab, inv_dict;
     std::vector<uint32_t> inv_codes;
     bool inv_coded = false;   // host copy of the smoothing normalisation table (kept alive for the async upload)
@@ -391,6 +394,10 @@ static int chain_upload(icnv_chain *ch, hipStream_t s) {
         if ((rc = upload(ch->d_inv, ch->inv_tab.data(), ch->inv_tab.size(), s))) return rc;
         if ((rc = upload(ch->d_inv_codes, ch->inv_codes.data(), ch->inv_codes.size(), s))) return rc;
         if ((rc = upload(ch->d_inv_dict, ch->inv_dict.data(), ch->inv_dict.size(), s))) return rc;
+        if (chain2_build_plan(ch->chr_start.data(), ch->cfg.n_chr, (int32_t)G, ch->T, ch->plan2, ch->dict2)) {
+            if ((rc = upload(ch->d_plan2, ch->plan2.data(), ch->plan2.size(), s))) return rc;
+            if ((rc = upload(ch->d_dict2, ch->dict2.data(), ch->dict2.size(), s))) return rc;
+        }
     }
     ch->uploaded = true;
     return ICNV_OK;
@@ -416,6 +423,8 @@ static ChainArgs chain_args(icnv_chain *ch, const double *in) {
     a.inv_coded = ch->inv_coded ? 1 : 0;
     a.partial = ch->d_partial.as<double>();
     a.cell_stats = ch->d_cellstats.as<double>();
+    a.plan2 = ch->plan2.empty() ? nullptr : ch->d_plan2.as<uint32_t>();
+    a.dict2 = ch->plan2.empty() ? nullptr : ch->d_dict2.as<double>();
     return a;
 }
 

@@ -285,6 +285,12 @@ def test_residency_skips_uploads_and_notices_changes(dev):
         assert s2[0] - s1[0] == 2 and s2[1] == s1[1]
         for a, b in zip(base, got2):
             np.testing.assert_array_equal(a, b)
+        # identity is by content, not by address: a copy of x elsewhere in memory is recognised
+        x2 = x.copy(order="F")
+        ref2 = _host_chain_and_hmm(L, x2, cs, refs, hmm)
+        s2b = stats()
+        assert s2b[0] - s2[0] == 2 and s2b[1] == s2[1]
+        s2 = s2b
         # run()'s stand-alone steps, each fed the previous step's result: only the first matrix is uploaded
         vp = lambda a: a.ctypes.data_as(ct.c_void_p)
         bufs = [np.empty_like(x, order="F") for _ in range(2)]
@@ -295,12 +301,7 @@ def test_residency_skips_uploads_and_notices_changes(dev):
         s3 = stats()
         assert s3[0] - s2[0] == 6 and s3[1] == s2[1]
         assert np.abs(cur - base[1]).max() < 1e-12              # six steps == the fused chain's pre-denoise output
-        # identity is by content, not by address: a copy of x elsewhere in memory is recognised ...
-        x2 = x.copy(order="F")
-        s4 = stats()
-        ref2 = _host_chain_and_hmm(L, x2, cs, refs, hmm)
-        assert stats()[1] == s4[1]
-        # ... and ONE element changed in place -- same address, same shape, a position the strided sample skips (the
+        # ONE element changed in place -- same address, same shape, a position the strided sample skips (the
         # sample takes every 47th value of this matrix) -- is noticed: uploaded again, the result follows the data
         assert (G * C) // 16384 == 47
         for pos, delta in (((1, 0), 0.5), ((G // 2 + 1, C // 2), 1e-9), ((0, 0), 0.25)):
