@@ -233,7 +233,7 @@ struct icnv_chain {
     // cells keeps its output (one column per position of ref_idx), so that the later rounds and the apply pass
     // continue from it instead of smoothing the same cells again (three times per chain otherwise).
     bool cache_enabled = false;
-    DevBuf d_cache, d_nonref;
+    DevBuf d_cache, d_nonref, d_iota;   // d_iota: 0 .. n_ref - 1 (the cache holds one column per position of ref_idx)
     std::vector<int32_t> nonref;      // cells that are in no reference group
     const double *cache_in = nullptr; // matrix the cache was computed from (nullptr: invalid)
     uint32_t cache_mask = 0;          // stages already applied to the cached columns
@@ -377,6 +377,9 @@ static int chain_upload(icnv_chain *ch, hipStream_t s) {
                 if (!is_ref[c]) ch->nonref.push_back((int32_t)c);
             if ((rc = ch->d_cache.alloc(bytes))) return rc;
             if ((rc = upload(ch->d_nonref, ch->nonref.data(), ch->nonref.size(), s))) return rc;
+            std::vector<int32_t> iota(nref);
+            for (size_t i = 0; i < nref; ++i) iota[i] = (int32_t)i;
+            if ((rc = upload(ch->d_iota, iota.data(), iota.size(), s))) return rc;
             ch->cache_enabled = true;
         }
     }
@@ -544,6 +547,26 @@ int icnv_chain_round_partial_dev(icnv_chain_t *ch, int round, const double *expr
     }
     const bool fill_cache = ch->cache_enabled && (a.mask & (ICNV_ST_SMOOTH | ICNV_ST_CENTER));
     if (fill_cache) ch->cache_in = nullptr;
+    if (fill_cache && a.plan2 && a.mask == 0x0Fu && a.T == 50 && !ch->cfg.inv_log && ng <= 256) {
+        // One launch runs steps 8-11 on the reference cells of EVERY group into their cache (chain2.hip), one streaming
+        // launch sums the cached columns per gene and group: two launches whatever the number of groups, where a
+        // statistics launch + a reduction per group made this round the most expensive of the three.
+        const int nref = (int)ch->ref_idx.size();
+        a.cells = ch->d_ref.as<int32_t>();
+        a.n_cells = nref;
+        a.out = ch->d_cache.as<double>();
+        a.out_by_pos = 1;
+        const int rc2 = launch_chain(a, MODE_APPLY, s);
+        if (rc2) return rc2;
+        if ((rc = launch_group_gene_sums(ch->d_cache.as<double>(), (int32_t)G, ch->d_iota.as<int32_t>(), ch->d_ref_off.as<int32_t>(), ng,
+                                         ch->d_partial.as<double>(), 256, sums, s)))
+            return rc;
+        ch->cache_in = expr_in;
+        ch->cache_mask = a.mask;
+        if (partial_dev) *partial_dev = sums;
+        if (n) *n = G * ng + ng;
+        return ICNV_OK;
+    }
     for (int q = 0; q < ng; ++q) {
         const int cnt = ch->ref_off[q + 1] - ch->ref_off[q];
         double *dst = sums + (size_t)q * G;

@@ -135,10 +135,36 @@ __global__ void __launch_bounds__(C2_NT, 4) chain2_kernel(const Chain2Args a) {
         auto slot_valid = [&](int s) -> bool { return (vmc >> s) & 1u; };
 
         // ---------------- steps 8, 9, 10: wave-private, sub-block by sub-block ----------------
+        // Sub-block 0's values (HBM) are requested here, sub-block 1's as soon as sub-block 0's are in its window, so that
+        // they arrive while sub-block 0 is smoothed (LDS work only); the step-8 bound vectors (L2) follow per group of
+        // four slots.  The first wait of the cell also drains the previous cell's stores (vmcnt counts in order).
+        double xin[C2_NCS + 1][2];
+        auto slot_offsets = [&](int sb, uint32_t lu, uint32_t (&go)[C2_NCS + 1]) {
+            const int32_t *hdr = hdr_all + (C2_NSB * w + sb) * C2_HDR;
+            const int cg = hdr[0], cgn = hdr[1];
+            // six core slots and the halo slot (lanes 0..31 the pairs below the core, 32..63 above it)
+#pragma unroll
+            for (int s = 0; s < C2_NCS; ++s) go[s] = 8u * min((uint32_t)cg + 2u * (64u * s + lu), G - 2u);
+            const int hp = (lu < 32u) ? (cg >> 1) - 32 + (int)lu : (cgn >> 1) + (int)lu - 32;
+            go[C2_NCS] = 16u * (uint32_t)min(max(hp, 0), (int)(G >> 1) - 1);
+        };
+        auto request_cell = [&](int sb) {
+            uint32_t go[C2_NCS + 1];
+            slot_offsets(sb, lane_u, go);
+#pragma unroll
+            for (int s = 0; s <= C2_NCS; ++s) load_vec_stream<2>(reinterpret_cast<const double *>(src + go[s]), xin[s]);
+        };
+        request_cell(0);
 #pragma unroll
         for (int sb = 0; sb < C2_NSB; ++sb) {
             const int32_t *hdr = hdr_all + (C2_NSB * w + sb) * C2_HDR;
-            const int cg = hdr[0], cgn = hdr[1], nz = hdr[2];
+            const int nz = hdr[2];
+            uint32_t go[C2_NCS + 1];
+            {
+                uint32_t lu = lane_u;
+                asm volatile("" : "+v"(lu));   // (recomputed per sub-block: carried, the offsets are spilled)
+                slot_offsets(sb, lu, go);
+            }
             // this lane's plan words of the sub-block (position-only, L2-resident)
             uint32_t cc[3], hcw, ic[4];
             {
@@ -147,31 +173,21 @@ __global__ void __launch_bounds__(C2_NT, 4) chain2_kernel(const Chain2Args a) {
                 cc[0] = p0.x; cc[1] = p0.y; cc[2] = p0.z; hcw = p0.w;
                 ic[0] = p1.x; ic[1] = p1.y; ic[2] = p1.z; ic[3] = p1.w;
             }
-            // global requests: six core slots and the halo slot (lanes 0..31 the pairs below the core, 32..63 above it)
-            uint32_t go[C2_NCS + 1];
-#pragma unroll
-            for (int s = 0; s < C2_NCS; ++s) go[s] = 8u * min((uint32_t)cg + 2u * (64u * s + lane_u), G - 2u);
-            {
-                const int hp = (lane_u < 32u) ? (cg >> 1) - 32 + (int)lane_u : (cgn >> 1) + (int)lane_u - 32;
-                go[C2_NCS] = 16u * (uint32_t)min(max(hp, 0), (int)(G >> 1) - 1);
-            }
             // padding inside the window's needed range: zero runs (position-only, from the plan)
             for (int z = 0; z < nz; ++z) {
                 const int zs = hdr[4 + 2 * z], zl = hdr[5 + 2 * z];
                 if ((int)lane_u < zl) win[zs + (int)lane_u] = 0.0;
             }
-            // steps 8, 9 in two groups of slots (4 + 3): a group's values and its step-8 bound vectors (L2) are requested
-            // together -- one exposed latency per group; all seven slots at once would hold 84 registers.  The second
-            // resident workgroup of the CU covers the waits: the pass has ~23 us per cell and CU before HBM is the limit.
-            constexpr int AGS = 3;
+            // steps 8, 9 in two groups of slots (4 + 3): the step-8 bound vectors (L2) of a group are requested together,
+            // one exposed L2 latency per group (all seven pairs of bounds at once would hold 56 registers)
+            constexpr int AGS = 4;
 #pragma unroll
             for (int grp = 0; grp * AGS <= C2_NCS; ++grp) {
-                double xin[AGS][2], lo1[AGS][2], hi1[AGS][2];
+                double lo1[AGS][2], hi1[AGS][2];
 #pragma unroll
                 for (int j = 0; j < AGS; ++j) {
                     const int s = grp * AGS + j;
                     if (s > C2_NCS) continue;
-                    load_vec_stream<2>(reinterpret_cast<const double *>(src + go[s]), xin[j]);
                     if (mask & ICNV_ST_SUBTRACT_REF_1) {
                         load_vec<2>(reinterpret_cast<const double *>(b1lo + go[s]), lo1[j]);
                         load_vec<2>(reinterpret_cast<const double *>(b1hi + go[s]), hi1[j]);
@@ -184,7 +200,7 @@ __global__ void __launch_bounds__(C2_NT, 4) chain2_kernel(const Chain2Args a) {
                     double y[2];
 #pragma unroll
                     for (int v = 0; v < 2; ++v) {
-                        double x = xin[j][v];
+                        double x = xin[s][v];
                         if (mask & ICNV_ST_SUBTRACT_REF_1) x = subtract_ref(x, lo1[j][v], hi1[j][v], 1);
                         if (mask & ICNV_ST_MAX_THRESH) x = max_raw(min_raw(x, thr_hi), thr_lo);   // R/inferCNV_ops.R:2974-2975
                         y[v] = x;
@@ -200,6 +216,7 @@ __global__ void __launch_bounds__(C2_NT, 4) chain2_kernel(const Chain2Args a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (sb + 1 < C2_NSB) request_cell(sb + 1);   // arrives during this sub-block's smoothing
             wave_mem_fence();
             // ---- chunk layout: this lane owns window positions [L lane, L lane + L) ----
             const int p0 = L * (int)lane_u;
@@ -568,62 +585,79 @@ __global__ void __launch_bounds__(C2_NT, 4) chain2_kernel(const Chain2Args a) {
         char *dst = (MODE == MODE_APPLY) ? reinterpret_cast<char *>(a.out + ocol * (int64_t)G) : nullptr;
         char *dpre = (MODE == MODE_APPLY && a.pre_out) ? reinterpret_cast<char *>(a.pre_out + ocol * (int64_t)G) : nullptr;
         const char *b2lo = reinterpret_cast<const char *>(a.b2), *b2hi = reinterpret_cast<const char *>(a.b2 + G);
-        {
+        // Every step-12 bound vector (L2) is requested before the cell's first store -- a load issued behind a store waits
+        // for that store to complete (vmcnt counts in order): sub-block 0's bounds, its final values formed in place
+        // (registers), then sub-block 1's bounds, and only then the stores of both.
+        auto final_values = [&](int sb, int s, const double (&lo2)[2], const double (&hi2)[2], double (&y)[2]) {
+            getv(sb * C2_NCS + s, y);
 #pragma unroll
-            for (int sb = 0; sb < C2_NSB; ++sb) {
-                const int cg = hdr_all[(C2_NSB * w + sb) * C2_HDR];
-                constexpr int EGS = 3;   // slots per group: the step-12 bound vectors (L2) of a group are requested together
-#pragma unroll
-                for (int grp = 0; grp < C2_NCS / EGS; ++grp) {
-                    uint32_t go[EGS];
-                    double lo2[EGS][2], hi2[EGS][2];
-#pragma unroll
-                    for (int j = 0; j < EGS; ++j) {
-                        const int s = grp * EGS + j;
-                        go[j] = 8u * min((uint32_t)cg + 2u * (64u * s + lane_u), G - 2u);
-                        if (mask & ICNV_ST_SUBTRACT_REF_2) {
-                            load_vec<2>(reinterpret_cast<const double *>(b2lo + go[j]), lo2[j]);
-                            load_vec<2>(reinterpret_cast<const double *>(b2hi + go[j]), hi2[j]);
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < EGS; ++j) {
-                        const int sl = sb * C2_NCS + grp * EGS + j;
-                        double y[2];
-                        getv(sl, y);
-#pragma unroll
-                        for (int v = 0; v < 2; ++v) {
-                            double x = y[v] - center;   // step 11
-                            if (mask & ICNV_ST_SUBTRACT_REF_2) x = subtract_ref(x, lo2[j][v], hi2[j][v], 1);
-                            y[v] = x;
-                        }
-                        if (mask & ICNV_ST_INVERT_LOG2) {   // R/inferCNV_ops.R:2818
-                            const bool wide = !(__builtin_fabs(y[0]) < 1022.0) || !(__builtin_fabs(y[1]) < 1022.0);
-                            if (__builtin_expect(__builtin_amdgcn_ballot_w64(wide) != 0, 0)) {
-                                asm volatile("; exp2 outside the lean range" ::: "memory");
-                                y[0] = exp2(y[0]);
-                                y[1] = exp2(y[1]);
-                            } else {
-                                y[0] = exp2_lean(y[0]);
-                                y[1] = exp2_lean(y[1]);
-                            }
-                        }
-                        if (MODE == MODE_APPLY) {
-                            if (slot_valid(sl)) {
-                                if (dpre) store_vec_stream<2>(reinterpret_cast<double *>(dpre + go[j]), y);
-                                double o[2];
-#pragma unroll
-                                for (int v = 0; v < 2; ++v) {
-                                    o[v] = y[v];
-                                    if (mask & ICNV_ST_DENOISE)   // strict bounds, R/inferCNV_ops.R:2335
-                                        if (o[v] > lo_d && o[v] < hi_d) o[v] = mu;
-                                }
-                                store_vec_stream<2>(reinterpret_cast<double *>(dst + go[j]), o);
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+            for (int v = 0; v < 2; ++v) {
+                double x = y[v] - center;   // step 11
+                if (mask & ICNV_ST_SUBTRACT_REF_2) x = subtract_ref(x, lo2[v], hi2[v], 1);
+                y[v] = x;
+            }
+            if (mask & ICNV_ST_INVERT_LOG2) {   // R/inferCNV_ops.R:2818
+                const bool wide = !(__builtin_fabs(y[0]) < 1022.0) || !(__builtin_fabs(y[1]) < 1022.0);
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(wide) != 0, 0)) {
+                    asm volatile("; exp2 outside the lean range" ::: "memory");
+                    y[0] = exp2(y[0]);
+                    y[1] = exp2(y[1]);
+                } else {
+                    y[0] = exp2_lean(y[0]);
+                    y[1] = exp2_lean(y[1]);
                 }
+            }
+        };
+        auto store_pair = [&](int sl, uint32_t gofs, const double (&y)[2]) {
+            if (slot_valid(sl)) {
+                if (dpre) store_vec_stream<2>(reinterpret_cast<double *>(dpre + gofs), y);
+                double o[2];
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    o[v] = y[v];
+                    if (mask & ICNV_ST_DENOISE)   // strict bounds, R/inferCNV_ops.R:2335
+                        if (o[v] > lo_d && o[v] < hi_d) o[v] = mu;
+                }
+                store_vec_stream<2>(reinterpret_cast<double *>(dst + gofs), o);
+            }
+        };
+        {
+            uint32_t lane_e = lane_u;
+            asm volatile("" : "+v"(lane_e));   // the slots' byte offsets are formed again here (carried from the loads, they are spilled)
+            uint32_t go0[C2_NCS + 1], go1[C2_NCS + 1];
+            slot_offsets(0, lane_e, go0);
+            double lo2[C2_NCS][2], hi2[C2_NCS][2];
+#pragma unroll
+            for (int s = 0; s < C2_NCS; ++s) {
+                if (mask & ICNV_ST_SUBTRACT_REF_2) {
+                    load_vec<2>(reinterpret_cast<const double *>(b2lo + go0[s]), lo2[s]);
+                    load_vec<2>(reinterpret_cast<const double *>(b2hi + go0[s]), hi2[s]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < C2_NCS; ++s) final_values(0, s, lo2[s], hi2[s], wv[s]);
+            __builtin_amdgcn_sched_barrier(0);
+            slot_offsets(1, lane_e, go1);
+#pragma unroll
+            for (int s = 0; s < C2_NCS; ++s) {
+                if (mask & ICNV_ST_SUBTRACT_REF_2) {
+                    load_vec<2>(reinterpret_cast<const double *>(b2lo + go1[s]), lo2[s]);
+                    load_vec<2>(reinterpret_cast<const double *>(b2hi + go1[s]), hi2[s]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t lane_s = lane_u;
+            asm volatile("" : "+v"(lane_s));   // (and once more for the stores: twelve offsets held through the arithmetic are spilled)
+            uint32_t gs[C2_NCS + 1];
+            slot_offsets(0, lane_s, gs);
+#pragma unroll
+            for (int s = 0; s < C2_NCS; ++s) store_pair(s, gs[s], wv[s]);
+            slot_offsets(1, lane_s, gs);
+#pragma unroll
+            for (int s = 0; s < C2_NCS; ++s) {
+                double y[2];
+                final_values(1, s, lo2[s], hi2[s], y);
+                store_pair(C2_NCS + s, gs[s], y);
             }
         }
     }

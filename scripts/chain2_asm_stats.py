@@ -11,7 +11,7 @@ marks = [("            // padding inside the window's needed range", "A_put"), (
          ("        // ---------------- step 11: exact median", "MED_hist"), ("                        if (t < 64) {   // one wavefront scans", "MED_scan"),
          ("                        const int sbin = sel[0]", "MED_collect"), ("                            const int want = target - base - sbefore;", "MED_rank"),
          ("                        // refine inside the selected bin", "MED_refine(cold)"),
-         ("                center = (G & 1) ? mid_lo", "MED_end"), ("        // ---------------- steps 11 (subtract), 12, 14, 22", "E")]
+         ("                center = (G & 1) ? mid_lo", "MED_end"), ("        // ---------------- steps 11 (subtract), 12, 14, 22", "E"), ("        // ---------------- steps 8, 9, 10: wave-private", "A_loads")]
 for m, name in marks:
     if m not in src:
         print("marker anchor missing:", name)
