@@ -369,7 +369,7 @@ static int chain_upload(icnv_chain *ch, hipStream_t s) {
         const size_t nref = ch->ref_idx.size();
         const size_t bytes = nref * (size_t)G * sizeof(double);
         const char *off = std::getenv("ICNV_REF_CACHE");   // developer switch: ICNV_REF_CACHE=0 recomputes the reference cells
-        if (!ch->large && nref > 0 && nref * 2 <= (size_t)ch->cfg.C && bytes <= ((size_t)16 << 30) && !(off && off[0] == '0') &&
+        if (!ch->large && nref > 0 && bytes <= ((size_t)16 << 30) && !(off && off[0] == '0') &&
             (ch->mask & (ICNV_ST_SMOOTH | ICNV_ST_CENTER))) {
             std::vector<char> is_ref((size_t)ch->cfg.C, 0);
             for (int32_t c : ch->ref_idx) is_ref[c] = 1;
@@ -547,8 +547,8 @@ int icnv_chain_round_partial_dev(icnv_chain_t *ch, int round, const double *expr
     }
     const bool fill_cache = ch->cache_enabled && (a.mask & (ICNV_ST_SMOOTH | ICNV_ST_CENTER));
     if (fill_cache) ch->cache_in = nullptr;
-    if (fill_cache && a.plan2 && a.mask == 0x0Fu && a.T == 50 && !ch->cfg.inv_log && ng <= 256) {
-        // One launch runs steps 8-11 on the reference cells of EVERY group into their cache (chain2.hip), one streaming
+    if (fill_cache && !ch->cfg.inv_log && ng <= 256) {
+        // One launch runs the stages in front of this round on the reference cells of EVERY group into their cache, one streaming
         // launch sums the cached columns per gene and group: two launches whatever the number of groups, where a
         // statistics launch + a reduction per group made this round the most expensive of the three.
         const int nref = (int)ch->ref_idx.size();

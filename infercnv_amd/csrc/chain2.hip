@@ -122,6 +122,7 @@ __global__ void __launch_bounds__(C2_NT, 4) chain2_kernel(const Chain2Args a) {
     const int32_t *hdr_all = reinterpret_cast<const int32_t *>(a.plan) + C2_P_HDR;
 
     for (int cell = (int)blockIdx.x; cell < a.n_cells; cell += (int)gridDim.x) {
+        PROF_DECL;
         const int64_t col = (int64_t)((a.cells && !a.in_by_pos) ? sload_i32(a.cells + cell) : cell);
         const char *src = reinterpret_cast<const char *>(a.in + col * (int64_t)G);
         const char *b1lo = reinterpret_cast<const char *>(a.b1), *b1hi = reinterpret_cast<const char *>(a.b1 + G);
@@ -216,6 +217,7 @@ __global__ void __launch_bounds__(C2_NT, 4) chain2_kernel(const Chain2Args a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            PROF(sb == 0 ? 0 : 2);
             if (sb + 1 < C2_NSB) request_cell(sb + 1);   // arrives during this sub-block's smoothing
             wave_mem_fence();
             // ---- chunk layout: this lane owns window positions [L lane, L lane + L) ----
@@ -314,6 +316,7 @@ __global__ void __launch_bounds__(C2_NT, 4) chain2_kernel(const Chain2Args a) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) cc1[j] = cc[j];
             }
+            PROF(sb == 0 ? 1 : 3);
             wave_mem_fence();
         }
         // the pair of S-layout slot s: registers (sub-block 0) or this wavefront's window (sub-block 1)
@@ -423,6 +426,7 @@ __global__ void __launch_bounds__(C2_NT, 4) chain2_kernel(const Chain2Args a) {
                         };
                         if (level == 0) hist_pass(std::true_type{}); else hist_pass(std::false_type{});
                         __syncthreads();
+                        PROF(4);
                         if (t < 64) {   // one wavefront scans the histogram: lane l owns bins [32 l, 32 l + 32)
                             constexpr int BPL = NB_HIST / 64;
                             uint32_t mine = 0;
@@ -448,6 +452,7 @@ __global__ void __launch_bounds__(C2_NT, 4) chain2_kernel(const Chain2Args a) {
                             if (t == 0) { sel[3] = (int)fresh_u64(0ull); skey[0] = fresh_u64(~0ull); skey[1] = fresh_u64(0ull); }
                         }
                         __syncthreads();
+                        PROF(5);
                         const int sbin = sel[0];
                         int sbefore = sel[1], scnt = sel[2];
                         for (int b = t; b < NB_HIST; b += C2_NT) hist[b] = 0u;   // ready for the next use
@@ -486,6 +491,7 @@ __global__ void __launch_bounds__(C2_NT, 4) chain2_kernel(const Chain2Args a) {
                                 }
                             }
                             __syncthreads();
+                            PROF(6);
                             const int want = target - base - sbefore;
                             {   // rank the candidates with the whole workgroup: candidate x slice, partial counts meet in cnt[]
                                 uint32_t *cnt = hist;
@@ -580,6 +586,7 @@ __global__ void __launch_bounds__(C2_NT, 4) chain2_kernel(const Chain2Args a) {
             }
         }
 
+        PROF(7);
         // ---------------- steps 11 (subtract), 12, 14, 22 and the stores: S layout ----------------
         const int64_t ocol = (int64_t)((a.cells && !a.out_by_pos) ? sload_i32(a.cells + cell) : cell);
         char *dst = (MODE == MODE_APPLY) ? reinterpret_cast<char *>(a.out + ocol * (int64_t)G) : nullptr;
@@ -660,6 +667,7 @@ __global__ void __launch_bounds__(C2_NT, 4) chain2_kernel(const Chain2Args a) {
                 store_pair(C2_NCS + s, gs[s], y);
             }
         }
+        PROF(8);
     }
 }
 
@@ -692,7 +700,13 @@ bool chain2_build_plan(const int32_t *chr_start, int32_t n_chr, int32_t G, int32
     plan.clear();
     dict.clear();
     if (T != 50 || (G & 1) || G < 4 || n_chr < 1) return false;
-    if (const char *e = std::getenv("ICNV_CHAIN2")) if (e[0] == '0') return false;   // developer switch: chain_kernel.inc only
+    // Opt-in (ICNV_CHAIN2=1): measured on MI355X this kernel is SLOWER than chain_kernel.inc (3.0 vs 2.36 ms for 45 000
+    // cells; DESIGN.md section 4 has the phase profile and the ablations), so the product path does not use it.  It stays
+    // in the tree, parity-tested, as the measured answer to "a second resident cell per CU".
+    {
+        const char *e = std::getenv("ICNV_CHAIN2");
+        if (!(e && e[0] == '1')) return false;
+    }
     const int PAD = (T + 3) & ~1, HALO = PAD, CORE = C2_WIN - 2 * HALO;
     std::vector<int32_t> chr_of((size_t)G);
     for (int k = 0; k < n_chr; ++k)
@@ -860,9 +874,9 @@ int launch_chain2(const ChainArgs &a, int mode, hipStream_t stream) {
     c.in_by_pos = a.in_by_pos; c.out_by_pos = a.out_by_pos; c.max_thresh = a.max_thresh; c.b1 = a.b1; c.b2 = a.b2; c.denoise = a.denoise;
     c.plan = a.plan2; c.inv_dict = a.dict2;
     const uint32_t m = a.mask;
-    if (mode == MODE_APPLY && m == 0x7Fu) return launch_chain2_t<MODE_APPLY, 0x7F, 50>(c, stream, a.in_by_pos ? "chain_apply_ref" : "chain_apply");
-    if (mode == MODE_APPLY && m == 0x3Fu) return launch_chain2_t<MODE_APPLY, 0x3F, 50>(c, stream, a.in_by_pos ? "chain_apply_ref" : "chain_apply");
-    if (mode == MODE_APPLY && m == 0x0Fu) return launch_chain2_t<MODE_APPLY, 0x0F, 50>(c, stream, "chain_stage_ref");   // steps 8-11 of the reference cells into their cache
+    if (mode == MODE_APPLY && m == 0x7Fu) return launch_chain2_t<MODE_APPLY, 0x7F, 50>(c, stream, "chain2_apply");
+    if (mode == MODE_APPLY && m == 0x3Fu) return launch_chain2_t<MODE_APPLY, 0x3F, 50>(c, stream, "chain2_apply");
+    if (mode == MODE_APPLY && m == 0x0Fu) return launch_chain2_t<MODE_APPLY, 0x0F, 50>(c, stream, "chain2_stage_ref");   // steps 8-11 of the reference cells into their cache
     return CHAIN_NOT_INSTANTIATED;
 }
 
@@ -871,6 +885,17 @@ int launch_chain2(const ChainArgs &a, int mode, hipStream_t stream) {
 // Developer / test hook (not part of include/icnv.h): the sub-block plan of a chromosome layout, so that the host logic
 // can be checked without a GPU (tests/test_host.py emulates the kernel's data movement from this image).
 // Returns the number of plan words (0: the layout is not covered); plan_out may be null to ask for the size.
+#ifdef ICNV_CHAIN_PROFILE
+extern "C" int icnv_debug_chain2_profile(unsigned long long *out32, int reset) {
+    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(icnv::g_chain_prof), 32 * sizeof(unsigned long long)) != hipSuccess) return 2;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(icnv::g_chain_prof), z, sizeof(z)) != hipSuccess) return 2;
+    }
+    return 0;
+}
+#endif
+
 extern "C" int icnv_debug_chain2_plan(const int32_t *chr_start, int32_t n_chr, int32_t G, int32_t T, uint32_t *plan_out,
                                       int32_t plan_cap, double *dict_out256) {
     std::vector<uint32_t> plan;
