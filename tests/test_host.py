@@ -351,7 +351,7 @@ def _chain2_emulate_smoothing(plan, dct, x, T=50):
 
 
 @pytest.mark.parametrize("layout", ["bench", "odd_starts", "short_chromosomes", "one_chromosome", "tail"])
-def test_chain2_plan_emulated_smoothing_equals_oracle(layout):
+def test_chain2_plan_emulated_smoothing_equals_oracle(layout, monkeypatch):
     """The host side of the two-cells-per-CU chain kernels (csrc/chain2.hip): the sub-block plan -- core gene ranges,
     window positions of every loaded pair, halo pairs, zero runs, dictionary codes -- drives a NumPy emulation of the
     kernel's data movement and arithmetic; the result must be the oracle's pyramid smoothing for every gene
@@ -359,6 +359,7 @@ def test_chain2_plan_emulated_smoothing_equals_oracle(layout):
     than the window, a single chromosome, and layouts the plan must refuse."""
     import oracle_np as onp
     from infercnv_amd import synth
+    monkeypatch.setenv("ICNV_CHAIN2", "1")                  # the kernels are opt-in (slower than the product kernel); so is their plan
     rng = np.random.default_rng(len(layout))
     if layout == "bench":
         G = 10000
