@@ -141,6 +141,102 @@ def host_path_rate(x_dev, chr_start, refs, hmm, cells=20000):
     return res
 
 
+def run_group_config(args, world, rank):
+    """BASELINE configs 4 (i3 HMM at subcluster level) and 5 (2-D median filter): subclusters / tiles are whole on their
+    rank (contiguous cell blocks cut at subcluster boundaries, sharded.align_to_groups); the inputs -- the smoothing
+    chain's outputs -- are produced once, untimed; a step is one pass of the group HMM (two all-reduces of two doubles for
+    the i3 mu / sigma, then rank-local) or of the median filter (no collective) over this rank's resident cells."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from infercnv_amd import device, sharded, synth
+    G, C_total = args.genes, args.cells * world
+    subs, is_ref, cuts = synth.subclusters(C_total)
+    c0, c1 = sharded.align_to_groups(C_total, world, cuts)[rank]
+    C_local = c1 - c0
+    x, chr_start = synth.make_matrix_torch(G, C_local, "cuda", cell_offset=c0, C_total=C_total)
+    refs_global, _ = synth.groups(C_total)
+    plan = device.ChainPlan(G, C_local, chr_start, sharded.localize_groups(refs_global, c0, c1))
+    out, pre = sharded.ShardedChain(plan).run(x, want_pre_denoise=True)
+    del x
+    mine = [i for i, g in enumerate(subs) if c0 <= int(g[0]) < c1]
+    assert all(c0 <= int(subs[i].min()) and int(subs[i].max()) < c1 for i in mine), "a subcluster straddles two ranks"
+    local = [(subs[i] - c0).astype(np.int32) for i in mine]
+    ref_local = np.concatenate([local[j] for j, i in enumerate(mine) if is_ref[i]] or [np.zeros(0, dtype=np.int32)])
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if args.config == 4:
+        del out
+        hmm = sharded.ShardedGroupHMM(device=dev)
+        result = [None]
+        def step():
+            result[0] = hmm.run_i3(pre, chr_start, local, ref_local)
+        names = ("chain_cell_stats", "group_means", "viterbi", "viterbi_groups", "viterbi_redo", "viterbi_exact_fallback", "broadcast_states")
+        what = "i3 HMM at subcluster level (R/inferCNV_i3HMM.R:249-308): i3 mu / sigma over the reference values (2 all-reduces of 2 doubles), group means, Viterbi per subcluster, broadcast"
+        alg = 9 * G * C_local          # read every value once (group means), write one state byte per gene*cell
+    else:
+        del pre
+        mf = sharded.ShardedMedianFilter()
+        result = [None]
+        def step():
+            result[0] = mf.run(out, chr_start, local, 7)
+        names = ("median_filter",)
+        what = "apply_median_filtering, window_size 7 (9 x 9 windows clamped at tile x chromosome edges; R/noise_reduction.R:43-113), tiles = subclusters x chromosomes, no collective"
+        alg = 2 * 8 * G * C_local
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_kernel_timing:
+        device.timing_reset()
+        device.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    device.timing_enable(False)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    cells = torch.tensor([float(C_local)], dtype=torch.float64, device="cuda")
+    csum = torch.tensor([float(result[0].sum(dtype=torch.float64))], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        allc = [torch.zeros_like(csum) for _ in range(world)]
+        dist.all_gather(allc, csum)
+        checks = [float(v.item()) for v in allc]
+    else:
+        checks = [float(csum.item())]
+    elapsed = float(tmax.item())
+    if rank == 0:
+        kernels = {}
+        for k in names:
+            ms, n = device.timing_get(k)
+            if n:
+                kernels[k] = {"avg_ms": ms / n, "launches_per_step": n / args.steps, "ms_per_step": ms / args.steps}
+        ms_per_step = elapsed / args.steps * 1e3
+        ksum = sum(v["ms_per_step"] for v in kernels.values())
+        res = {"metric": ("cells/sec through the i3 HMM at subcluster level, 10k genes" if args.config == 4 else
+                          "cells/sec through apply_median_filtering, 10k genes"),
+               "value": C_total * args.steps / elapsed, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic",
+               "config": {"workload": f"BASELINE config {args.config}: synthetic {G} genes x {args.cells} cells per GPU ({C_total} total), "
+                                      f"{what}; inputs (the smoothing chain's output) resident in HBM",
+                          "genes": G, "cells_per_gpu": args.cells, "cells_total": C_total, "subclusters_rank0": len(local),
+                          "parallelism": f"whole subclusters per GPU x{world} (contiguous blocks cut at subcluster boundaries)"},
+               "roofline": {"bound": "hbm", "achieved": alg / (max(ksum, 1e-9) * 1e-3) / 1e9 if kernels else None, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": (alg / (ksum * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernels and ksum > 0 else None, "traffic": None,
+                            "algorithmic_bytes_per_step": alg, "kernel_ms_per_step": ksum,
+                            "note": "all kernels of the step together (group means / Viterbi / broadcast, or the interior and edge median kernels)"},
+               "kernels": kernels, "cpu_baseline": None,
+               "checksums": {"per_rank": checks, "meaning": "sum of the step's output (states, or the filtered matrix) over the rank's cells"}}
+        print(json.dumps(res))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,6 +246,9 @@ def main():
     ap.add_argument("--cells", type=int, default=50000, help="cells per GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5),
+                    help="BASELINE.json config: 2 (default) fused smooth chain + per-cell i6 HMM -- the headline metric; "
+                         "4 i3 HMM at subcluster level; 5 apply_median_filtering (whole subclusters / tiles per GPU, SURVEY.md 8e)")
     ap.add_argument("--checksum", type=int, default=0, metavar="PARTS",
                     help="also print checksums of the outputs: per rank (N > 1), or -- on one rank -- per residue class of the cell "
                          "index modulo PARTS, i.e. the cells rank r of a PARTS-rank run holds (tests/test_gpu_entrypoints.py)")
@@ -180,6 +279,12 @@ def main():
 
     G, C_local = args.genes, args.cells
     C_total = C_local * world
+    if args.config in (4, 5):
+        run_group_config(args, world, rank)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     # cells are dealt to the ranks round-robin (sharded.cyclic_cells): every rank holds its share of every
     # reference group, so the reference rounds are balanced (the generator puts the reference cells first)
     x, chr_start = synth.make_matrix_torch(G, C_local, "cuda", cell_offset=rank, cell_stride=world, C_total=C_total)

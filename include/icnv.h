@@ -296,6 +296,14 @@ int icnv_states_to_proxy_dev(const uint8_t *states, double *out, int64_t n, int3
 int icnv_cells_mean_sd_dev(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx,
                            int64_t n_cells, double *out2_host, void *stream);
 int icnv_cells_mean_sd(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx, int64_t n_cells, double *out2);
+/* The same statistic split in two for a cell-sharded caller ("i3: [sum x, sum x^2, n] over reference
+ * values"; in the two-pass form R's sd() uses):
+ *   phase 0: out3_host = {sum of the values, number of values, 0}                 -> all-reduce(sum) -> mean = sum / n
+ *   phase 1: out3_host = {sum of (x - mean)^2 over the values, number, 0}         -> all-reduce(sum) -> sd = sqrt(ss / (n - 1))
+ * A rank that holds none of the cells passes n_cells = 0 (expr may then be NULL) and contributes zeros.
+ * Replaces the mean(ref values) / sd(ref values) of .i3HMM_get_sd_trend_by_num_cells_fit, R/inferCNV_i3HMM.R:38-52. */
+int icnv_cells_moments_partial_dev(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx, int64_t n_cells,
+                                   int32_t phase, double mean, double *out3_host, void *stream);
 
 /* ---- 2-D median denoise -------------------------------------------------- */
 /* apply_median_filtering / .median_filter (R/noise_reduction.R:43-113): for

@@ -103,6 +103,7 @@ PROTOTYPES = {
     "icnv_states_to_proxy_dev": (ct.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "icnv_cells_mean_sd_dev": (ct.c_int, [_vp, _i64, _i64, _ip, _i64, _dp, _vp]),
     "icnv_cells_mean_sd": (ct.c_int, [_vp, _i64, _i64, _ip, _i64, _dp]),
+    "icnv_cells_moments_partial_dev": (ct.c_int, [_vp, _i64, _i64, _ip, _i64, ct.c_int32, ct.c_double, _dp, _vp]),
     "icnv_median_filter": (ct.c_int, [_vp, _vp, _i64, _i64, _ip, _i32, _ip, _ip, _i32, _i32]),
     "icnv_median_filter_dev": (ct.c_int, [_vp, _vp, _i64, _i64, _ip, _i32, _ip, _ip, _i32, _i32, _vp]),
     "icnv_timing_enable": (None, [ct.c_int]),

@@ -1376,11 +1376,11 @@ int icnv_states_to_proxy(const uint8_t *states, double *out, int64_t n, int32_t 
     return ICNV_OK;
 }
 
-int icnv_cells_mean_sd_dev(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx, int64_t n_cells,
-                           double *out2_host, void *stream) {
-    if (!expr || !out2_host || G < 1 || n_cells < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
-    // mean over all G*n values, then sd around that mean: one GENE_SUMS-free pass
-    // over the listed cells using the chain kernel's per-cell statistics.
+// per-cell (sum, sd) of the listed cells -> host, through the chain kernel's per-cell statistics
+static int cells_sum_sd(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx, int64_t n_cells,
+                        std::vector<double> &cstat, void *stream) {
+    cstat.assign((size_t)std::max<int64_t>(n_cells, 0) * 2, 0.0);
+    if (n_cells == 0) return ICNV_OK;
     icnv_chain_cfg cfg;
     std::memset(&cfg, 0, sizeof(cfg));
     std::vector<int32_t> cs = {0, (int32_t)G}, off = {0, (int32_t)n_cells};
@@ -1393,7 +1393,6 @@ int icnv_cells_mean_sd_dev(const double *expr, int64_t G, int64_t C, const int32
     double *part = nullptr;
     rc = icnv_chain_round_partial_dev(ch, 0, expr, &part, nullptr, stream);
     hipStream_t s = (hipStream_t)stream;
-    std::vector<double> cstat((size_t)n_cells * 2);
     if (!rc) {
         hipError_t e = hipMemcpyAsync(cstat.data(), ch->d_cellstats.p, cstat.size() * sizeof(double),
                                       hipMemcpyDeviceToHost, s);
@@ -1401,8 +1400,48 @@ int icnv_cells_mean_sd_dev(const double *expr, int64_t G, int64_t C, const int32
         if (e != hipSuccess) rc = hip_fail(e, "copy cell stats", __FILE__, __LINE__);
     }
     icnv_chain_end(ch);
+    return rc;
+}
+
+// Split-phase mean / sd over ALL values of the listed cells (i3 emission parameters, R/inferCNV_i3HMM.R:17-80) for a
+// cell-sharded caller: the statistic is two dependent sums,
+//   phase 0: out3 = {sum of the values, number of values, 0}                       -> all-reduce -> mean = sum / n
+//   phase 1: out3 = {sum of (x - mean)^2 over the values, number of values, 0}     -> all-reduce -> sd = sqrt(ss / (n - 1))
+// (R's sd() is this two-pass form).  The squares are pooled exactly from the per-cell (sum, sd) pairs of the chain
+// kernel's statistics pass: sum_c [sd_c^2 (G - 1) + G (m_c - mean)^2], accumulated in long double on the host.
+// A rank without listed cells passes n_cells = 0 and contributes zeros.
+int icnv_cells_moments_partial_dev(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx, int64_t n_cells,
+                                   int32_t phase, double mean, double *out3_host, void *stream) {
+    if (!out3_host || G < 1 || n_cells < 0 || (n_cells > 0 && !expr) || (phase != 0 && phase != 1))
+        ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    int rc = validate_index_list(cell_idx, n_cells, C, "cell");
     if (rc) return rc;
-    // combine per-cell (sum, sd): total mean, pooled sum of squares
+    std::vector<double> cstat;
+    if ((rc = cells_sum_sd(expr, G, C, cell_idx, n_cells, cstat, stream))) return rc;
+    long double acc = 0;
+    if (phase == 0) {
+        for (int64_t i = 0; i < n_cells; ++i) acc += cstat[2 * i];
+    } else {
+        const long double mu = mean;
+        for (int64_t i = 0; i < n_cells; ++i) {
+            const long double m_i = (long double)cstat[2 * i] / (long double)G;
+            const long double sd_i = cstat[2 * i + 1];
+            acc += sd_i * sd_i * (long double)(G - 1) + (long double)G * (m_i - mu) * (m_i - mu);
+        }
+    }
+    out3_host[0] = (double)acc;
+    out3_host[1] = (double)n_cells * (double)G;
+    out3_host[2] = 0.0;
+    return ICNV_OK;
+}
+
+int icnv_cells_mean_sd_dev(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx, int64_t n_cells,
+                           double *out2_host, void *stream) {
+    if (!expr || !out2_host || G < 1 || n_cells < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    // one rank: the two phases of the split form share the per-cell statistics
+    std::vector<double> cstat;
+    int rc = cells_sum_sd(expr, G, C, cell_idx, n_cells, cstat, stream);
+    if (rc) return rc;
     long double tot = 0;
     for (int64_t i = 0; i < n_cells; ++i) tot += cstat[2 * i];
     const long double N = (long double)n_cells * (long double)G;

@@ -271,6 +271,17 @@ def cells_mean_sd(x, cell_idx):
     return out[0], out[1]
 
 
+def cells_moments_partial(x, cell_idx, phase, mean=0.0):
+    """One rank's share of the split-phase mean / sd over all values of the listed cells (icnv_cells_moments_partial_dev):
+    phase 0 -> (sum of values, number of values), phase 1 -> (sum of (x - mean)^2, number of values)."""
+    L = _lib.load()
+    C, G = _check_matrix(x)
+    idx, ip = i32(cell_idx)
+    out = (ct.c_double * 3)()
+    check(L.icnv_cells_moments_partial_dev(_ptr(x), G, C, ip, idx.size, int(phase), float(mean), out, _stream()))
+    return out[0], out[1]
+
+
 # ------------------------------------------------------------------ median filter
 def median_filter(x, chr_start, tiles, window_size=7, out=None):
     """apply_median_filtering (R/noise_reduction.R:43-113) on device tensors."""

@@ -88,3 +88,125 @@ class ShardedChain:
             self._all_reduce(buf)
             self.engine.round_finish(r)
         return self.engine.apply(x_local, out=out, want_pre_denoise=want_pre_denoise)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Group-level HMM (BASELINE config 4: i3 at subcluster level) and the 2-D median filter (config 5) on cell shards.
+#
+# Groups are independent in the group HMM (R/inferCNV_HMM.R:371, 529-533; R/inferCNV_i3HMM.R:249-308) and tiles in the
+# median filter (R/noise_reduction.R:57-86), so the partition puts every group / tile WHOLE on one rank: no halo, no
+# cross-rank mean.  RCCL call sequence per step (all latency-bound, f64, sum):
+#   group HMM, i3:  all-reduce of 2 doubles {sum x, n} over the reference values     -> mu
+#                   all-reduce of 2 doubles {sum (x - mu)^2, n}                      -> sigma, delta = |qnorm(p, 0, sigma)|
+#                   then group means -> Viterbi -> broadcast, rank-local
+#   group HMM, i6:  none (the per-group sd comes from the hspike fit, a host-side input)
+#   median filter:  none
+def assign_groups(group_sizes, world: int):
+    """Whole groups to ranks: longest group first onto the least loaded rank (ties: lowest rank) -- deterministic.
+    Returns one ascending list of group ids per rank."""
+    sizes = [int(s) for s in group_sizes]
+    load = [0] * world
+    out = [[] for _ in range(world)]
+    for gid in sorted(range(len(sizes)), key=lambda i: (-sizes[i], i)):
+        r = min(range(world), key=lambda k: (load[k], k))
+        out[r].append(gid)
+        load[r] += sizes[gid]
+    return [sorted(v) for v in out]
+
+
+def gather_groups(groups, group_ids):
+    """The cells a rank holds when it owns `group_ids`: (global cell ids in storage order, the groups as LOCAL index lists).
+    A cell that sits in several owned groups is stored once."""
+    cells, pos = [], {}
+    local = []
+    for gid in group_ids:
+        idx = []
+        for c in np.asarray(groups[gid], dtype=np.int64):
+            c = int(c)
+            if c not in pos:
+                pos[c] = len(cells)
+                cells.append(c)
+            idx.append(pos[c])
+        local.append(np.asarray(idx, dtype=np.int32))
+    return np.asarray(cells, dtype=np.int64), local
+
+
+def _all_reduce_pair(a, b, pg=None, device=None):
+    """all-reduce(sum) of two doubles; a no-op without an initialised process group."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(pg) > 1):
+        return float(a), float(b)
+    buf = torch.tensor([a, b], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=pg)
+    v = buf.cpu().tolist()
+    return v[0], v[1]
+
+
+def sharded_mean_sd(moments_partial, pg=None, device=None):
+    """mean and sd over ALL reference values of a cell-sharded matrix (R/inferCNV_i3HMM.R:38-52: mean(ref), sd(ref)):
+    `moments_partial(phase, mean)` returns this rank's {sum, n} (phase 0) or {sum (x - mean)^2, n} (phase 1) --
+    icnv_cells_moments_partial_dev; two all-reduces of two doubles."""
+    s, n = _all_reduce_pair(*moments_partial(0, 0.0), pg=pg, device=device)
+    if not n > 1:
+        raise ValueError("fewer than two reference values")
+    mean = s / n
+    ss, n2 = _all_reduce_pair(*moments_partial(1, mean), pg=pg, device=device)
+    return mean, float(np.sqrt(ss / (n2 - 1.0)))
+
+
+class DeviceGroupEngine:
+    """The rank-local pieces of the group HMM / median filter on libicnv_hip.so (device-resident tensors)."""
+
+    def moments_partial(self, x_local, ref_local, phase, mean):
+        from . import device
+        return device.cells_moments_partial(x_local, ref_local, phase, mean)
+
+    def viterbi_groups(self, x_local, chr_start, groups_local, means, sds, logPi, logDelta):
+        from . import device
+        return device.viterbi_groups(x_local, chr_start, groups_local, means, sds, logPi, logDelta)[0]
+
+    def median_filter(self, x_local, chr_start, tiles_local, window_size):
+        from . import device
+        return device.median_filter(x_local, chr_start, tiles_local, window_size)
+
+
+class ShardedGroupHMM:
+    """predict_CNV_via_HMM_on_tumor_subclusters / _whole_tumor_samples and their i3 forms on a cell-sharded matrix whose
+    groups are whole on their ranks (assign_groups + gather_groups, or contiguous blocks cut by align_to_groups)."""
+
+    def __init__(self, engine=None, process_group=None, device=None):
+        self.engine = engine or DeviceGroupEngine()
+        self.pg = process_group
+        self.device = device
+
+    def i3_params(self, x_local, ref_local, i3_p_val=0.05):
+        """(mu, sigma, delta) of .i3HMM_get_sd_trend_by_num_cells_fit (R/inferCNV_i3HMM.R:17-80, 435-445)."""
+        import statistics
+        mu, sigma = sharded_mean_sd(lambda ph, m: self.engine.moments_partial(x_local, ref_local, ph, m), self.pg, self.device)
+        return mu, sigma, abs(statistics.NormalDist(0.0, sigma).inv_cdf(i3_p_val))
+
+    def run_i3(self, x_local, chr_start, groups_local, ref_local, t=1e-6, i3_p_val=0.05):
+        """i3HMM_predict_CNV_via_HMM_on_tumor_subclusters (R/inferCNV_i3HMM.R:249-308): states of this rank's cells."""
+        mu, sigma, delta = self.i3_params(x_local, ref_local, i3_p_val)
+        Pi = np.full((3, 3), t)
+        np.fill_diagonal(Pi, 1.0 - 5.0 * t)               # the reference's 1 - 5t diagonal with three states (:108-112)
+        d0 = np.array([t, 1.0 - 5.0 * t, t])
+        means = np.array([mu - delta, mu, mu + delta])
+        return self.engine.viterbi_groups(x_local, chr_start, groups_local, means, [sigma] * len(groups_local),
+                                          np.log(Pi), np.log(d0))
+
+    def run_i6(self, x_local, chr_start, groups_local, means, sd_per_group, logPi, logDelta):
+        """predict_CNV_via_HMM_on_tumor_subclusters (R/inferCNV_HMM.R:345-408): no exchange at all."""
+        return self.engine.viterbi_groups(x_local, chr_start, groups_local, means, sd_per_group, logPi, logDelta)
+
+
+class ShardedMedianFilter:
+    """apply_median_filtering (R/noise_reduction.R:43-113) on a cell-sharded matrix whose tiles are whole on their ranks:
+    rank-local, no collective."""
+
+    def __init__(self, engine=None):
+        self.engine = engine or DeviceGroupEngine()
+
+    def run(self, x_local, chr_start, tiles_local, window_size=7):
+        return self.engine.median_filter(x_local, chr_start, tiles_local, window_size)

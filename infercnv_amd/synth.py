@@ -51,6 +51,25 @@ def groups(C, ref_frac=0.10, n_ref_groups=2, n_clones=4):
     return refs, obs
 
 
+def subclusters(C, size=500, ref_frac=0.10, n_ref_groups=2, n_clones=4):
+    """BASELINE configs 4 / 5: consecutive blocks of `size` members within each annotation group.
+    Returns (subclusters as global cell index arrays -- reference groups first --, is_ref flag per subcluster, cut
+    candidates: the cell offsets at which no subcluster is split, for sharded.align_to_groups)."""
+    refs, obs = groups(C, ref_frac, n_ref_groups, n_clones)
+    subs, is_ref = [], []
+    for flag, grp in ((True, refs), (False, obs)):
+        for g in grp:
+            for s in range(0, len(g), size):
+                subs.append(g[s:s + size])
+                is_ref.append(flag)
+    n_ref = int(sum(len(r) for r in refs))
+    cuts = {0, C, n_ref}
+    for r in refs:
+        cuts.update(int(r[0]) + k for k in range(0, len(r), size))
+    cuts.update(range(n_ref, C, size * n_clones))          # the clones interleave: a block of every clone spans size * n_clones columns
+    return subs, is_ref, sorted(cuts)
+
+
 def _cnv_factor_table(chr_start, n_clones=4):
     """k[clone+1, chr]: clone q gains on chr (1+q),(7+q), losses on chr (10+q),(17+q) (1-based); row 0 = reference."""
     n_chr = len(chr_start) - 1

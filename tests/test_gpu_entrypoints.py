@@ -451,3 +451,34 @@ def test_r_shim_driven_from_c(dev):
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     res = subprocess.run([os.path.join(mock, "test_shim"), "gpu"], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and "SHIM_GPU_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+@pytest.mark.parametrize("config", [4, 5])
+def test_bench_group_configs_two_ranks_equal_one_rank(dev, config):
+    """BASELINE configs 4 (i3 HMM at subcluster level) and 5 (median filter) through bench.py --config: two ranks on ONE GPU
+    over gloo, whole subclusters / tiles per rank (sharded.align_to_groups), the i3 (mu, sigma) from two all-reduces of
+    two doubles -- against one rank holding all the cells: the sums of the state calls / of the filtered matrix over the
+    same global cells.  (RCCL on N GPUs is the driver's scaling run.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ICNV_BENCH_ONE_DEVICE="1", ICNV_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    common = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-kernel-timing", "--config", str(config), "--genes", "4000"]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(29541 + config), os.path.join(root, "bench.py"), "--gpus", "2", "--cells", "10000"] + common,
+                         env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--cells", "20000"] + common,
+                         env=dict(os.environ), capture_output=True, text=True, timeout=900, cwd=root)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
+    line = lambda r: json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    a, b = line(two), line(one)
+    assert a["n_gpus"] == 2 and b["n_gpus"] == 1 and a["config"]["cells_total"] == b["config"]["cells_total"] == 20000
+    s2, s1 = sum(a["checksums"]["per_rank"]), sum(b["checksums"]["per_rank"])
+    assert len(a["checksums"]["per_rank"]) == 2 and min(a["checksums"]["per_rank"]) > 0
+    if config == 4:
+        assert abs(s2 - s1) <= 50, (s2, s1)              # state calls: identical but for a decision within 1e-16 of a tie
+        assert s1 > 2 * 4000 * 20000 * 0.9               # i3 states 1..3, most of them neutral (2)
+    else:
+        assert abs(s2 - s1) <= 1e-9 * abs(s1), (s2, s1)  # the reference sums are added in another order: rounding only

@@ -393,3 +393,78 @@ def test_chain2_plan_emulated_smoothing_equals_oracle(layout, monkeypatch):
     want = onp.smooth_by_chromosome(x[:, None], chr_codes, 101)[:, 0]
     assert not np.isnan(got).any(), np.nonzero(np.isnan(got))[0][:10]
     assert np.abs(got - want).max() < 1e-12 * max(1.0, np.abs(want).max())
+
+
+WORKER_GROUPS = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
+import numpy as np, torch, torch.distributed as dist
+import oracle_np as onp
+from infercnv_amd import sharded, synth
+
+class OracleGroupEngine:
+    """The three methods of sharded.DeviceGroupEngine, arithmetic by the NumPy oracle (test-only)."""
+    def __init__(self, chr_codes): self.chr_codes = chr_codes
+    def moments_partial(self, x, ref, phase, mean):
+        v = x[:, np.asarray(ref, dtype=np.int64)].astype(np.longdouble)
+        return (float(v.sum()), float(v.size)) if phase == 0 else (float(((v - np.longdouble(mean)) ** 2).sum()), float(v.size))
+    def viterbi_groups(self, x, chr_start, groups, means, sds, logPi, logDelta):
+        return onp.predict_cnv_on_groups(x, self.chr_codes, groups, means, [np.full(len(means), s) for s in sds], np.exp(logPi), np.exp(logDelta))
+    def median_filter(self, x, chr_start, tiles, window):
+        return onp.apply_median_filtering(x, self.chr_codes, tiles, window)
+
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=2)
+rank = dist.get_rank()
+G, C = 700, 230
+x, cs = synth.make_matrix_np(G, C)
+chr_codes = np.repeat(np.arange(len(cs) - 1), np.diff(cs))
+rng = np.random.default_rng(5)
+perm = rng.permutation(C)
+sizes = [40, 7, 55, 1, 30, 23, 50, 24]                     # subclusters of uneven size, cells scattered over the matrix
+off = np.concatenate([[0], np.cumsum(sizes)])
+groups = [perm[off[i]:off[i + 1]] for i in range(len(sizes))]
+is_ref = [False, False, True, False, False, True, False, False]
+# config 4: i3 at subcluster level -- whole groups per rank, (mu, sigma) by two all-reduces of two doubles
+owned = sharded.assign_groups(sizes, 2)[rank]
+assert sorted(sharded.assign_groups(sizes, 2)[0] + sharded.assign_groups(sizes, 2)[1]) == list(range(len(sizes)))
+cells, local = sharded.gather_groups(groups, owned)
+ref_local = np.concatenate([local[j] for j, gid in enumerate(owned) if is_ref[gid]] or [np.zeros(0, dtype=np.int32)])
+xl = np.ascontiguousarray(x[:, cells])
+hmm = sharded.ShardedGroupHMM(OracleGroupEngine(chr_codes))
+mu, sigma, delta = hmm.i3_params(xl, ref_local, 0.05)
+ref_all = np.concatenate([g for g, r in zip(groups, is_ref) if r])
+wmu, wsigma, wdelta = onp.i3_params(x, ref_all, 0.05)
+assert abs(mu - wmu) < 1e-14 and abs(sigma - wsigma) < 1e-14 and abs(delta - wdelta) < 1e-13, (mu, wmu, sigma, wsigma)
+st = hmm.run_i3(xl, cs, local, ref_local)
+Pi3, d3 = onp.get_HMM_i3(1e-6)
+want = onp.predict_cnv_on_groups(x, chr_codes, groups, np.array([wmu - wdelta, wmu, wmu + wdelta]), [np.full(3, wsigma)] * len(groups), Pi3, d3)
+assert np.array_equal(st, want[:, cells]), (st != want[:, cells]).sum()
+# config 5: the median filter on whole tiles per rank -- no collective
+mf = sharded.ShardedMedianFilter(OracleGroupEngine(chr_codes)).run(xl, cs, local, 7)
+wmf = onp.apply_median_filtering(x, chr_codes, groups, 7)
+assert np.array_equal(mf, wmf[:, cells])
+# contiguous-block groups: cuts moved to group boundaries
+bounds = sharded.align_to_groups(230, 2, off)
+assert bounds[0][1] in off and bounds[0][1] == bounds[1][0]
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_sharded_group_hmm_and_median_filter_two_ranks_gloo(tmp_path):
+    """BASELINE configs 4 and 5 on two ranks (gloo, CPU, oracle-backed engine): whole groups / tiles per rank
+    (assign_groups + gather_groups), the i3 (mu, sigma) from the split-phase moments by two all-reduces of two doubles
+    (SURVEY.md 8e), group HMM states and median-filter output of every rank's cells equal to the one-rank result."""
+    script = tmp_path / "worker_groups.py"
+    script.write_text(WORKER_GROUPS)
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(port), str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
+        assert f"rank {r} ok" in o
