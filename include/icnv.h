@@ -77,7 +77,9 @@ void icnv_shutdown(void);
  * visible device, n: devices 0 .. n-1, 1 (the default): the calling thread's current device.  With more than one device
  * icnv_smooth_chain and icnv_viterbi_cells split the cells into one contiguous block per device (one host thread, one
  * stream per device); the chain's reference statistics (per-gene sums of the reference groups) are added
- * on the host in device order.  The other host-buffer entry points run on the current device.  This is what lets a
+ * on the host in device order.  icnv_viterbi_groups and icnv_median_filter deal WHOLE groups / tiles to the devices
+ * (longest first onto the least loaded one; every worker packs the columns of its groups' cells, no exchange between
+ * devices).  The remaining host-buffer entry points run on the current device.  This is what lets a
  * single R process (infercnv::run() is single-threaded) use the 8 GPUs of a node, each over its own PCIe link.
  * The *_dev entry points are not affected: a device-resident caller (one process per GPU, infercnv_amd/sharded.py)
  * shards by itself. */
@@ -161,6 +163,44 @@ void icnv_chain_end(icnv_chain_t *chain);
  * mean_c max_g x}; threshold "auto" of step 9 is mean(abs(out2)). */
 int icnv_average_bounds(const double *expr, int64_t G, int64_t C, double *out2);
 int icnv_average_bounds_dev(const double *expr, int64_t G, int64_t C, double *out2_host, void *stream);
+
+/* ---- ingest from the raw COUNT matrix: steps 2, 3, 4 of run() in one call ------------------
+ * Replaces require_above_min_mean_expr_cutoff + require_above_min_cells_ref (R/inferCNV_ops.R:2128-2213; run() :560-566),
+ * normalize_counts_by_seq_depth (:3064-3111) and log2xplus1 (:2756-2769).  The counts cross PCIe once as integers --
+ * dense int32 (G x C column-major) or CSC (colptr [C + 1], rowidx / vals [nnz]; 0-based, any order inside a column) --
+ * and the f64 matrix of the KEPT genes (G_out x C) is formed on the device.  Integer sums are exact: the result is bit
+ * for bit what icnv_gene_stats + icnv_select_genes + icnv_normalize_log2 give on the f64 copy of the counts.
+ *   min_mean_expr_cutoff  NaN: no filter; a gene with rowMeans(counts) < cutoff is removed
+ *   min_cells_per_gene    <= 0: no filter; a gene needs counts > 0 in at least that many cells
+ *   normalize_factor      NaN: median(colSums) over the kept genes (the reference's default, normalize_factor = NA)
+ *   keep_idx [G], G_out   the kept genes (ascending, 0-based) and their number; "All genes removed" is an error (:2194)
+ *   expr_out              capacity G x C doubles, filled G_out x C; h2d_bytes (nullable): bytes uploaded */
+typedef struct icnv_counts {
+    const int32_t *dense;    /* dense form, or NULL */
+    const int64_t *colptr;   /* CSC form, or NULL */
+    const int32_t *rowidx;
+    const int32_t *vals;
+    int64_t nnz;             /* CSC: stored entries */
+} icnv_counts;
+int icnv_ingest_counts(const icnv_counts *cnt, int64_t G, int64_t C, double min_mean_expr_cutoff, int32_t min_cells_per_gene,
+                       double normalize_factor, int32_t *keep_idx, int64_t *G_out, double *expr_out, double *factor_used,
+                       int64_t *h2d_bytes);
+/* The same with the count arrays and the output already on the device (keep_idx stays a host array). */
+int icnv_ingest_counts_dev(const icnv_counts *cnt, int64_t G, int64_t C, double min_mean_expr_cutoff, int32_t min_cells_per_gene,
+                           double normalize_factor, int32_t *keep_idx_host, int64_t *G_out, double *expr_out_dev,
+                           double *factor_used, void *stream);
+/* Split phases for a cell-sharded caller (infercnv_amd/sharded.py: ShardedIngest):
+ *   gene_stats   stats2G_dev = [G sums of the counts | G numbers of cells with count > 0] as doubles -> all-reduce(sum)
+ *   select       the filter decision from the all-reduced statistics (host arithmetic, the same on every rank)
+ *   col_sums     colSums over the kept genes (keep_mask_dev: G bytes, 1 = kept)     -> all-gather, median = the factor
+ *   apply        expr_out[j, c] = log2(count[keep[j], c] / col_sum[c] * factor + 1), the reference's operation order */
+int icnv_ingest_gene_stats_dev(const icnv_counts *cnt, int64_t G, int64_t C, double *stats2G_dev, void *stream);
+int icnv_ingest_select(const double *stats2G_host, int64_t G, int64_t C_total, double min_mean_expr_cutoff, int32_t min_cells_per_gene,
+                       int32_t *keep_idx, int64_t *G_out);
+int icnv_ingest_col_sums_dev(const icnv_counts *cnt, int64_t G, int64_t C, const uint8_t *keep_mask_dev, double *col_sums_dev, void *stream);
+int icnv_ingest_apply_dev(const icnv_counts *cnt, int64_t G, int64_t C, const int32_t *keep_idx_dev, int64_t G_out,
+                          const double *col_sums_dev, double factor, int32_t do_normalize, int32_t do_log2, double *expr_out,
+                          void *stream);
 
 /* ---- ingest: steps 3 and 4 of run() (first "next" row) -------- */
 /* colSums(expr.data) per cell (R/inferCNV_ops.R:3089), device pointers. */

@@ -50,6 +50,11 @@ class ChainCfg(ct.Structure):
     ]
 
 
+class Counts(ct.Structure):
+    """icnv_counts of include/icnv.h: the raw count matrix, dense int32 or CSC (pointers: host or device, by entry point)."""
+    _fields_ = [("dense", ct.c_void_p), ("colptr", ct.c_void_p), ("rowidx", ct.c_void_p), ("vals", ct.c_void_p), ("nnz", ct.c_int64)]
+
+
 _vp, _i64, _i32, _dbl = ct.c_void_p, ct.c_int64, ct.c_int32, ct.c_double
 _ip = ct.POINTER(ct.c_int32)
 _dp = ct.POINTER(ct.c_double)
@@ -103,6 +108,14 @@ PROTOTYPES = {
     "icnv_states_to_proxy_dev": (ct.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "icnv_cells_mean_sd_dev": (ct.c_int, [_vp, _i64, _i64, _ip, _i64, _dp, _vp]),
     "icnv_cells_mean_sd": (ct.c_int, [_vp, _i64, _i64, _ip, _i64, _dp]),
+    "icnv_ingest_counts": (ct.c_int, [ct.POINTER(Counts), _i64, _i64, ct.c_double, ct.c_int32, ct.c_double, _ip, ct.POINTER(_i64), _vp,
+                                      _dp, ct.POINTER(_i64)]),
+    "icnv_ingest_counts_dev": (ct.c_int, [ct.POINTER(Counts), _i64, _i64, ct.c_double, ct.c_int32, ct.c_double, _ip, ct.POINTER(_i64),
+                                          _vp, _dp, _vp]),
+    "icnv_ingest_gene_stats_dev": (ct.c_int, [ct.POINTER(Counts), _i64, _i64, _vp, _vp]),
+    "icnv_ingest_select": (ct.c_int, [_dp, _i64, _i64, ct.c_double, ct.c_int32, _ip, ct.POINTER(_i64)]),
+    "icnv_ingest_col_sums_dev": (ct.c_int, [ct.POINTER(Counts), _i64, _i64, _vp, _vp, _vp]),
+    "icnv_ingest_apply_dev": (ct.c_int, [ct.POINTER(Counts), _i64, _i64, _vp, _i64, _vp, ct.c_double, ct.c_int32, ct.c_int32, _vp, _vp]),
     "icnv_cells_moments_partial_dev": (ct.c_int, [_vp, _i64, _i64, _ip, _i64, ct.c_int32, ct.c_double, _dp, _vp]),
     "icnv_median_filter": (ct.c_int, [_vp, _vp, _i64, _i64, _ip, _i32, _ip, _ip, _i32, _i32]),
     "icnv_median_filter_dev": (ct.c_int, [_vp, _vp, _i64, _i64, _ip, _i32, _ip, _ip, _i32, _i32, _vp]),

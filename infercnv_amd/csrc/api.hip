@@ -1291,10 +1291,14 @@ int icnv_viterbi_groups_dev(const double *expr, uint8_t *states, int64_t G, int6
     return launch_broadcast_states(d_gs.as<uint8_t>(), (int32_t)G, C, d_map.as<int32_t>(), states, s);
 }
 
-int icnv_viterbi_groups(const double *expr, uint8_t *states, int64_t G, int64_t C, const int32_t *chr_start,
-                        int32_t n_chr, const int32_t *grp_idx, const int32_t *grp_off, int32_t n_grp, int32_t K,
-                        const double *mean, const double *sd_shared_per_grp, const double *logPi,
-                        const double *logDelta) {
+}  // extern "C"
+// single-device forms of the host-buffer group entry points (the extern "C" ones live in host_path.hip: they deal whole
+// groups / tiles to the devices of icnv_set_devices)
+namespace icnv {
+int viterbi_groups_host_one(const double *expr, uint8_t *states, int64_t G, int64_t C, const int32_t *chr_start,
+                            int32_t n_chr, const int32_t *grp_idx, const int32_t *grp_off, int32_t n_grp, int32_t K,
+                            const double *mean, const double *sd_shared_per_grp, const double *logPi,
+                            const double *logDelta) {
     if (!expr || !states) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
     MatrixLease in;
     DevBuf ds, dn;
@@ -1312,6 +1316,8 @@ int icnv_viterbi_groups(const double *expr, uint8_t *states, int64_t G, int64_t 
     if (bad) ICNV_FAIL(ICNV_ERR_UNDERFLOW, "Problems With Underflow in " + std::to_string(bad) + " sequences");
     return ICNV_OK;
 }
+}  // namespace icnv
+extern "C" {
 
 int icnv_state_consensus_dev(const uint8_t *states, int64_t G, int64_t C, const int32_t *grp_idx,
                              const int32_t *grp_off, int32_t n_grp, uint8_t *consensus, uint8_t *states_out,
@@ -1545,9 +1551,11 @@ int icnv_median_filter_dev(const double *expr_in, double *expr_out, int64_t G, i
                                 window_size, plan9, s);
 }
 
-int icnv_median_filter(const double *expr_in, double *expr_out, int64_t G, int64_t C, const int32_t *chr_start,
-                       int32_t n_chr, const int32_t *tile_idx, const int32_t *tile_off, int32_t n_tiles,
-                       int32_t window_size) {
+}  // extern "C"
+namespace icnv {
+int median_filter_host_one(const double *expr_in, double *expr_out, int64_t G, int64_t C, const int32_t *chr_start,
+                           int32_t n_chr, const int32_t *tile_idx, const int32_t *tile_off, int32_t n_tiles,
+                           int32_t window_size) {
     if (!expr_in || !expr_out) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
     MatrixLease in;
     DevBuf dout;
@@ -1561,5 +1569,4 @@ int icnv_median_filter(const double *expr_in, double *expr_out, int64_t G, int64
     publish_output(expr_out, G * C, std::move(dout));
     return ICNV_OK;
 }
-
-}  // extern "C"
+}  // namespace icnv

@@ -514,4 +514,150 @@ int icnv_viterbi_cells(const double *expr, uint8_t *states, int64_t G, int64_t C
     return ICNV_OK;
 }
 
+// ------------------------------------------------------------------ group HMM and median filter, host buffers
+// Groups (HMM subclusters / samples) and median-filter tiles are independent (R/inferCNV_HMM.R:371, 529-533;
+// R/noise_reduction.R:57-86): with icnv_set_devices(n) whole groups / tiles are dealt to the devices -- longest first onto
+// the least loaded device --, every worker packs the columns of ITS groups' cells from the host matrix, runs the *_dev
+// entry point on its own stream and hands back the columns of those cells.  No exchange between devices.
+namespace {
+struct GroupDeal {
+    std::vector<int32_t> cells;       // global cell ids this device holds, first appearance in its groups' order
+    std::vector<int32_t> idx, off;    // its groups as LOCAL index lists (packed)
+    std::vector<int32_t> gids;        // global ids of its groups, ascending
+};
+void deal_groups(const int32_t *grp_idx, const int32_t *grp_off, int32_t n_grp, int nd, int64_t C, std::vector<GroupDeal> &deal) {
+    deal.assign((size_t)nd, GroupDeal());
+    std::vector<int32_t> order((size_t)n_grp);
+    for (int32_t q = 0; q < n_grp; ++q) order[(size_t)q] = q;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return grp_off[a + 1] - grp_off[a] > grp_off[b + 1] - grp_off[b]; });
+    std::vector<int64_t> load((size_t)nd, 0);
+    for (int32_t q : order) {
+        int best = 0;
+        for (int w = 1; w < nd; ++w)
+            if (load[(size_t)w] < load[(size_t)best]) best = w;
+        deal[(size_t)best].gids.push_back(q);
+        load[(size_t)best] += grp_off[q + 1] - grp_off[q];
+    }
+    std::vector<int32_t> pos((size_t)std::max<int64_t>(C, 1));
+    for (auto &d : deal) {
+        std::sort(d.gids.begin(), d.gids.end());
+        std::fill(pos.begin(), pos.end(), -1);
+        d.off.push_back(0);
+        for (int32_t q : d.gids) {
+            for (int32_t i = grp_off[q]; i < grp_off[q + 1]; ++i) {
+                const int32_t c = grp_idx[i];
+                if (pos[(size_t)c] < 0) { pos[(size_t)c] = (int32_t)d.cells.size(); d.cells.push_back(c); }
+                d.idx.push_back(pos[(size_t)c]);
+            }
+            d.off.push_back((int32_t)d.idx.size());
+        }
+    }
+}
+int check_groups_host(const int32_t *idx, const int32_t *off, int32_t n, int64_t C, const char *what) {
+    if (n < 0 || (n > 0 && (!idx || !off))) ICNV_FAIL(ICNV_ERR_ARG, std::string("bad ") + what);
+    for (int32_t q = 0; q < n; ++q) {
+        if (off[q + 1] < off[q]) ICNV_FAIL(ICNV_ERR_ARG, std::string(what) + " offsets must not decrease");
+        for (int32_t i = off[q]; i < off[q + 1]; ++i)
+            if (idx[i] < 0 || idx[i] >= C) ICNV_FAIL(ICNV_ERR_ARG, std::string(what) + " index out of range");
+    }
+    return ICNV_OK;
+}
+}  // namespace
+
+int icnv_viterbi_groups(const double *expr, uint8_t *states, int64_t G, int64_t C, const int32_t *chr_start, int32_t n_chr,
+                        const int32_t *grp_idx, const int32_t *grp_off, int32_t n_grp, int32_t K, const double *mean,
+                        const double *sd_shared_per_grp, const double *logPi, const double *logDelta) {
+    if (!expr || !states || G < 1 || C < 0) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    const int nd = (int)std::max<int64_t>(1, std::min<int64_t>(g_ndev.load(), n_grp));
+    if (nd == 1) return viterbi_groups_host_one(expr, states, G, C, chr_start, n_chr, grp_idx, grp_off, n_grp, K, mean, sd_shared_per_grp, logPi, logDelta);
+    int rc = check_groups_host(grp_idx, grp_off, n_grp, C, "groups");
+    if (rc) return rc;
+    if (!sd_shared_per_grp) ICNV_FAIL(ICNV_ERR_ARG, "sd_shared_per_grp missing");
+    std::vector<GroupDeal> deal;
+    deal_groups(grp_idx, grp_off, n_grp, nd, C, deal);
+    // a cell listed by several groups takes the states of the LAST of them (as the one-device path and R's loop do)
+    std::vector<int32_t> winner((size_t)std::max<int64_t>(C, 1), -1), dev_of((size_t)n_grp, 0);
+    for (int32_t q = 0; q < n_grp; ++q)
+        for (int32_t i = grp_off[q]; i < grp_off[q + 1]; ++i) winner[(size_t)grp_idx[i]] = q;
+    for (int w = 0; w < nd; ++w)
+        for (int32_t q : deal[(size_t)w].gids) dev_of[(size_t)q] = w;
+    std::memset(states, 0xFF, (size_t)G * (size_t)C);
+    std::atomic<int64_t> bad_total{0};
+    rc = on_devices(nd, [&](int w, hipStream_t s, int rc0) -> int {
+        if (rc0) return rc0;
+        const GroupDeal &d = deal[(size_t)w];
+        const int64_t nc = (int64_t)d.cells.size();
+        if (nc == 0) return ICNV_OK;
+        std::vector<double> xin((size_t)G * (size_t)nc);
+        for (int64_t j = 0; j < nc; ++j) std::memcpy(&xin[(size_t)(j * G)], expr + (int64_t)d.cells[(size_t)j] * G, (size_t)G * sizeof(double));
+        std::vector<double> sd;
+        for (int32_t q : d.gids) sd.push_back(sd_shared_per_grp[q]);
+        DevBuf dx, ds, dn;
+        int r;
+        if ((r = dx.alloc(xin.size() * sizeof(double))) || (r = ds.alloc((size_t)G * (size_t)nc)) || (r = dn.alloc(sizeof(int32_t)))) return r;
+        ICNV_HIP(hipMemcpyAsync(dx.p, xin.data(), xin.size() * sizeof(double), hipMemcpyHostToDevice, s));
+        ICNV_HIP(hipMemsetAsync(dn.p, 0, sizeof(int32_t), s));
+        if ((r = icnv_viterbi_groups_dev(dx.as<double>(), ds.as<uint8_t>(), G, nc, chr_start, n_chr, d.idx.data(), d.off.data(),
+                                         (int32_t)d.gids.size(), K, mean, sd.data(), logPi, logDelta, dn.as<int32_t>(), s)))
+            return r;
+        std::vector<uint8_t> st((size_t)G * (size_t)nc);
+        int32_t bad = 0;
+        ICNV_HIP(hipMemcpyAsync(st.data(), ds.p, st.size(), hipMemcpyDeviceToHost, s));
+        ICNV_HIP(hipMemcpyAsync(&bad, dn.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        ICNV_HIP(hipStreamSynchronize(s));
+        bad_total += bad;
+        for (int64_t j = 0; j < nc; ++j) {
+            const int32_t c = d.cells[(size_t)j];
+            if (dev_of[(size_t)winner[(size_t)c]] == w)   // (the winning group is this device's last group holding the cell)
+                std::memcpy(states + (int64_t)c * G, &st[(size_t)(j * G)], (size_t)G);
+        }
+        return ICNV_OK;
+    });
+    if (rc) return rc;
+    if (bad_total.load())
+        ICNV_FAIL(ICNV_ERR_UNDERFLOW, "Problems With Underflow in " + std::to_string(bad_total.load()) + " sequences");
+    return ICNV_OK;
+}
+
+int icnv_median_filter(const double *expr_in, double *expr_out, int64_t G, int64_t C, const int32_t *chr_start, int32_t n_chr,
+                       const int32_t *tile_idx, const int32_t *tile_off, int32_t n_tiles, int32_t window_size) {
+    if (!expr_in || !expr_out || G < 1 || C < 0) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    const int nd = (int)std::max<int64_t>(1, std::min<int64_t>(g_ndev.load(), n_tiles));
+    bool disjoint = true;   // tiles that share a cell keep the one-device path (its in-place order of the tiles)
+    if (nd > 1) {
+        if (int rc = check_groups_host(tile_idx, tile_off, n_tiles, C, "tiles")) return rc;
+        std::vector<char> seen((size_t)std::max<int64_t>(C, 1), 0);
+        for (int32_t i = 0; i < tile_off[n_tiles] && disjoint; ++i) {
+            if (seen[(size_t)tile_idx[i]]) disjoint = false;
+            seen[(size_t)tile_idx[i]] = 1;
+        }
+    }
+    if (nd == 1 || !disjoint) return median_filter_host_one(expr_in, expr_out, G, C, chr_start, n_chr, tile_idx, tile_off, n_tiles, window_size);
+    std::vector<GroupDeal> deal;
+    deal_groups(tile_idx, tile_off, n_tiles, nd, C, deal);
+    std::vector<char> covered((size_t)std::max<int64_t>(C, 1), 0);
+    for (int32_t i = 0; i < tile_off[n_tiles]; ++i) covered[(size_t)tile_idx[i]] = 1;
+    for (int64_t c = 0; c < C; ++c)   // cells in no tile pass through (R/noise_reduction.R:57-86 touches the tiles only)
+        if (!covered[(size_t)c] && expr_out != expr_in) std::memcpy(expr_out + c * G, expr_in + c * G, (size_t)G * sizeof(double));
+    return on_devices(nd, [&](int w, hipStream_t s, int rc0) -> int {
+        if (rc0) return rc0;
+        const GroupDeal &d = deal[(size_t)w];
+        const int64_t nc = (int64_t)d.cells.size();
+        if (nc == 0) return ICNV_OK;
+        std::vector<double> xin((size_t)G * (size_t)nc);
+        for (int64_t j = 0; j < nc; ++j) std::memcpy(&xin[(size_t)(j * G)], expr_in + (int64_t)d.cells[(size_t)j] * G, (size_t)G * sizeof(double));
+        DevBuf dx, dout;
+        int r;
+        if ((r = dx.alloc(xin.size() * sizeof(double))) || (r = dout.alloc(xin.size() * sizeof(double)))) return r;
+        ICNV_HIP(hipMemcpyAsync(dx.p, xin.data(), xin.size() * sizeof(double), hipMemcpyHostToDevice, s));
+        if ((r = icnv_median_filter_dev(dx.as<double>(), dout.as<double>(), G, nc, chr_start, n_chr, d.idx.data(), d.off.data(),
+                                        (int32_t)d.gids.size(), window_size, s)))
+            return r;
+        ICNV_HIP(hipMemcpyAsync(xin.data(), dout.p, xin.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        ICNV_HIP(hipStreamSynchronize(s));
+        for (int64_t j = 0; j < nc; ++j) std::memcpy(expr_out + (int64_t)d.cells[(size_t)j] * G, &xin[(size_t)(j * G)], (size_t)G * sizeof(double));
+        return ICNV_OK;
+    });
+}
+
 }  // extern "C"

@@ -54,6 +54,11 @@ struct MatrixLease {
 };
 int acquire_input(const double *host, int64_t n_doubles, hipStream_t s, MatrixLease &lease);
 void publish_output(const double *host, int64_t n_doubles, DevBuf &&buf);
+int viterbi_groups_host_one(const double *expr, uint8_t *states, int64_t G, int64_t C, const int32_t *chr_start, int32_t n_chr,
+                            const int32_t *grp_idx, const int32_t *grp_off, int32_t n_grp, int32_t K, const double *mean,
+                            const double *sd_shared_per_grp, const double *logPi, const double *logDelta);
+int median_filter_host_one(const double *expr_in, double *expr_out, int64_t G, int64_t C, const int32_t *chr_start, int32_t n_chr,
+                           const int32_t *tile_idx, const int32_t *tile_off, int32_t n_tiles, int32_t window_size);
 bool residency_release_idle();   // host_path.hip: hand the idle resident matrices of this pool domain back to the pool
 void viterbi_release_contexts();  // api.hip: device tables / pinned words / events of the per-device Viterbi state
 

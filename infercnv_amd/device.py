@@ -271,6 +271,82 @@ def cells_mean_sd(x, cell_idx):
     return out[0], out[1]
 
 
+# ------------------------------------------------------------------ ingest from integer counts (steps 2-4)
+class DeviceCounts:
+    """The raw count matrix on the device: dense int32 (C, G) tensor -- row-major (C, G) is R's column-major G x C -- or
+    CSC (colptr int64 [C + 1], rowidx int32 [nnz], vals int32 [nnz]) tensors."""
+
+    def __init__(self, G, C, dense=None, colptr=None, rowidx=None, vals=None):
+        self.G, self.C = int(G), int(C)
+        self.t = (dense, colptr, rowidx, vals)          # keeps the tensors alive
+        if dense is not None:
+            assert dense.is_cuda and dense.dtype == torch.int32 and dense.is_contiguous() and tuple(dense.shape) == (C, G)
+            self.c = _lib.Counts(dense.data_ptr(), None, None, None, 0)
+        else:
+            assert colptr.dtype == torch.int64 and rowidx.dtype == torch.int32 and vals.dtype == torch.int32
+            assert colptr.numel() == C + 1 and rowidx.numel() == vals.numel()
+            self.c = _lib.Counts(None, colptr.data_ptr(), rowidx.data_ptr() if rowidx.numel() else None,
+                                 vals.data_ptr() if vals.numel() else None, int(vals.numel()))
+
+    @property
+    def device(self):
+        return next(t for t in self.t if t is not None).device
+
+
+def ingest_gene_stats(counts):
+    """[G sums | G counts of cells with a positive count] as one float64 tensor (all-reduce it in a sharded run)."""
+    L = _lib.load()
+    out = torch.empty(2 * counts.G, dtype=torch.float64, device=counts.device)
+    check(L.icnv_ingest_gene_stats_dev(ct.byref(counts.c), counts.G, counts.C, _ptr(out), _stream()))
+    return out
+
+
+def ingest_select(stats_host, G, C_total, min_mean_expr_cutoff=None, min_cells_per_gene=0):
+    """Step 2's decision from the gene statistics (R/inferCNV_ops.R:2128-2213) -> kept gene indices."""
+    L = _lib.load()
+    st, sp = f64(stats_host)
+    keep = np.empty(G, dtype=np.int32)
+    n = ct.c_int64()
+    check(L.icnv_ingest_select(sp, G, int(C_total), float("nan") if min_mean_expr_cutoff is None else float(min_mean_expr_cutoff),
+                               int(min_cells_per_gene), keep.ctypes.data_as(ct.POINTER(ct.c_int32)), ct.byref(n)))
+    return keep[:n.value].copy()
+
+
+def ingest_col_sums(counts, keep_idx):
+    L = _lib.load()
+    mask = torch.zeros(counts.G, dtype=torch.uint8, device=counts.device)
+    mask[torch.as_tensor(np.asarray(keep_idx, dtype=np.int64), device=counts.device)] = 1
+    out = torch.empty(counts.C, dtype=torch.float64, device=counts.device)
+    check(L.icnv_ingest_col_sums_dev(ct.byref(counts.c), counts.G, counts.C, _ptr(mask), _ptr(out), _stream()))
+    torch.cuda.current_stream().synchronize()           # (the mask is released when this returns)
+    return out
+
+
+def ingest_apply(counts, keep_idx, col_sums, factor):
+    """log2(count / colSum * factor + 1) of the kept genes -> (C, G_out) float64 tensor."""
+    L = _lib.load()
+    keep = torch.as_tensor(np.asarray(keep_idx, dtype=np.int32), device=counts.device)
+    out = torch.empty((counts.C, int(keep.numel())), dtype=torch.float64, device=counts.device)
+    check(L.icnv_ingest_apply_dev(ct.byref(counts.c), counts.G, counts.C, _ptr(keep), int(keep.numel()), _ptr(col_sums), float(factor),
+                                  1, 1, _ptr(out), _stream()))
+    torch.cuda.current_stream().synchronize()
+    return out
+
+
+def ingest_counts(counts, min_mean_expr_cutoff=None, min_cells_per_gene=0, normalize_factor=None):
+    """Steps 2-4 of run() in one call on one device -> (expr (C, G_out) float64, kept gene indices, factor used)."""
+    L = _lib.load()
+    keep = np.empty(counts.G, dtype=np.int32)
+    n, used = ct.c_int64(), ct.c_double()
+    buf = torch.empty((counts.C * counts.G,), dtype=torch.float64, device=counts.device)
+    check(L.icnv_ingest_counts_dev(ct.byref(counts.c), counts.G, counts.C,
+                                   float("nan") if min_mean_expr_cutoff is None else float(min_mean_expr_cutoff), int(min_cells_per_gene),
+                                   float("nan") if normalize_factor is None else float(normalize_factor),
+                                   keep.ctypes.data_as(ct.POINTER(ct.c_int32)), ct.byref(n), _ptr(buf), ct.byref(used), _stream()))
+    g_out = n.value
+    return buf[: counts.C * g_out].view(counts.C, g_out), keep[:g_out].copy(), used.value
+
+
 def cells_moments_partial(x, cell_idx, phase, mean=0.0):
     """One rank's share of the split-phase mean / sd over all values of the listed cells (icnv_cells_moments_partial_dev):
     phase 0 -> (sum of values, number of values), phase 1 -> (sum of (x - mean)^2, number of values)."""

@@ -64,6 +64,19 @@ def _gene_stats(infercnv_obj):
     return sums, nnz
 
 
+def _keep_gene_rows(infercnv_obj, keep):
+    """The per-gene slots of remove_genes (R/inferCNV.R:445-457) restricted to rows `keep`; expr.data is the caller's."""
+    new = infercnv_obj.copy()
+    if infercnv_obj.count_data is not None:
+        new.count_data = np.asarray(infercnv_obj.count_data)[keep]
+    go = infercnv_obj.gene_order
+    new.gene_order = type(go)(np.asarray(go.chr)[keep], None if go.start is None else np.asarray(go.start)[keep],
+                              None if go.stop is None else np.asarray(go.stop)[keep])
+    if infercnv_obj.gene_names is not None:
+        new.gene_names = np.asarray(infercnv_obj.gene_names)[keep]
+    return new
+
+
 def remove_genes(infercnv_obj: InfercnvObject, gene_indices_to_remove) -> InfercnvObject:
     """remove_genes (R/inferCNV.R:445-457): drops the rows (0-based here) from expr.data (on the device),
     count.data and gene_order."""
@@ -78,15 +91,8 @@ def remove_genes(infercnv_obj: InfercnvObject, gene_indices_to_remove) -> Inferc
     out = np.empty((keep.size, C), dtype=np.float64, order="F")
     check(L.icnv_select_genes(x.ctypes.data_as(ct.c_void_p), G, C, keep.ctypes.data_as(ct.POINTER(ct.c_int32)), keep.size,
                               out.ctypes.data_as(ct.c_void_p)))
-    new = infercnv_obj.copy()
+    new = _keep_gene_rows(infercnv_obj, keep)
     new.expr_data = out
-    if infercnv_obj.count_data is not None:
-        new.count_data = np.asarray(infercnv_obj.count_data)[keep]
-    go = infercnv_obj.gene_order
-    new.gene_order = type(go)(np.asarray(go.chr)[keep], None if go.start is None else np.asarray(go.start)[keep],
-                              None if go.stop is None else np.asarray(go.stop)[keep])
-    if infercnv_obj.gene_names is not None:
-        new.gene_names = np.asarray(infercnv_obj.gene_names)[keep]
     new.validate()
     return new
 
@@ -132,6 +138,53 @@ def log2xplus1(infercnv_obj: InfercnvObject) -> InfercnvObject:
     """R/inferCNV_ops.R:2756-2769."""
     hs = log2xplus1(infercnv_obj.hspike) if infercnv_obj.hspike is not None else None
     return _with_expr(infercnv_obj, _normalize_log2(infercnv_obj, None, False, True), hs)
+
+
+def ingest_counts(infercnv_obj: InfercnvObject, min_mean_expr_cutoff=None, min_cells_per_gene=0, normalize_factor=None,
+                  sparse=None):
+    """Steps 2, 3, 4 of run() in ONE call from the integer count matrix (`infercnv_obj.expr_data` holding raw counts --
+    a dense integer array or a scipy.sparse matrix): require_above_min_mean_expr_cutoff + require_above_min_cells_ref
+    (R/inferCNV_ops.R:2128-2213), normalize_counts_by_seq_depth (:3064-3111), log2xplus1 (:2756-2769).  The counts are
+    uploaded once as int32 (dense) or CSC; the result equals the four step functions applied in run()'s order, bit for
+    bit.  Returns (object with the log-scale matrix of the kept genes, bytes uploaded)."""
+    L = _lib.load()
+    x = infercnv_obj.expr_data
+    is_sparse = hasattr(x, "tocsc")
+    if sparse is None:
+        sparse = is_sparse
+    G, C = x.shape
+    if sparse:
+        m = x.tocsc() if is_sparse else __import__("scipy.sparse", fromlist=["csc_matrix"]).csc_matrix(np.asarray(x))
+        m.sum_duplicates()
+        vals = np.ascontiguousarray(m.data)
+        if not np.array_equal(vals, np.rint(vals)):
+            raise ValueError("ingest_counts wants integer counts")
+        colptr = np.ascontiguousarray(m.indptr, dtype=np.int64)
+        rowidx = np.ascontiguousarray(m.indices, dtype=np.int32)
+        vals = np.ascontiguousarray(vals, dtype=np.int32)
+        cnt = _lib.Counts(None, colptr.ctypes.data, rowidx.ctypes.data, vals.ctypes.data, int(vals.size))
+        keepalive = (colptr, rowidx, vals)
+    else:
+        xd = np.asarray(x.todense() if is_sparse else x)
+        if not np.array_equal(xd, np.rint(xd)):
+            raise ValueError("ingest_counts wants integer counts")
+        dense = np.asfortranarray(xd, dtype=np.int32)
+        cnt = _lib.Counts(dense.ctypes.data, None, None, None, 0)
+        keepalive = (dense,)
+    keep = np.empty(G, dtype=np.int32)
+    n, used, up = ct.c_int64(), ct.c_double(), ct.c_int64()
+    out = np.empty((G, C), dtype=np.float64, order="F")
+    check(L.icnv_ingest_counts(ct.byref(cnt), G, C, float("nan") if min_mean_expr_cutoff is None else float(min_mean_expr_cutoff),
+                               int(min_cells_per_gene), float("nan") if normalize_factor is None else float(normalize_factor),
+                               keep.ctypes.data_as(ct.POINTER(ct.c_int32)), ct.byref(n), out.ctypes.data_as(ct.c_void_p), ct.byref(used),
+                               ct.byref(up)))
+    del keepalive
+    g_out = n.value
+    keep = keep[:g_out]
+    expr = np.asfortranarray(out.ravel(order="F")[: g_out * C].reshape((g_out, C), order="F"))
+    new = _keep_gene_rows(infercnv_obj, keep)
+    new.expr_data = expr
+    return new, up.value
 
 
 # ------------------------------------------------------------------ step 8 / 12

@@ -210,3 +210,53 @@ class ShardedMedianFilter:
 
     def run(self, x_local, chr_start, tiles_local, window_size=7):
         return self.engine.median_filter(x_local, chr_start, tiles_local, window_size)
+
+
+class ShardedIngest:
+    """Steps 2-4 of run() from integer counts on cell shards.  Exchange steps:
+        all-reduce(sum) of [G gene sums | G numbers of expressing cells]   -> the filter decision, identical on every rank
+        all-gather of the ranks' column sums over the kept genes          -> median(colSums) = the normalisation factor
+    `engine` has gene_stats(counts) -> 2G vector, col_sums(counts, keep) -> C_local vector and apply(counts, keep, col_sums,
+    factor) -> matrix; the default one runs on libicnv_hip.so (device.ingest_*)."""
+
+    def __init__(self, engine=None, process_group=None):
+        self.engine = engine
+        self.pg = process_group
+
+    def run(self, counts_local, C_total, min_mean_expr_cutoff=None, min_cells_per_gene=0, normalize_factor=None):
+        import torch
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1
+        eng = self.engine
+        if eng is None:
+            from . import device as eng_mod
+            class _Dev:
+                gene_stats = staticmethod(eng_mod.ingest_gene_stats)
+                col_sums = staticmethod(eng_mod.ingest_col_sums)
+                apply = staticmethod(eng_mod.ingest_apply)
+                select = staticmethod(eng_mod.ingest_select)
+            eng = _Dev
+        stats = eng.gene_stats(counts_local)
+        if multi:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.pg)
+        stats_h = stats.cpu().numpy() if hasattr(stats, "cpu") else np.asarray(stats)
+        G = stats_h.size // 2
+        keep = eng.select(stats_h, G, C_total, min_mean_expr_cutoff, min_cells_per_gene)
+        cs = eng.col_sums(counts_local, keep)
+        factor = normalize_factor
+        if factor is None:
+            if multi:
+                world = dist.get_world_size(self.pg)
+                n_local = torch.tensor([cs.numel()], dtype=torch.int64, device=cs.device)
+                sizes = [torch.zeros_like(n_local) for _ in range(world)]
+                dist.all_gather(sizes, n_local, group=self.pg)
+                nmax = int(max(int(v.item()) for v in sizes))
+                pad = torch.zeros(nmax, dtype=cs.dtype, device=cs.device)
+                pad[: cs.numel()] = cs
+                parts = [torch.zeros_like(pad) for _ in range(world)]
+                dist.all_gather(parts, pad, group=self.pg)
+                allcs = np.concatenate([p[: int(n.item())].cpu().numpy() for p, n in zip(parts, sizes)])
+            else:
+                allcs = cs.cpu().numpy() if hasattr(cs, "cpu") else np.asarray(cs)
+            factor = float(np.median(allcs))              # stats::median: mean of the two middle values for an even count
+        return eng.apply(counts_local, keep, cs, factor), keep, factor

@@ -365,6 +365,31 @@ for resident in (0, 1, 1):
     check(L.icnv_viterbi_cells(vp(one[1]), vp(st1), *args))
     assert np.array_equal(st1, st3) and np.array_equal(st1, one[2])
 check(L.icnv_residency(0))
+# group HMM and median filter: whole groups / tiles per device (uneven groups, scattered cells, a cell in two groups --
+# the later group wins --, cells in no group), identical to the one-device result
+rng = np.random.default_rng(3)
+perm = rng.permutation(C)
+sizes = [60, 5, 41, 1, 33, 80, 17]
+offs = np.concatenate([[0], np.cumsum(sizes)])
+groups = [perm[offs[i]:offs[i + 1]].astype(np.int32) for i in range(len(sizes))]
+groups_dup = groups[:-1] + [np.concatenate([groups[-1], groups[0][:3]]).astype(np.int32)]
+from infercnv_amd._lib import pack_groups
+def run_groups(gr):
+    idx, off = pack_groups(gr); idx, ip = i32(idx); off, op = i32(off)
+    sds, sdp = f64(np.linspace(0.06, 0.2, len(gr)))
+    st = np.empty((G, C), dtype=np.uint8, order="F")
+    check(L.icnv_viterbi_groups(vp(one[1]), vp(st), G, C, csp, csa.size - 1, ip, op, len(gr), 6, mp, sdp, lp.ctypes.data_as(ct.POINTER(ct.c_double)), ldp))
+    return st
+def run_median(gr):
+    idx, off = pack_groups(gr); idx, ip = i32(idx); off, op = i32(off)
+    o = np.empty_like(x)
+    check(L.icnv_median_filter(vp(one[0]), vp(o), G, C, csp, csa.size - 1, ip, op, len(gr), 7))
+    return o
+check(L.icnv_set_devices(3)); g3, g3d, m3 = run_groups(groups), run_groups(groups_dup), run_median(groups)
+check(L.icnv_set_devices(1)); g1, g1d, m1 = run_groups(groups), run_groups(groups_dup), run_median(groups)
+assert np.array_equal(g3, g1) and np.array_equal(g3d, g1d) and np.array_equal(m3, m1)
+assert (g1[:, perm[offs[-1]:]] == 255).all() and (g1[:, perm[:offs[-1]]] != 255).all()
+assert np.array_equal(m1[:, perm[offs[-1]:]], one[0][:, perm[offs[-1]:]]) and not np.array_equal(m1, one[0])
 # errors surface from the workers: an empty reference group, an even window
 check(L.icnv_set_devices(3))
 out = np.empty_like(x)
@@ -482,3 +507,54 @@ def test_bench_group_configs_two_ranks_equal_one_rank(dev, config):
         assert s1 > 2 * 4000 * 20000 * 0.9               # i3 states 1..3, most of them neutral (2)
     else:
         assert abs(s2 - s1) <= 1e-9 * abs(s1), (s2, s1)  # the reference sums are added in another order: rounding only
+
+
+def test_ingest_from_integer_counts_equals_the_step_functions(dev, run_inputs, golden_dir):
+    """steps 2, 3, 4 of run() in ONE call from integer counts uploaded once -- dense int32 and CSC --
+    against the four step functions (gene filters, depth normalisation, log2(x + 1)) on the f64 copy: kept genes, the
+    normalisation factor and every value bit for bit; bytes crossing PCIe reported.  (a) the reference's golden object
+    (@count.data, int32) replayed to @expr.data; (b) example/run.R's matrix rounded to counts (9 939 x 184, 59 % zeros)
+    with run()'s filters (cutoff = 1, min_cells_per_gene = 3, R/inferCNV_ops.R:560-566)."""
+    import scipy.sparse as sp
+    from infercnv_amd import GeneOrder, InfercnvObject, ops
+    # (a) golden object
+    d = np.load(os.path.join(golden_dir, "infercnv_object_example.npz"))
+    counts = d["count_data"].astype(np.int64)
+    levels = d["chr_levels"][d["chr_codes"]]
+    mk = lambda m: InfercnvObject(expr_data=m, gene_order=GeneOrder(chr=levels),
+                                  reference_grouped_cell_indices={"normal": d["ref_normal"]},
+                                  observation_grouped_cell_indices={"tumor": d["obs_tumor"]})
+    o4, up = ops.ingest_counts(mk(counts))
+    assert up == counts.size * 4 and o4.expr_data.shape == counts.shape
+    want = onp.log2xplus1(onp.normalize_counts_by_seq_depth(counts.astype(np.float64)))
+    assert np.abs(o4.expr_data - want).max() < 1e-12
+    final = ops.hip_smooth_chain(o4)
+    assert np.abs(final.expr_data - d["expr_data"]).max() < 1e-10          # @count.data -> @expr.data, the reference's own pair
+    # (b) run()'s step 2-4 on a count matrix with real sparsity
+    x = np.rint(run_inputs["counts"])
+    obj = InfercnvObject(expr_data=x, count_data=x, gene_order=GeneOrder(chr=run_inputs["chr"]),
+                         reference_grouped_cell_indices=run_inputs["refs"], observation_grouped_cell_indices=run_inputs["obs"])
+    o = ops.require_above_min_mean_expr_cutoff(obj, 1)
+    o = ops.require_above_min_cells_ref(o, 3)
+    steps = ops.log2xplus1(ops.normalize_counts_by_seq_depth(o))
+    dense, up_dense = ops.ingest_counts(obj, 1, 3)
+    csc, up_csc = ops.ingest_counts(InfercnvObject(expr_data=sp.csc_matrix(x), gene_order=obj.gene_order,
+                                                  reference_grouped_cell_indices=run_inputs["refs"],
+                                                  observation_grouped_cell_indices=run_inputs["obs"]), 1, 3)
+    for got in (dense, csc):
+        assert got.expr_data.shape == steps.expr_data.shape and 3000 < got.expr_data.shape[0] < x.shape[0]
+        np.testing.assert_array_equal(got.expr_data, steps.expr_data)
+        np.testing.assert_array_equal(np.asarray(got.gene_order.chr), np.asarray(steps.gene_order.chr))
+    nnz = int((x != 0).sum())
+    assert up_dense == x.size * 4 and up_csc == (x.shape[1] + 1) * 8 + nnz * 8
+    print(f"[ingest] H2D bytes: f64 matrix {x.size * 8}, int32 dense {up_dense}, CSC {up_csc} ({nnz} stored entries)")
+    # every gene removed is the reference's stop(998)
+    with pytest.raises(Exception, match="All genes removed"):
+        ops.ingest_counts(obj, 1e9, 0)
+    # device-resident flavour, explicit factor, no filters
+    t = torch.from_numpy(np.ascontiguousarray(x.T.astype(np.int32))).cuda()
+    e, keep, used = dev.ingest_counts(dev.DeviceCounts(x.shape[0], x.shape[1], dense=t), normalize_factor=1e5)
+    assert used == 1e5 and keep.size == x.shape[0]
+    cs = x.sum(axis=0)
+    nz = cs > 0
+    assert np.abs(to_host(e)[:, nz] - np.log2(x[:, nz] / cs[nz] * 1e5 + 1.0)).max() < 1e-11

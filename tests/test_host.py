@@ -468,3 +468,64 @@ def test_sharded_group_hmm_and_median_filter_two_ranks_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
         assert f"rank {r} ok" in o
+
+
+WORKER_INGEST = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
+import numpy as np, torch, torch.distributed as dist
+import oracle_np as onp
+from infercnv_amd import sharded
+
+class NumpyIngestEngine:
+    """The four methods ShardedIngest needs, in NumPy on integer counts (test-only stand-in for device.ingest_*)."""
+    @staticmethod
+    def gene_stats(c): return torch.from_numpy(np.concatenate([c.sum(axis=1), (c > 0).sum(axis=1)]).astype(np.float64))
+    @staticmethod
+    def select(st, G, C_total, cutoff, min_cells):
+        keep = np.ones(G, dtype=bool)
+        if cutoff is not None: keep &= ~(st[:G] / C_total < cutoff)
+        if min_cells > 0: keep &= st[G:] >= min_cells
+        return np.nonzero(keep)[0].astype(np.int32)
+    @staticmethod
+    def col_sums(c, keep): return torch.from_numpy(c[keep].sum(axis=0).astype(np.float64))
+    @staticmethod
+    def apply(c, keep, cs, factor): return np.log2(c[keep].astype(np.float64) / cs.numpy() * factor + 1.0)
+
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=2)
+rank = dist.get_rank()
+rng = np.random.default_rng(9)
+G, C = 500, 91                                              # odd number of cells: the ranks' blocks differ in size
+counts = rng.poisson(rng.gamma(0.3, 4.0, size=(G, 1)), size=(G, C)).astype(np.int64)
+c0, c1 = sharded.shard_bounds(C, 2, rank)
+out, keep, factor = sharded.ShardedIngest(NumpyIngestEngine).run(counts[:, c0:c1], C, 0.5, 3)
+f = counts.astype(np.float64)
+drop = onp.below_min_mean_expr_cutoff(f, 0.5)
+k = np.setdiff1d(np.arange(G), drop)
+k = k[onp.genes_passing_min_cells(f[k], 3)]
+assert np.array_equal(keep, k) and 50 < k.size < G
+want = onp.log2xplus1(onp.normalize_counts_by_seq_depth(f[k]))
+assert factor == float(np.median(f[k].sum(axis=0)))
+assert np.abs(out - want[:, c0:c1]).max() < 1e-12
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_sharded_ingest_two_ranks_gloo(tmp_path):
+    """Steps 2-4 from integer counts on two ranks (gloo, CPU, NumPy engine): gene statistics all-reduced, the filter
+    decision identical on both ranks, column sums all-gathered for the global median (ranks of different size) -- the
+    rank's block equals the one-rank result of the reference's four step functions (oracle)."""
+    script = tmp_path / "worker_ingest.py"
+    script.write_text(WORKER_INGEST)
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(port), str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
+        assert f"rank {r} ok" in o
