@@ -345,6 +345,13 @@ int icnv_cells_mean_sd(const double *expr, int64_t G, int64_t C, const int32_t *
 int icnv_cells_moments_partial_dev(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx, int64_t n_cells,
                                    int32_t phase, double mean, double *out3_host, void *stream);
 
+/* Values of the matrix at element offsets g + G c (host list in, host values out): the draws of
+ * sample(expr_vals, size = ncells, replace = TRUE) in get_hspike_cnv_mean_sd_trend_by_num_cells_fit
+ * (R/inferCNV_HMM.R:164) taken from the resident hidden-spike matrix; the index stream itself is R's RNG, restated on the
+ * host (infercnv_amd/r_rng.py). */
+int icnv_gather_values_dev(const double *expr, int64_t n_elements, const int64_t *offsets_host, int64_t n, double *out_host, void *stream);
+int icnv_gather_values(const double *expr, int64_t G, int64_t C, const int64_t *offsets, int64_t n, double *out);
+
 /* ---- 2-D median denoise -------------------------------------------------- */
 /* apply_median_filtering / .median_filter (R/noise_reduction.R:43-113): for
  * every (tile, chromosome) block -- tile = one tumour subcluster or one whole

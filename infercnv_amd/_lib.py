@@ -116,6 +116,8 @@ PROTOTYPES = {
     "icnv_ingest_select": (ct.c_int, [_dp, _i64, _i64, ct.c_double, ct.c_int32, _ip, ct.POINTER(_i64)]),
     "icnv_ingest_col_sums_dev": (ct.c_int, [ct.POINTER(Counts), _i64, _i64, _vp, _vp, _vp]),
     "icnv_ingest_apply_dev": (ct.c_int, [ct.POINTER(Counts), _i64, _i64, _vp, _i64, _vp, ct.c_double, ct.c_int32, ct.c_int32, _vp, _vp]),
+    "icnv_gather_values_dev": (ct.c_int, [_vp, _i64, ct.POINTER(_i64), _i64, _dp, _vp]),
+    "icnv_gather_values": (ct.c_int, [_vp, _i64, _i64, ct.POINTER(_i64), _i64, _dp]),
     "icnv_cells_moments_partial_dev": (ct.c_int, [_vp, _i64, _i64, _ip, _i64, ct.c_int32, ct.c_double, _dp, _vp]),
     "icnv_median_filter": (ct.c_int, [_vp, _vp, _i64, _i64, _ip, _i32, _ip, _ip, _i32, _i32]),
     "icnv_median_filter_dev": (ct.c_int, [_vp, _vp, _i64, _i64, _ip, _i32, _ip, _ip, _i32, _i32, _vp]),

@@ -828,6 +828,29 @@ int icnv_select_genes(const double *expr_in, int64_t G_in, int64_t C, const int3
     return ICNV_OK;
 }
 
+// values of the matrix at arbitrary element offsets (g + G c): the draws of the spike-in resampling fit
+int icnv_gather_values_dev(const double *expr, int64_t n_elements, const int64_t *offsets_host, int64_t n, double *out_host, void *stream) {
+    if (!expr || n < 0 || (n > 0 && (!offsets_host || !out_host))) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    for (int64_t i = 0; i < n; ++i)
+        if (offsets_host[i] < 0 || offsets_host[i] >= n_elements) ICNV_FAIL(ICNV_ERR_ARG, "element offset out of range");
+    if (n == 0) return ICNV_OK;
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf doff, dout;
+    int rc;
+    if ((rc = upload(doff, offsets_host, (size_t)n, s)) || (rc = dout.alloc((size_t)n * sizeof(double)))) return rc;
+    if ((rc = launch_gather_values(expr, doff.as<int64_t>(), n, dout.as<double>(), s))) return rc;
+    ICNV_HIP(hipMemcpyAsync(out_host, dout.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    ICNV_HIP(hipStreamSynchronize(s));
+    return ICNV_OK;
+}
+int icnv_gather_values(const double *expr, int64_t G, int64_t C, const int64_t *offsets, int64_t n, double *out) {
+    if (!expr || G < 1 || C < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    MatrixLease in;
+    int rc;
+    if ((rc = acquire_input(expr, G * C, nullptr, in))) return rc;
+    return icnv_gather_values_dev(in.dev, G * C, offsets, n, out, nullptr);
+}
+
 int icnv_block_mean_sd_dev(const double *expr, int64_t G, int64_t C, const int32_t *gene_idx, int64_t n_genes,
                            const int32_t *cell_idx, int64_t n_cells, double *out2_host, void *stream) {
     if (!expr || !out2_host || G < 1 || G > 0x7fffffff || n_cells < 1 || n_cells > 0x7fffffff || !cell_idx)

@@ -1,6 +1,8 @@
 // Gene filters of the ingest (steps 2: require_above_min_mean_expr_cutoff / require_above_min_cells_ref,
 // R/inferCNV_ops.R:2128-2213), row selection (remove_genes) and the mean / sd of a gene x cell block
 // (get_spike_dists, R/inferCNV_HMM.R:15-99) for gfx950.  All HBM-bound streaming work.
+#include <algorithm>
+
 #include "icnv_internal.h"
 
 namespace icnv {
@@ -74,7 +76,20 @@ __global__ void block_cell_reduce_kernel(const double *__restrict__ x, int G, co
     if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// out[i] = x[offsets[i]]: the resampling of the hidden spike-in's residuals (R/inferCNV_HMM.R:164) on the resident matrix
+__global__ void gather_values_kernel(const double *__restrict__ x, const int64_t *__restrict__ offsets, int64_t n, double *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = x[offsets[i]];
+}
+
 }  // namespace
+
+int launch_gather_values(const double *x, const int64_t *offsets_dev, int64_t n, double *out, hipStream_t stream) {
+    if (n <= 0) return ICNV_OK;
+    KernelTimer kt("gather_values", stream);
+    hipLaunchKernelGGL(gather_values_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, stream, x, offsets_dev, n, out);
+    ICNV_HIP(hipGetLastError());
+    return ICNV_OK;
+}
 
 int gene_stats_nsplit(int32_t G, int64_t C) {
     const int tiles = (G + GS_TILE - 1) / GS_TILE;

@@ -81,6 +81,74 @@ def get_spike_dists(hspike_obj: InfercnvObject, chr_info=HSPIKE_CHR_INFO):
     return out
 
 
+def _hspike_level_offsets(hspike_obj, chr_info=HSPIKE_CHR_INFO):
+    """.get_gene_expr_by_cnv (R/inferCNV_HMM.R:45-68) as element offsets: level -> int64 offsets (g + G c) of
+    c(spike.expr.data[chr_gene_idx, ]) for every fake chromosome of the level, concatenated in chr_info order."""
+    G = hspike_obj.expr_data.shape[0]
+    cells = np.concatenate([np.asarray(v, dtype=np.int64) for v in hspike_obj.observation_grouped_cell_indices.values()])
+    chrs = np.asarray(hspike_obj.gene_order.chr)
+    out = {}
+    for name, cnv in chr_info:
+        genes = np.nonzero(chrs == name)[0].astype(np.int64)
+        block = (genes[:, None] + G * cells[None, :]).ravel(order="F")       # column-major flatten: genes fastest
+        key = "cnv:%g" % cnv
+        out[key] = np.concatenate([out[key], block]) if key in out else block
+    return out
+
+
+def get_hspike_cnv_mean_sd_trend_by_num_cells_fit(hspike_obj: InfercnvObject, seed=None, rng=None, chr_info=HSPIKE_CHR_INFO,
+                                                  nrounds=100, max_cells=100):
+    """get_hspike_cnv_mean_sd_trend_by_num_cells_fit (R/inferCNV_HMM.R:154-212): for every CNV level of the hidden
+    spike-in and every ncells in 1..100, `vals <- replicate(100, sample(expr_vals, size = ncells, replace = TRUE))`,
+    `sd(rowMeans(vals))` (for ncells = 1 `vals` is a vector, `means` a single number and its sd NA), then
+    `lm(log(sd) ~ log(num_cells))` per level.  Reference behaviour kept: rowMeans runs over the ROUNDS, not over the cells
+    of a round, so every sd estimates sigma / sqrt(100) and the fitted slope is ~0.
+
+    The draws are R's own stream -- `seed` as in set.seed(seed) right before the call (infercnv_amd/r_rng.py); the
+    reference never seeds, so an unseeded run of it is not reproducible either.  The 3 M sampled residuals are gathered
+    from the hidden-spike matrix on the device in one call (icnv_gather_values); sd and the 99-point regressions are
+    host arithmetic in R's precision (long double accumulation).  Returns {level: (intercept, slope)} -- what
+    `.get_state_emission_params` predicts from -- plus the sd vectors under the key "_sd"."""
+    from .r_rng import RRandom
+    if rng is None:
+        if seed is None:
+            raise ValueError("give the RNG state: seed (as in set.seed(seed)) or an RRandom")
+        rng = RRandom(seed)
+    offs = _hspike_level_offsets(hspike_obj, chr_info)
+    draws = {}                                                   # (nrounds, max_cells: the reference's constants, :160-162)
+    for level, o in offs.items():                                # names(gene_expr_by_cnv) order; ncells 1..100; round; draw
+        if o.size == 0:
+            raise ValueError(f"no hidden-spike values for {level}")
+        draws[level] = o[rng.sample_replace(o.size, nrounds * (max_cells * (max_cells + 1) // 2))]
+    allo = np.ascontiguousarray(np.concatenate(list(draws.values())), dtype=np.int64)
+    vals = np.empty(allo.size, dtype=np.float64)
+    L = _lib.load()
+    x = np.asfortranarray(hspike_obj.expr_data, dtype=np.float64)
+    check(L.icnv_gather_values(x.ctypes.data_as(ct.c_void_p), x.shape[0], x.shape[1], allo.ctypes.data_as(ct.POINTER(ct.c_int64)),
+                               allo.size, vals.ctypes.data_as(ct.POINTER(ct.c_double))))
+    LD = np.longdouble
+    fits, sds_all, pos = {}, {}, 0
+    for level in offs:
+        sds = np.full(max_cells, np.nan)
+        for ncells in range(1, max_cells + 1):
+            v = vals[pos:pos + nrounds * ncells].reshape(nrounds, ncells)   # round r, draw i  (R: vals[i, r])
+            pos += nrounds * ncells
+            if ncells == 1:
+                continue                                          # means is one number: sd(means) is NA
+            means = np.asarray(v.astype(LD).sum(axis=0) / LD(nrounds), dtype=np.float64)    # rowMeans(vals): over the rounds
+            m = means.astype(LD).sum() / LD(ncells)
+            m = m + (means.astype(LD) - m).sum() / LD(ncells)                              # mean(): one refinement pass
+            sds[ncells - 1] = float(np.sqrt(((means.astype(LD) - m) ** 2).sum() / LD(ncells - 1)))
+        ok = ~np.isnan(sds)                                       # lm drops the NA row (na.action = na.omit)
+        lx, ly = np.log(np.arange(1, max_cells + 1, dtype=np.float64)[ok]).astype(LD), np.log(sds[ok]).astype(LD)
+        mx, my = lx.mean(), ly.mean()
+        slope = ((lx - mx) * (ly - my)).sum() / ((lx - mx) ** 2).sum()
+        fits[level] = (float(my - slope * mx), float(slope))
+        sds_all[level] = sds
+    fits["_sd"] = sds_all
+    return fits
+
+
 def _log(a):
     with np.errstate(divide="ignore"):
         return np.log(np.asarray(a, dtype=np.float64))

@@ -663,3 +663,98 @@ def cell_distances(expr, cells):
         diff = x[i + 1:] - x[i]
         d[i, i + 1:] = np.sqrt((diff * diff).sum(axis=1))
     return d + d.T
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# R's RNG and the sd-vs-cell-count resampling fit (R/inferCNV_HMM.R:154-212), restated independently of
+# infercnv_amd/r_rng.py: the Mersenne-Twister recurrence is written out here (Matsumoto & Nishimura's genrand_int32, what
+# base R's MT_genrand runs), the R-specific parts -- seed scrambling, rbits / rejection sampling, sample(), replicate,
+# rowMeans, sd, lm -- as scalar loops.
+class RMersenne:
+    """`set.seed(seed)` of base R (src/main/RNG.c: RNG_Init + FixupSeeds), Mersenne-Twister, one output at a time."""
+    N, M = 624, 397
+
+    def __init__(self, seed):
+        s = int(seed) & 0xFFFFFFFF
+        for _ in range(50):
+            s = (69069 * s + 1) & 0xFFFFFFFF
+        seedvec = []
+        for _ in range(625):
+            s = (69069 * s + 1) & 0xFFFFFFFF
+            seedvec.append(s)
+        self.mt = np.array(seedvec[1:], dtype=np.uint64)     # seedvec[0] is mti, set to N by FixupSeeds
+        self.mti = self.N
+        self.buf = np.zeros(0, dtype=np.uint64)
+        self.pos = 0
+
+    def _regenerate(self):
+        mt, N, M = self.mt, self.N, self.M
+        UP, LO, A = np.uint64(0x80000000), np.uint64(0x7FFFFFFF), np.uint64(0x9908B0DF)
+        def twist(u, v):
+            y = (u & UP) | (v & LO)
+            return (y >> np.uint64(1)) ^ np.where((y & np.uint64(1)) != 0, A, np.uint64(0))
+        # the recurrence reads words it has already renewed once kk >= N - M: three dependent segments
+        mt[0:N - M] = mt[M:N] ^ twist(mt[0:N - M], mt[1:N - M + 1])
+        for a in range(N - M, N - 1, N - M):                  # segments of at most N - M words, each reading renewed ones
+            b = min(a + (N - M), N - 1)
+            mt[a:b] = mt[a - (N - M):b - (N - M)] ^ twist(mt[a:b], mt[a + 1:b + 1])
+        y = (mt[N - 1] & UP) | (mt[0] & LO)
+        mt[N - 1] = mt[M - 1] ^ (y >> np.uint64(1)) ^ (A if (int(y) & 1) else np.uint64(0))
+        y = mt.copy()
+        y ^= y >> np.uint64(11)
+        y ^= (y << np.uint64(7)) & np.uint64(0x9D2C5680)
+        y ^= (y << np.uint64(15)) & np.uint64(0xEFC60000)
+        y ^= y >> np.uint64(18)
+        self.buf = y & np.uint64(0xFFFFFFFF)
+        self.pos = 0
+
+    def genrand_int32(self):
+        if self.pos >= self.buf.size:
+            self._regenerate()
+        v = int(self.buf[self.pos])
+        self.pos += 1
+        return v
+
+    def unif_rand(self):
+        u = self.genrand_int32() * 2.3283064365386963e-10
+        if u <= 0.0:
+            return 0.5 * 2.328306437080797e-10
+        if 1.0 - u <= 0.0:
+            return 1.0 - 0.5 * 2.328306437080797e-10
+        return u
+
+    def unif_index(self, dn):
+        """R_unif_index, sample.kind = "Rejection" (src/main/RNG.c)."""
+        if dn <= 0:
+            return 0
+        bits = int(np.ceil(np.log2(dn)))
+        while True:
+            v, n = 0, 0
+            while n <= bits:
+                v = 65536 * v + int(np.floor(self.unif_rand() * 65536))
+                n += 16
+            if bits < 64:
+                v &= (1 << bits) - 1
+            if v < dn:
+                return v
+
+
+def hspike_sd_trend_fit(expr_vals_by_level, seed, nrounds=100, max_cells=100):
+    """R/inferCNV_HMM.R:154-212 on {level: vector of residuals}: returns {level: (sds[max_cells], (intercept, slope))}."""
+    rng = RMersenne(seed)
+    out = {}
+    for level, ev in expr_vals_by_level.items():
+        ev = np.asarray(ev, dtype=np.float64)
+        sds = np.full(max_cells, np.nan)
+        for ncells in range(1, max_cells + 1):
+            vals = np.empty((ncells, nrounds))                 # replicate(): one column per round
+            for r in range(nrounds):
+                for i in range(ncells):
+                    vals[i, r] = ev[rng.unif_index(ev.size)]   # sample(expr_vals, size = ncells, replace = TRUE)
+            if ncells > 1:
+                sds[ncells - 1] = float(r_sd(r_row_means(vals), axis=0))
+        ok = ~np.isnan(sds)                                     # lm(): na.omit
+        X = np.stack([np.ones(int(ok.sum())), np.log(np.arange(1, max_cells + 1)[ok])], axis=1)
+        coef, *_ = np.linalg.lstsq(X, np.log(sds[ok]), rcond=None)
+        out[level] = (sds, (float(coef[0]), float(coef[1])))
+    return out

@@ -558,3 +558,43 @@ def test_ingest_from_integer_counts_equals_the_step_functions(dev, run_inputs, g
     cs = x.sum(axis=0)
     nz = cs > 0
     assert np.abs(to_host(e)[:, nz] - np.log2(x[:, nz] / cs[nz] * 1e5 + 1.0)).max() < 1e-11
+
+
+def test_hspike_sd_trend_resampling_fit_vs_oracle(dev):
+    """SURVEY.md 8f #3, second half: get_hspike_cnv_mean_sd_trend_by_num_cells_fit (R/inferCNV_HMM.R:154-212) -- the
+    sample() draws are R's stream (set.seed(seed); tests/test_oracle.py pins it), the sampled residuals are gathered from
+    the hidden-spike matrix on the device, sd / lm on the host -- against the oracle's scalar restatement: the sd of every
+    (level, ncells), NA for ncells = 1, intercept and slope of the six regressions.  A hidden spike-in with the reference's
+    eleven fake chromosomes (.get_hspike_chr_info), levels with one and with six chromosomes."""
+    from infercnv_amd import GeneOrder, InfercnvObject, hmm
+    rng = np.random.default_rng(12)
+    sizes = [40, 33, 51, 37, 46, 35, 42, 39, 44, 31, 48]
+    chr_names = np.concatenate([[name] * n for (name, _), n in zip(hmm.HSPIKE_CHR_INFO, sizes)])
+    G, C = chr_names.size, 70
+    level_of = {name: cnv for name, cnv in hmm.HSPIKE_CHR_INFO}
+    x = np.stack([rng.normal(level_of[c] if level_of[c] > 0.02 else 0.05, 0.15 + 0.05 * level_of[c], size=C) for c in chr_names])
+    spike = {"spike_a": np.arange(20, 45, dtype=np.int32), "spike_b": np.array([69, 3, 50, 51, 7], dtype=np.int32)}
+    hs = InfercnvObject(expr_data=x, gene_order=GeneOrder(chr=chr_names),
+                        reference_grouped_cell_indices={"normal": np.arange(0, 3, dtype=np.int32)},
+                        observation_grouped_cell_indices=spike)
+    import inspect
+    sig = inspect.signature(hmm.get_hspike_cnv_mean_sd_trend_by_num_cells_fit)
+    assert sig.parameters["nrounds"].default == 100 and sig.parameters["max_cells"].default == 100    # the reference's constants
+    got = hmm.get_hspike_cnv_mean_sd_trend_by_num_cells_fit(hs, seed=2024, max_cells=30)
+    cells = np.concatenate(list(spike.values()))
+    ev = {}
+    for name, cnv in hmm.HSPIKE_CHR_INFO:                       # .get_gene_expr_by_cnv (:45-68)
+        key = "cnv:%g" % cnv
+        block = x[np.nonzero(chr_names == name)[0]][:, cells].ravel(order="F")
+        ev[key] = np.concatenate([ev[key], block]) if key in ev else block
+    assert list(ev) == ["cnv:1", "cnv:0.01", "cnv:0.5", "cnv:1.5", "cnv:2", "cnv:3"]
+    want = onp.hspike_sd_trend_fit(ev, 2024, max_cells=30)
+    for level in ev:
+        sds, (b0, b1) = want[level]
+        assert np.isnan(got["_sd"][level][0]) and np.isnan(sds[0])
+        assert np.abs(got["_sd"][level][1:] - sds[1:]).max() < 1e-14
+        assert abs(got[level][0] - b0) < 1e-11 and abs(got[level][1] - b1) < 1e-11
+        # every sd estimates sigma / sqrt(nrounds): the slope is ~0 (the reference's rowMeans runs over the rounds)
+        assert abs(got[level][1]) < 0.2 and abs(np.exp(got[level][0]) / (np.std(ev[level]) / 10.0) - 1.0) < 0.35
+    # the fit feeds .get_state_emission_params (R/inferCNV_HMM.R:586-614) as before
+    assert hmm._group_sd(25, {k: {"mean": 1.0, "sd": 0.2} for k in hmm.CNV_LEVELS}, {k: got[k] for k in hmm.CNV_LEVELS}) > 0

@@ -373,3 +373,26 @@ def test_exp2_lean():
         ulp = np.spacing(float(want)) if float(want) > 2.3e-308 else 5e-324
         worst = max(worst, float(abs(mp.mpf(float(gi)) - want)) / ulp)
     assert worst <= 1.0, worst
+
+
+def test_r_rng_restatements_reproduce_known_r_outputs():
+    """R's default stream (Mersenne-Twister seeded by set.seed, rejection sampling of sample(); base R, outside
+    /root/reference) as restated twice -- infercnv_amd/r_rng.py on NumPy's MT19937 bit generator, oracle_np.RMersenne with
+    the recurrence written out -- against outputs of R >= 3.6 that are common knowledge: set.seed(42); runif(3) and the
+    seeds 1 and 123; set.seed(123); sample(1:100, 5) = 31 79 51 14 67; set.seed(42); sample(1:10) =
+    1 5 10 8 2 4 6 9 7 3; set.seed(1); sample(1:10) = 9 4 7 1 2 5 3 10 6 8.  Both restatements give one stream, also when
+    populations of different size (one, two draws per attempt) follow each other."""
+    from infercnv_amd.r_rng import RRandom
+    known = {42: [0.9148060, 0.9370754, 0.2861395], 1: [0.2655087, 0.3721239, 0.5728534], 123: [0.2875775, 0.7883051, 0.4089769]}
+    for seed, want in known.items():
+        assert np.abs(RRandom(seed).unif_rand(3) - want).max() < 5e-8
+        o = onp.RMersenne(seed)
+        assert np.abs(np.array([o.unif_rand() for _ in range(3)]) - want).max() < 5e-8
+    assert list(RRandom(123).sample_replace(100, 5) + 1) == [31, 79, 51, 14, 67]      # (the first five draws happen to be distinct)
+    assert list(RRandom(42).sample_perm(10) + 1) == [1, 5, 10, 8, 2, 4, 6, 9, 7, 3]
+    assert list(RRandom(1).sample_perm(10) + 1) == [9, 4, 7, 1, 2, 5, 3, 10, 6, 8]
+    a, b = onp.RMersenne(7), RRandom(7)
+    want = [a.unif_index(37) for _ in range(3000)] + [a.unif_index(70000) for _ in range(1500)] + [a.unif_index(1000003) for _ in range(800)]
+    got = np.concatenate([b.unif_index(37, 3000), b.unif_index(70000, 1500), b.unif_index(1000003, 800)])
+    assert np.array_equal(np.array(want), got)
+    assert abs(a.unif_rand() - b.unif_rand(1)[0]) == 0.0                              # and both stand at the same place afterwards
