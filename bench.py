@@ -26,8 +26,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy ceiling
-STREAM_1R2W_GBS = 5300.0     # what a plain grid-stride kernel gets for the fused pass's traffic mix (one matrix read, two
-                             # written; scripts/ubench/stream_1r2w.hip on MI355X: 5.2-5.3 TB/s with or without nt hints)
+def _stream_ceiling():
+    """What a plain grid-stride kernel gets for the fused pass's traffic mix (one matrix read, two written): the best
+    "1r2w" line of profiles/ubench_stream_1r2w.txt, the tracked output of scripts/ubench/stream_1r2w.hip on MI355X
+    (scripts/refresh_profiles.sh refreshes it); 5300 GB/s -- the value measured in rounds 2 and 3 -- if the file is absent."""
+    best = None
+    try:
+        for line in open(os.path.join(ROOT, "profiles", "ubench_stream_1r2w.txt")):
+            if line.startswith("1r2w") and "TB/s" in line:
+                v = float(line.split()[-2]) * 1000.0
+                best = v if best is None else max(best, v)
+    except Exception:
+        pass
+    return (best, "profiles/ubench_stream_1r2w.txt") if best else (5300.0, "constant (profiles/ubench_stream_1r2w.txt absent)")
+
+
+STREAM_1R2W_GBS, STREAM_1R2W_SOURCE = _stream_ceiling()
 FP64_VECTOR_PEAK_TF = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 
 
@@ -399,7 +413,7 @@ def main():
             roof["chain_apply"]["hbm_traffic"] = {"bytes_per_launch": moved, "source": "3 x 8 B per gene*cell",
                                                   "achieved": moved / t / 1e9, "unit": "GB/s",
                                                   "frac_of_peak": moved / t / 1e9 / HBM_PEAK_GBS,
-                                                  "stream_1r2w": STREAM_1R2W_GBS,
+                                                  "stream_1r2w": STREAM_1R2W_GBS, "stream_1r2w_source": STREAM_1R2W_SOURCE,
                                                   "frac_of_stream_1r2w": moved / t / 1e9 / STREAM_1R2W_GBS}
         traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(traffic_file) and G == 10000 and C_local == 50000:   # counters were collected on this shape
@@ -431,6 +445,11 @@ def main():
             # largest on this box (the pass and the Viterbi are within 5 % of each other)
             "roofline_fused_smooth_pass": roof.get("chain_apply"),
             "roofline_by_kernel": roof,
+            # the whole step against the same roofline: algorithmic bytes of the pass (16 B per gene*cell) and of the Viterbi (9 B)
+            "roofline_step": {"bound": "hbm", "algorithmic_bytes_per_step": (16 + 9) * G * C_local,
+                              "achieved": (16 + 9) * G * C_local / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": (16 + 9) * G * C_local / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "ms_outside_kernels": ms_per_step - sum(v["ms_per_step"] for v in kernels.values()) if kernels else None},
             "kernels": kernels,
         }
         if checksums is not None:

@@ -209,6 +209,26 @@ def smooth_window(data, window_length):
     return out
 
 
+def smooth_window_na(col, window_length):
+    """.smooth_helper on ONE cell's chromosome with missing values (R/inferCNV_ops.R:2487-2489, 2529): the NAs are taken
+    out, the shortened sequence is smoothed as if the genes either side of a gap were neighbours, and the NAs are put back
+    at their positions.  run() never reaches this (its chain input is log2(x + 1) of counts); restated so that the
+    library's own policy for non-finite input -- which is NOT this one, see tests/test_gpu_parity.py -- can be stated
+    against it."""
+    col = np.asarray(col, dtype=np.float64)
+    nas = np.isnan(col)
+    out = col.copy()
+    if (~nas).any():
+        out[~nas] = smooth_window(col[~nas][:, None], window_length)[:, 0]
+    return out
+
+
+def center_columns_na(expr):
+    """.center_columns with method "median": median(x, na.rm = TRUE) per cell, NAs stay NA (R/inferCNV_ops.R:2098)."""
+    expr = np.asarray(expr, dtype=np.float64)
+    return expr - np.nanmedian(expr, axis=0)[None, :]
+
+
 def chr_segments(chr_codes):
     """Order of first appearance, like unique(gene_order$chr); returns a list of
     index arrays (which(chr == c)) -- genes of one chr need not be contiguous

@@ -1193,3 +1193,47 @@ def test_chain2_opt_in_kernels_vs_oracle(dev, monkeypatch, case):
     ms, n = dev.timing_get("chain2_apply")
     dev.timing_enable(False)
     assert n >= 1, "the chain2 kernels did not run"
+
+
+def test_chain_missing_values_policy_against_the_reference_semantics(dev):
+    """What happens to NA / NaN in the chain, stated against the reference.  R: `.smooth_helper` strips a cell's NAs,
+    smooths the shortened sequence and re-inserts them (R/inferCNV_ops.R:2487-2489, 2529); `median(x, na.rm = TRUE)`
+    centres on the values present (:2098); the NA itself stays NA through every step.  run() cannot produce one (its
+    chain input is log2(x + 1) of counts), and the library does NOT restate that path.  Its policy, asserted here:
+      * a cell WITHOUT a NaN is untouched by NaNs elsewhere in the matrix (same values as the oracle on the clean data),
+        as long as the NaN is not in a reference cell (there it makes that gene's reference mean NaN, as rowMeans does);
+      * inside the affected cell, stand-alone smoothing spreads the NaN over its half window on that chromosome
+        (R: only the NA position stays NA, its neighbours are smoothed over the gap) -- every other chromosome of the cell
+        equals the reference's result;
+      * with step 9 in the chain the NaN is clamped to the threshold (v_min / v_max return the number): the cell comes out
+        finite where R keeps an NA."""
+    from infercnv_amd import synth
+    G, C = 1500, 24
+    x, cs = synth.make_matrix_np(G, C)
+    x = x - 1.5
+    refs = [np.arange(0, 4, dtype=np.int32)]
+    bad_cell, bad_gene = 9, 400
+    xn = x.copy()
+    xn[bad_gene, bad_cell] = np.nan
+    chr_codes = np.repeat(np.arange(len(cs) - 1), np.diff(cs))
+    k = int(chr_codes[bad_gene])
+    # stand-alone smoothing (step 10)
+    got = to_host(dev.smooth_chain(to_dev(xn), cs, refs, stage_mask=0x04)[0])
+    clean = np.delete(np.arange(C), bad_cell)
+    want_clean = oc.smooth_by_chromosome(x, cs, 101)
+    assert np.abs(got[:, clean] - want_clean[:, clean]).max() < 1e-11
+    r_col = np.concatenate([onp.smooth_window_na(xn[cs[j]:cs[j + 1], bad_cell], 101) for j in range(len(cs) - 1)])
+    other = chr_codes != k
+    assert np.abs(got[other, bad_cell] - r_col[other]).max() < 1e-11            # other chromosomes of the cell: the reference's values
+    assert np.isnan(r_col).sum() == 1 and np.isnan(r_col[bad_gene])             # R: exactly the NA position stays NA
+    lib_nan = np.nonzero(np.isnan(got[:, bad_cell]))[0]
+    assert lib_nan.min() >= max(cs[k], bad_gene - 50) and lib_nan.max() <= min(cs[k + 1] - 1, bad_gene + 50) and bad_gene in lib_nan
+    # stand-alone median centring (step 11): R centres the cell on its present values and keeps the NA
+    got11 = to_host(dev.smooth_chain(to_dev(xn), cs, refs, stage_mask=0x08)[0])
+    assert np.abs(got11[:, clean] - onp.center_columns_na(xn)[:, clean]).max() == 0.0
+    assert np.isfinite(got11[np.arange(G) != bad_gene, bad_cell]).all()          # the cell terminates and stays finite elsewhere
+    # the full chain: step 9 clamps the NaN to the threshold -> finite output where R has an NA
+    out, pre = dev.smooth_chain(to_dev(xn), cs, refs, want_pre_denoise=True)
+    assert np.isfinite(to_host(pre)).all() and np.isfinite(to_host(out)).all()
+    want_pre = oc.smooth_chain(x, cs, refs, want_pre_denoise=True)[1]
+    assert np.abs(to_host(pre)[:, clean] - want_pre[:, clean]).max() < 1e-11
