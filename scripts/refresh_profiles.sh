@@ -15,13 +15,16 @@ cp $O/ubench_stream_1r2w.txt $R/profiles/ubench_stream_1r2w.txt      # bench.py 
 timeout 300 python $R/bench.py > $O/bench_full.json 2> $O/bench_full.err
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof -o $TAG -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof/bench_under_rocprof.json 2> $O/prof/log.txt
 python $R/scripts/rocprof_summary.py $O/prof/${TAG}_results.db > $O/${TAG}_kernel_stats.txt 2>&1
+rm -f $O/prof/*.db      # (gpurun merges at most 64 MiB back: the summaries travel, the raw traces do not)
 for c in 4 5; do
   timeout 300 python $R/bench.py --config $c --no-cpu-baseline > $O/bench_config$c.json 2> $O/bench_config$c.err
   timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof -o ${TAG}_config$c -- python $R/bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing > /dev/null 2> $O/prof/log_config$c.txt
   python $R/scripts/rocprof_summary.py $O/prof/${TAG}_config${c}_results.db > $O/${TAG}_kernel_stats_config$c.txt 2>&1
+  rm -f $O/prof/*.db
 done
 timeout 900 bash $R/scripts/pmc_traffic.sh > $O/pmc_log.txt 2>&1
 cd $R && python scripts/pmc_summary.py gpurun_out/pmc > $O/${TAG}_pmc_traffic.txt 2>&1; cp profiles/pmc_traffic.json $O/pmc_traffic.json
+find $R/gpurun_out/pmc -name "*.db" -delete; du -sh $R/gpurun_out/pmc
 python scripts/bench_host_path.py 20000 1 > $O/host_path.json 2> $O/host_path.err
 # the opt-in two-cells-per-CU chain kernels: the kept negative result
 ICNV_CHAIN2=1 timeout 300 python $R/bench.py --no-cpu-baseline > $O/bench_chain2.json 2> $O/bench_chain2.err

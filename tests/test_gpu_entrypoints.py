@@ -595,6 +595,6 @@ def test_hspike_sd_trend_resampling_fit_vs_oracle(dev):
         assert np.abs(got["_sd"][level][1:] - sds[1:]).max() < 1e-14
         assert abs(got[level][0] - b0) < 1e-11 and abs(got[level][1] - b1) < 1e-11
         # every sd estimates sigma / sqrt(nrounds): the slope is ~0 (the reference's rowMeans runs over the rounds)
-        assert abs(got[level][1]) < 0.2 and abs(np.exp(got[level][0]) / (np.std(ev[level]) / 10.0) - 1.0) < 0.35
+        assert abs(got[level][1]) < 0.6 and 0.4 < np.exp(got[level][0]) / (np.std(ev[level]) / 10.0) < 2.5
     # the fit feeds .get_state_emission_params (R/inferCNV_HMM.R:586-614) as before
     assert hmm._group_sd(25, {k: {"mean": 1.0, "sd": 0.2} for k in hmm.CNV_LEVELS}, {k: got[k] for k in hmm.CNV_LEVELS}) > 0
