@@ -28,8 +28,8 @@
 // comparison  nu_k + b  vs  nu_i1 + a  (row i1 keeps itself: b - a is far outside the band):
 // 2 K + 5 (K - 1) operations instead of 4 K^2.  Back-pointers shrink to K bits + i1 (uint16).
 //
-// Mapping: persistent workgroups of 16 wavefronts (the table fills most of the CU's LDS), every
-// wavefront pulls (chromosome, 64-column block) tasks, longest chromosomes first, one lane per
+// Mapping: persistent workgroups of 16 wavefronts -- four per SIMD -- (the table fills most of the CU's LDS),
+// every wavefront pulls (chromosome, 64-column block) tasks, longest chromosomes first, one lane per
 // sequence as in the exact kernel.
 #include <algorithm>
 #include <cstring>
@@ -45,11 +45,16 @@ namespace icnv {
 namespace {
 
 // Launch geometry and chunk sizes (measured choices; experiments with other values are built as replacement translation
-// units by scripts/build_variant.sh, never by -D switches on this file):
-//   512 threads = 2 wavefronts per SIMD measured fastest (256: 5.2 ms, 384: 4.2, 512: 3.65, 640: 4.6, 768: 4.6, 1024: 6.7):
-//   fewer column streams per XCD (their lines survive in the 4 MiB L2) and no register spills
-constexpr int FAST_NT = 512;
-constexpr int FAST_TG = 32;   // traceback group: 2 x 32 back-pointer lines in flight per wavefront
+// units by scripts/viterbi_variants.py / scripts/build_variant.sh, never by -D switches on this file).
+// Round 3: 1024 threads = FOUR wavefronts per SIMD at <= 128 registers.  Rounds 1-2 ran 512 threads (2 per SIMD, 256
+// registers): with the scheduler free to request the fifteen coefficient gathers of several genes at once the gene loop
+// needs ~250 registers, and every larger workgroup spilled (768 threads: 3.0-3.3 ms against 2.32).  The register-lean gene
+// step below (bookkeeping first, scores gathered and consumed in two batches behind fake dependences, the launch
+// descriptor re-read from the kernel-argument segment instead of living in ~60 scalar registers that spill into VGPR lanes)
+// fits 128 registers without scratch in the gene loop: 512 threads 2.47 ms (the serialisation costs when only two
+// wavefronts hide it), 768 threads 2.22, 1024 threads 2.19 ms -- the vector and the LDS pipe are then both ~70 % busy.
+constexpr int FAST_NT = 1024;
+constexpr int FAST_TG = 8;    // traceback group of the non-uniform-alignment walk: 2 x 8 back-pointer lines in flight (registers)
 constexpr int FAST_TB = 16;   // genes per block of the uniform-alignment traceback (16: 2.54 ms, 32: 2.58, 64: 2.61)
 constexpr int FAST_CH = 8;    // genes per observation chunk: 64 bytes per lane and request
 constexpr int NCF = EMIS_DEG + 1;
@@ -131,7 +136,23 @@ __device__ inline uint32_t near_top_bits<3>(const double (&e)[3], double t2) {
     return b;
 }
 template <int K>
-__global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbiArgs A) {
+__global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbiArgs A_in) {
+    // The descriptor (~60 dwords) is read from the kernel-argument segment where it is used (scalar loads) instead of living
+    // in scalar registers for the whole launch: held, it does not fit next to the loop state, the allocator parks it in
+    // VGPR lanes / scratch and the gene loop reloads a wave-uniform double per gene.
+    (void)A_in;
+    typedef const FastViterbiArgs __attribute__((address_space(4))) *ArgsK;
+    ArgsK ap = (ArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+#define A (*ap)
+#define ARGS_HERE()                                                                                      \
+    do {                                                                                                 \
+        unsigned long long ap_bits_ = (unsigned long long)ap;                                            \
+        const unsigned ap_lo_ = __builtin_amdgcn_readfirstlane((unsigned)ap_bits_);                       \
+        const unsigned ap_hi_ = __builtin_amdgcn_readfirstlane((unsigned)(ap_bits_ >> 32));               \
+        ap_bits_ = ((unsigned long long)ap_hi_ << 32) | ap_lo_;                                           \
+        asm volatile("" : "+s"(ap_bits_));                                                                \
+        ap = (ArgsK)ap_bits_;                                                                             \
+    } while (0)
     extern __shared__ __attribute__((aligned(16))) double tab[];
     {
         const int n_dbl = SEG_DOUBLES + A.n_int * rec_doubles(K);
@@ -146,6 +167,7 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
     const int64_t n_tasks = ncg * A.n_chr;
 
     for (;;) {
+        ARGS_HERE();
         int task = 0;
         if (lane == 0) task = atomicAdd(A.task_counter, 1);
         task = __builtin_amdgcn_readfirstlane(task);
@@ -170,6 +192,8 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         const double thr = 4.0 * np1 * (A.eps + 0x1.8p-51 * B);
         const double ab = A.a - A.b;      // off-diagonal minus diagonal log transition
         const double t2 = -ab - thr;
+        const double x_hi_s = A.x_hi, x_lo_s = A.x_lo, cell_lo_s = A.cell_lo, inv_wc_s = A.inv_wc;
+        const int n_cells_m1_s = A.n_cells_m1;
 
         double nu[K];
         uint64_t seqflag = 0;   // lanes with an observation the table cannot score: the whole sequence goes to the exact kernel
@@ -179,11 +203,11 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         constexpr int REC = rec_doubles(K);
         auto locate = [&](double xv, int &idx, double &tn) {
             // clamp into the table's domain; an observation the clamp changes (NaN included) flags its sequence
-            const double xs = max_raw_s(min_raw_s(xv, A.x_hi), A.x_lo);
+            const double xs = max_raw_s(min_raw_s(xv, x_hi_s), x_lo_s);
             seqflag |= __builtin_amdgcn_ballot_w64(!(xs == xv));
             // segment (which state means lie below xs) from the lookup cells: at most one mean per cell
-            int ci = (int)((xs - A.cell_lo) * A.inv_wc);
-            ci = ci > A.n_cells_m1 ? A.n_cells_m1 : ci;
+            int ci = (int)((xs - cell_lo_s) * inv_wc_s);
+            ci = ci > n_cells_m1_s ? n_cells_m1_s : ci;
             const double2 cl = *reinterpret_cast<const double2 *>(tab + CELL_OFF + 2 * ci);   // boundary, {seg_below, pad}
             const int seg = (int)(uint32_t)__double_as_longlong(cl.y) + ((xs >= cl.x) ? 1 : 0);
             const double2 sg = *reinterpret_cast<const double2 *>(tab + 4 * seg);           // lo, inv_w
@@ -217,33 +241,38 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         // if the off-diagonal candidate wins -- the best predecessor leads the second best by more than thr as well
         // (exactly one state has nu~_k >= m1 - thr, i.e. e_k >= -(a - b) - thr).  The comparisons leave wave masks;
         // their combination is scalar work.
-        auto step = [&](const double (&sc)[K]) -> uint32_t {
+        //
+        // One gene, register-lean (four wavefronts per SIMD: <= 128 registers): the bookkeeping that needs no score -- the
+        // candidates e_k, the keep bits, the near-top word -- runs first, then the K - 1 score polynomials are gathered and
+        // consumed in two batches (states 1-2, states 3-5), every score folded into its row of the recurrence as soon as it
+        // exists.  Fake dependences (empty asm) keep batch B's gathers behind batch A's arithmetic and a gene behind its
+        // predecessor: left to itself the scheduler requests all fifteen gathers of several genes at once (60 registers
+        // per gene) -- the right thing with 256 registers, spills with 168 or 128.
+        auto gene = [&](double xv, int i) {
+            asm volatile("" : "+v"(xv) : "v"(nu[K - 1]));      // this gene starts when the previous one's last row is done
+            double tn;
+            int idx;
+            locate(xv, idx, tn);
             double m1 = nu[0];
 #pragma unroll
             for (int k = 1; k < K; ++k) m1 = max_raw(m1, nu[k]);
             const double c = m1 + ab;
             uint32_t sb = 0;
             double e[K];
-            double amin = 0.0;   // min_k |e_k|: one comparison for "some row's decision lies inside the band"
+            double amin = 0.0;
 #pragma unroll
             for (int k = K - 1; k >= 0; --k) {
                 e[k] = nu[k] - c;
-                sb = __builtin_amdgcn_alignbit(sb, (uint32_t)__double2hiint(e[k]), 31);   // (sb << 1) | sign(e_k)
-                amin = (k == K - 1) ? __builtin_fabs(e[k]) : __builtin_fmin(amin, __builtin_fabs(e[k]));   // (differences: no canonicalisation)
-                nu[k] = max_raw(nu[k], c);
-                if (k > 0) nu[k] += sc[k];
+                sb = __builtin_amdgcn_alignbit(sb, (uint32_t)__double2hiint(e[k]), 31);
+                amin = (k == K - 1) ? __builtin_fabs(e[k]) : __builtin_fmin(amin, __builtin_fabs(e[k]));
             }
-            // (e_k is never NaN: the launch requires a finite initial log probability, so m1 and c are finite, and a row
-            // at -Inf gives e_k = -Inf)
             const uint64_t band = __builtin_amdgcn_ballot_w64(!(amin > thr));
-            static_assert(K == 3 || K == 6, "near_top_bits blocks");
             const uint32_t near = near_top_bits<K>(e, t2);
-            const uint32_t i1 = (uint32_t)__builtin_ctz(near | 0x80u);   // the one state near the top (when there are two, the rows that need it are flagged)
-            const uint64_t two_near = __builtin_amdgcn_ballot_w64(__builtin_popcount(near) != 1);   // (none: cannot happen with finite values; flagged all the same)
+            const uint32_t i1 = (uint32_t)__builtin_ctz(near | 0x80u);
+            const uint64_t two_near = __builtin_amdgcn_ballot_w64(__builtin_popcount(near) != 1);
             uint32_t word = sb | (i1 << 6);
-            // the "inside the band" bits are needed by almost no gene: one scalar branch for the whole wavefront
             if (__builtin_expect((band | two_near) != 0, 0)) {
-                asm volatile("; uncertain decision in this wavefront" ::: "memory");   // keeps the block a real branch
+                asm volatile("; uncertain decision in this wavefront" ::: "memory");
                 const bool top_unsure = (two_near >> lane) & 1u;
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
@@ -251,15 +280,29 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
                     word |= unsure ? (512u << k) : 0u;
                 }
             }
-            return word;
-        };
-        auto gene = [&](double xv, int i) {
-            double sc[K], tn;
-            int idx;
-            locate(xv, idx, tn);
-            poly(idx, tn, sc);
-            const uint32_t word = step(sc);
-            bpc[i * 64] = (uint16_t)word;   // (no scheduling barrier between the genes of a chunk: neighbours overlap a little)
+            bpc[i * 64] = (uint16_t)word;
+            nu[0] = max_raw(nu[0], c);
+            constexpr int KA = (K - 1) < 2 ? (K - 1) : 2;    // states of batch A
+            auto score_rows = [&](int k0, int k1, int idxq) {
+                const double *cq = coef + idxq;
+#pragma unroll
+                for (int k = k0; k <= k1; ++k) {
+                    const double2 c01 = *reinterpret_cast<const double2 *>(cq + (k - 1) * NCF);
+                    const double2 c23 = *reinterpret_cast<const double2 *>(cq + (k - 1) * NCF + 2);
+                    const double2 c45 = *reinterpret_cast<const double2 *>(cq + (k - 1) * NCF + 4);
+                    double p = __builtin_fma(c45.y, tn, c45.x);
+                    p = __builtin_fma(p, tn, c23.y);
+                    p = __builtin_fma(p, tn, c23.x);
+                    p = __builtin_fma(p, tn, c01.y);
+                    nu[k] = max_raw(nu[k], c) + __builtin_fma(p, tn, c01.x);
+                }
+            };
+            score_rows(1, KA, idx);
+            if (K - 1 > KA) {
+                int idxb = idx;
+                asm volatile("" : "+v"(idxb) : "v"(nu[KA]));   // batch B's gathers behind batch A's arithmetic
+                score_rows(KA + 1, K - 1, idxb);
+            }
         };
         {
             double sc[K], tn0;
@@ -307,6 +350,7 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             }
         }
         for (; i < n; ++i) gene(xc[i], i);
+        ARGS_HERE();
         // last row: R's which.max
         double m1 = nu[0], m2 = -__builtin_inf();
         int cur = 0;
@@ -342,6 +386,9 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         }
     }
 }
+
+#undef A
+#undef ARGS_HERE
 
 }  // namespace
 
