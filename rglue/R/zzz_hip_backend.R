@@ -278,6 +278,32 @@ hip_cell_dist <- function(tumor_expr_data) {
     stats::as.dist(d)
 }
 
+## Steps 2, 3, 4 of run() in one call from the raw counts (R/inferCNV_ops.R:560-620): require_above_min_mean_expr_cutoff,
+## require_above_min_cells_ref, normalize_counts_by_seq_depth, log2xplus1.  The counts cross PCIe once as integers -- a
+## dgCMatrix as its CSC slots, a dense matrix as int32 -- and the log-scale matrix of the kept genes comes back (and, with
+## residency on, stays on the device for step 8).  Same result as the four step functions; counts must be integers.
+hip_ingest_counts <- function(infercnv_obj, min_mean_expr_cutoff, min_cells_per_gene = 3, normalize_factor = NA_real_) {
+    x <- infercnv_obj@expr.data
+    G <- nrow(x); C <- ncol(x)
+    res <- if (is(x, "dgCMatrix")) {
+        if (any(x@x != round(x@x))) stop("hip_ingest_counts wants integer counts")
+        .Call("icnv_R_ingest_counts", NULL, as.integer(x@p), as.integer(x@i), as.integer(round(x@x)), G, C,
+              as.numeric(min_mean_expr_cutoff), as.integer(min_cells_per_gene), as.numeric(normalize_factor))
+    } else {
+        m <- as.matrix(x)
+        if (any(m != round(m))) stop("hip_ingest_counts wants integer counts")
+        storage.mode(m) <- "integer"
+        .Call("icnv_R_ingest_counts", m, NULL, NULL, NULL, G, C, as.numeric(min_mean_expr_cutoff),
+              as.integer(min_cells_per_gene), as.numeric(normalize_factor))
+    }
+    keep <- res[[2]]
+    if (length(keep) < G) infercnv_obj <- remove_genes(infercnv_obj, setdiff(seq_len(G), keep))   # gene_order, count.data follow
+    expr <- res[[1]]
+    dimnames(expr) <- list(rownames(x)[keep], colnames(x))
+    infercnv_obj@expr.data <- expr
+    infercnv_obj
+}
+
 ## Swap the package's step functions for the hip ones.  devices: 0 = every visible MI355X (cells are split into one
 ## contiguous block per GPU inside the library, one host thread per GPU), n = the first n, -1 = the current one only.
 ## residency: keep the last results on the device(s) so that the next step skips the upload of the matrix it was

@@ -24,6 +24,7 @@
 #define S5 S3, SEXP, SEXP
 #define S6 S5, SEXP
 #define S8 S6, SEXP, SEXP
+#define S9 S8, SEXP
 #define S12 S8, SEXP, SEXP, SEXP, SEXP
 #define ARITY(fn, n, ...) _Static_assert(__builtin_types_compatible_p(__typeof__(&fn), SEXP (*)(__VA_ARGS__)), #fn " does not take " #n " SEXPs");
 ARITY(icnv_R_smooth_chain, 12, S12)
@@ -34,11 +35,12 @@ ARITY(icnv_R_median_filter, 5, S5)
 ARITY(icnv_R_cell_distances, 2, S2)
 ARITY(icnv_R_states_to_proxy, 2, S2)
 ARITY(icnv_R_state_consensus_overwrite, 3, S3)
+ARITY(icnv_R_ingest_counts, 9, S9)
 ARITY(icnv_R_init, 2, S2)
 static const struct { const char *name; int n; } expected[] = {
     {"icnv_R_smooth_chain", 12}, {"icnv_R_average_bounds", 1}, {"icnv_R_viterbi_cells", 6}, {"icnv_R_viterbi_groups", 8},
     {"icnv_R_median_filter", 5}, {"icnv_R_cell_distances", 2}, {"icnv_R_states_to_proxy", 2},
-    {"icnv_R_state_consensus_overwrite", 3}, {"icnv_R_init", 2}};
+    {"icnv_R_state_consensus_overwrite", 3}, {"icnv_R_ingest_counts", 9}, {"icnv_R_init", 2}};
 
 static int check_registration(void) {
     R_init_infercnv(mock_r_dll());
@@ -158,6 +160,40 @@ static int run_gpu(void) {
     CHECK(raised == 0 && mock_r_protect_depth == 0 && Rf_getAttrib(mf, R_DimNamesSymbol) == dn);
     CHECK(icnv_median_filter(REAL(out), o2, G, C, chr_start, 2, gidx, goff, 2, 7) == 0);
     CHECK(memcmp(o2, REAL(mf), sizeof(double) * G * C) == 0);
+    /* ---- ingest from integer counts: dense and CSC give the same matrix; the kept genes are 1-based ---- */
+    {
+        enum { IG = 50, IC = 12 };
+        SEXP cm = Rf_allocMatrix(INTSXP, IG, IC);
+        int nnz = 0;
+        for (int c = 0; c < IC; c++)
+            for (int g = 0; g < IG; g++) {
+                const int v = ((g * 7 + c * 3) % 11 < 4 && g % 10 != 3) ? (g + c) % 9 + 1 : 0;   /* genes 3, 13, ... never expressed */
+                INTEGER(cm)[g + IG * c] = v;
+                nnz += v != 0;
+            }
+        int *cp = (int *)malloc(sizeof(int) * (IC + 1)), *ri = (int *)malloc(sizeof(int) * (size_t)nnz), *vv = (int *)malloc(sizeof(int) * (size_t)nnz);
+        int k = 0;
+        for (int c = 0; c < IC; c++) {
+            cp[c] = k;
+            for (int g = 0; g < IG; g++)
+                if (INTEGER(cm)[g + IG * c]) { ri[k] = g; vv[k] = INTEGER(cm)[g + IG * c]; k++; }
+        }
+        cp[IC] = k;
+        SEXP rd = NULL, rs = NULL;
+        mock_r_try(raised, rd = icnv_R_ingest_counts(cm, R_NilValue, R_NilValue, R_NilValue, mock_r_int(IG), mock_r_int(IC), mock_r_real(0.05),
+                                                     mock_r_int(2), mock_r_real(NA_REAL)));
+        CHECK(raised == 0 && mock_r_protect_depth == 0);
+        mock_r_try(raised, rs = icnv_R_ingest_counts(R_NilValue, mock_r_ints(cp, IC + 1), mock_r_ints(ri, nnz), mock_r_ints(vv, nnz), mock_r_int(IG),
+                                                     mock_r_int(IC), mock_r_real(0.05), mock_r_int(2), mock_r_real(NA_REAL)));
+        CHECK(raised == 0 && mock_r_protect_depth == 0);
+        SEXP ed = VECTOR_ELT(rd, 0), es = VECTOR_ELT(rs, 0), kd = VECTOR_ELT(rd, 1), ks = VECTOR_ELT(rs, 1);
+        CHECK(Rf_ncols(ed) == IC && Rf_nrows(ed) == (int)XLENGTH(kd) && Rf_nrows(ed) < IG && Rf_nrows(ed) > 10);
+        CHECK(XLENGTH(kd) == XLENGTH(ks) && memcmp(INTEGER(kd), INTEGER(ks), sizeof(int) * (size_t)XLENGTH(kd)) == 0);
+        CHECK(memcmp(REAL(ed), REAL(es), sizeof(double) * (size_t)XLENGTH(ed)) == 0);
+        for (R_xlen_t j = 0; j < XLENGTH(kd); j++) CHECK(INTEGER(kd)[j] >= 1 && INTEGER(kd)[j] <= IG && INTEGER(kd)[j] % 10 != 4);   /* 1-based; gene 3 (0-based) is gone */
+        CHECK(REAL(VECTOR_ELT(rd, 2))[1] == (double)(IG * IC * 4) && REAL(VECTOR_ELT(rs, 2))[1] == (double)((IC + 1) * 8 + nnz * 8));
+        free(cp); free(ri); free(vv);
+    }
     /* ---- average bounds ---- */
     SEXP ab = NULL;
     mock_r_try(raised, ab = icnv_R_average_bounds(x));

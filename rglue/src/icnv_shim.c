@@ -166,6 +166,53 @@ SEXP icnv_R_state_consensus_overwrite(SEXP states, SEXP grp_idx, SEXP grp_off) {
     return widen_states(so, states);
 }
 
+/* .Call("icnv_R_ingest_counts", counts, colptr, rowidx, vals, G, C, min_mean_expr_cutoff, min_cells_per_gene, normalize_factor)
+ *   -> list(expr = G_out x C numeric matrix (log2(count / depth * factor + 1) of the kept genes), keep = 1-based kept genes,
+ *           factor = normalisation factor used, h2d_bytes)
+ * Steps 2, 3, 4 of run() in one call from the raw counts (R/inferCNV_ops.R:2128-2213, 3064-3111, 2756-2769).  Dense: `counts`
+ * is an INTEGER matrix (G x C) and colptr / rowidx / vals are NULL.  Sparse: `counts` is NULL and colptr / rowidx / vals are the
+ * @p, @i, @x slots of a dgCMatrix (x rounded to integer by the R wrapper); R has no 64-bit integers, so @p arrives as INTEGER
+ * and is widened here. */
+SEXP icnv_R_ingest_counts(SEXP counts, SEXP colptr, SEXP rowidx, SEXP vals, SEXP G_, SEXP C_, SEXP min_mean_expr_cutoff,
+                          SEXP min_cells_per_gene, SEXP normalize_factor) {
+    const int64_t G = Rf_asInteger(G_), C = Rf_asInteger(C_);
+    icnv_counts cnt;
+    memset(&cnt, 0, sizeof(cnt));
+    int64_t *cp64 = NULL;
+    if (counts != R_NilValue) {
+        if (Rf_nrows(counts) != G || Rf_ncols(counts) != C) Rf_error("counts must be a G x C integer matrix");
+        cnt.dense = (const int32_t *)INTEGER(counts);
+    } else {
+        if (XLENGTH(colptr) != C + 1) Rf_error("colptr must have C + 1 entries");
+        cp64 = (int64_t *)R_alloc((size_t)C + 1, sizeof(int64_t));
+        for (int64_t c = 0; c <= C; c++) cp64[c] = (int64_t)INTEGER(colptr)[c];
+        cnt.colptr = cp64;
+        cnt.rowidx = (const int32_t *)INTEGER(rowidx);
+        cnt.vals = (const int32_t *)INTEGER(vals);
+        cnt.nnz = (int64_t)XLENGTH(vals);
+    }
+    int32_t *keep = (int32_t *)R_alloc((size_t)G, sizeof(int32_t));
+    double *buf = (double *)R_alloc((size_t)G * (size_t)C, sizeof(double));   /* capacity G x C, filled G_out x C */
+    int64_t g_out = 0, up = 0;
+    double used = 0.0;
+    int rc = icnv_ingest_counts(&cnt, G, C, Rf_asReal(min_mean_expr_cutoff), Rf_asInteger(min_cells_per_gene), Rf_asReal(normalize_factor),
+                                keep, &g_out, buf, &used, &up);
+    if (rc) fail(rc);
+    SEXP expr = PROTECT(Rf_allocMatrix(REALSXP, (int)g_out, (int)C));
+    memcpy(REAL(expr), buf, (size_t)g_out * (size_t)C * sizeof(double));
+    SEXP kept = PROTECT(Rf_allocVector(INTSXP, (R_xlen_t)g_out));
+    for (int64_t j = 0; j < g_out; j++) INTEGER(kept)[j] = keep[j] + 1;
+    SEXP f = PROTECT(Rf_allocVector(REALSXP, 2));
+    REAL(f)[0] = used;
+    REAL(f)[1] = (double)up;
+    SEXP res = PROTECT(Rf_allocVector(VECSXP, 3));
+    SET_VECTOR_ELT(res, 0, expr);
+    SET_VECTOR_ELT(res, 1, kept);
+    SET_VECTOR_ELT(res, 2, f);
+    UNPROTECT(4);
+    return res;
+}
+
 /* .Call("icnv_R_init", devices, residency): devices 0 = all visible GPUs, n = the first n, -1 = the current one only */
 SEXP icnv_R_init(SEXP devices, SEXP residency) {
     const int nd = Rf_asInteger(devices);
@@ -185,6 +232,7 @@ static const R_CallMethodDef call_methods[] = {
     {"icnv_R_cell_distances", (DL_FUNC)&icnv_R_cell_distances, 2},
     {"icnv_R_states_to_proxy", (DL_FUNC)&icnv_R_states_to_proxy, 2},
     {"icnv_R_state_consensus_overwrite", (DL_FUNC)&icnv_R_state_consensus_overwrite, 3},
+    {"icnv_R_ingest_counts", (DL_FUNC)&icnv_R_ingest_counts, 9},
     {"icnv_R_init", (DL_FUNC)&icnv_R_init, 2},
     {NULL, NULL, 0}};
 
