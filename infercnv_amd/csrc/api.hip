@@ -943,6 +943,11 @@ struct ViterbiCtx {
     hipEvent_t flag_ev = nullptr;
     int64_t stats[4] = {0, 0, 0, 0};   // last call: path (0 exact / 1 fast), sequences, flagged (-1: pending), table intervals
     int64_t flag_limit = 0;            // of the last column batch: more flagged sequences than this -> exact kernel
+    // chromosome layout of the last call on the device ([n_chr + 1] starts, then [n_chr] chromosomes longest first): a
+    // pipeline calls with one layout over and over, and two pageable uploads per call are two stalls of the stream
+    std::vector<int32_t> layout_key;
+    int32_t *d_layout = nullptr;
+    size_t layout_cap = 0;
 };
 std::mutex g_vctx_mu;
 std::map<int, ViterbiCtx *> g_vctx;
@@ -984,6 +989,8 @@ void viterbi_release_contexts() {
         if (c.counters) (void)hipFree(c.counters);
         if (c.host_flag) (void)hipHostFree(c.host_flag);
         if (c.flag_ev) (void)hipEventDestroy(c.flag_ev);
+        if (c.d_layout) (void)hipFree(c.d_layout);
+        c.d_layout = nullptr; c.layout_cap = 0; c.layout_key.clear();
         c.dev = nullptr; c.dev_bytes = 0; c.counters = nullptr; c.host_flag = nullptr; c.flag_ev = nullptr;
         c.valid = false;
     }
@@ -1035,17 +1042,36 @@ static int fast_table_for(ViterbiCtx &c, const HmmParams &p, double sd, hipStrea
 static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t ncols, const int32_t *chr_start,
                            int32_t n_chr, const HmmParams &p, const double *sd_per_col_dev, double sd_shared,
                            int32_t *n_underflow_dev, hipStream_t s) {
-    DevBuf d_chr, d_ord, d_bp, d_list, d_redo;
+    DevBuf d_bp, d_list, d_redo;
     int rc;
     std::vector<int32_t> order;
     chr_order_longest_first(chr_start, n_chr, order);
-    if ((rc = upload(d_chr, chr_start, (size_t)n_chr + 1, s))) return rc;
-    if ((rc = upload(d_ord, order.data(), order.size(), s))) return rc;
     int32_t max_len = 0;
     for (int k = 0; k < n_chr; ++k) max_len = std::max(max_len, chr_start[k + 1] - chr_start[k]);
 
     ViterbiCtx &vc = *viterbi_ctx_ptr();
     std::lock_guard<std::mutex> vlk(vc.mu);
+    {
+        std::vector<int32_t> key(chr_start, chr_start + n_chr + 1);
+        key.insert(key.end(), order.begin(), order.end());
+        if (key != vc.layout_key || !vc.d_layout) {
+            if (key.size() > vc.layout_cap) {
+                ICNV_HIP(hipStreamSynchronize(s));
+                if (vc.d_layout) (void)hipFree(vc.d_layout);
+                vc.d_layout = nullptr;
+                vc.layout_cap = 0;
+                vc.layout_key.clear();
+                ICNV_HIP(hipMalloc((void **)&vc.d_layout, key.size() * sizeof(int32_t)));
+                vc.layout_cap = key.size();
+            }
+            // work queued on the stream may still read the previous layout: order the upload behind it
+            ICNV_HIP(hipStreamSynchronize(s));
+            vc.layout_key.clear();
+            ICNV_HIP(hipMemcpy(vc.d_layout, key.data(), key.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            vc.layout_key = std::move(key);
+        }
+    }
+    const int32_t *const dev_chr = vc.d_layout, *const dev_ord = vc.d_layout + n_chr + 1;
     // the certified fast path needs a shared sd, the .get_HMM transition structure and a table that met its accuracy target
     bool fast = false;
     double a = 0, b = 0;
@@ -1075,7 +1101,7 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
         DevBuf d_all, d_scr;
         if ((rc = upload(d_all, list.data(), list.size(), s))) return rc;
         if ((rc = d_scr.alloc(viterbi_redo_scratch_bytes(max_len)))) return rc;
-        return launch_viterbi_redo(x, states, (int32_t)G, d_chr.as<int32_t>(), p, sd_per_col_dev, sd_shared,
+        return launch_viterbi_redo(x, states, (int32_t)G, dev_chr, p, sd_per_col_dev, sd_shared,
                                    d_all.as<int32_t>() + 2 * (size_t)count, d_all.as<int32_t>(), 0x7fffffff, d_scr.as<uint32_t>(),
                                    n_underflow_dev, max_len, "viterbi", s);
     }
@@ -1097,7 +1123,7 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
     for (int64_t c0 = 0; c0 < ncols; c0 += batch) {
         const int64_t nc = std::min(batch, ncols - c0);
         if (!fast) {
-            rc = launch_viterbi(x + c0 * G, states + c0 * G, (int32_t)G, nc, d_chr.as<int32_t>(), d_ord.as<int32_t>(), n_chr,
+            rc = launch_viterbi(x + c0 * G, states + c0 * G, (int32_t)G, nc, dev_chr, dev_ord, n_chr,
                                 0, p, sd_per_col_dev ? sd_per_col_dev + c0 : nullptr, sd_shared, d_bp.as<uint32_t>(),
                                 n_underflow_dev, nullptr, 0, s);
             if (rc) return rc;
@@ -1109,8 +1135,8 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
         fa.states = states + c0 * G;
         fa.G = (int32_t)G;
         fa.ncols = nc;
-        fa.chr_start = d_chr.as<int32_t>();
-        fa.chr_order = d_ord.as<int32_t>();
+        fa.chr_start = dev_chr;
+        fa.chr_order = dev_ord;
         fa.n_chr = n_chr;
         fa.table = (const double *)vc.dev;
         fa.n_int = vc.tab.n_int;
@@ -1141,10 +1167,10 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
         // recomputed as a whole by the lane-per-sequence exact kernel.  Both are launched, the flag count -- on the
         // device -- decides which of them does the work.
         const int32_t limit = (int32_t)std::min<double>(REDO_MAX_SHARE * (double)(nc * n_chr), 2e9);
-        if ((rc = launch_viterbi_redo(fa.x, fa.states, (int32_t)G, d_chr.as<int32_t>(), p, nullptr, sd_shared, fa.flag_count,
+        if ((rc = launch_viterbi_redo(fa.x, fa.states, (int32_t)G, dev_chr, p, nullptr, sd_shared, fa.flag_count,
                                       fa.flag_list, limit, d_redo.as<uint32_t>(), n_underflow_dev, max_len, "viterbi_redo", s)))
             return rc;
-        if ((rc = launch_viterbi(fa.x, fa.states, (int32_t)G, nc, d_chr.as<int32_t>(), d_ord.as<int32_t>(), n_chr, 0, p, nullptr,
+        if ((rc = launch_viterbi(fa.x, fa.states, (int32_t)G, nc, dev_chr, dev_ord, n_chr, 0, p, nullptr,
                                  sd_shared, d_bp.as<uint32_t>(), n_underflow_dev, fa.flag_count, limit, s)))
             return rc;
         ICNV_HIP(hipMemcpyAsync(vc.host_flag, fa.flag_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
