@@ -184,7 +184,7 @@ def run_group_config(args, world, rank):
         result = [None]
         def step():
             result[0] = hmm.run_i3(pre, chr_start, local, ref_local)
-        names = ("chain_cell_stats", "group_means", "viterbi", "viterbi_groups", "viterbi_redo", "viterbi_exact_fallback", "broadcast_states")
+        names = ("cells_moments", "group_means", "viterbi", "viterbi_groups", "viterbi_redo", "viterbi_exact_fallback", "broadcast_states")
         what = "i3 HMM at subcluster level (R/inferCNV_i3HMM.R:249-308): i3 mu / sigma over the reference values (2 all-reduces of 2 doubles), group means, Viterbi per subcluster, broadcast"
         alg = 9 * G * C_local          # read every value once (group means), write one state byte per gene*cell
     else:
@@ -389,23 +389,24 @@ def main():
         if "viterbi" in roof:
             st = device.viterbi_last_stats()
             roof["viterbi"]["note"] = (f"certified fast path ({st['path']}; {st['flagged']} of {st['sequences']} sequences redone exactly): "
-                                       "table-driven emission scores + max-plus recurrence, about 99 vector and 37 other instructions "
-                                       "(18 of them LDS gathers) per gene and wavefront, every lane streaming its own column; paced by the "
-                                       "dependent chain of a gene step behind two wavefronts per SIMD (hardware counters: vector pipes busy "
-                                       "~60 % of the launch, the wavefronts stalled ~55 % of their life), no MFMA-shaped work")
+                                       "table-driven emission scores + max-plus recurrence, 101 vector + 18 LDS-gather + 21 other instructions per gene "
+                                       "and wavefront in the forward pass (113 vector instructions per gene with the traceback), every lane "
+                                       "streaming its own column, four wavefronts per SIMD; hardware counters (profiles/r03_pmc_viterbi_fast.txt): "
+                                       "vector pipes busy 81 % of the launch, LDS 71 % (29 % of that bank conflicts of the random coefficient "
+                                       "gathers) -- fp64 vector issue paces it, no MFMA-shaped work")
         if "viterbi" in roof:
             # second ceiling of the Viterbi (SURVEY.md 8d asks for HBM GB/s *and* the fp64 rate): its forward pass issues
-            # ~99 vector instructions per gene and wavefront (static count, scripts/vf_asm_stats.py), every one of them 4
-            # cycles of a 16-lane SIMD; 256 CUs x 4 SIMDs at the 2.4 GHz peak clock
-            instr = 99.0
+            # 113 vector instructions per gene and wavefront (SQ_INSTS_VALU of the launch / gene steps; 101 of them in the forward
+            # pass by static count, scripts/vf_asm_stats.py), every one of them 4 cycles of a 16-lane SIMD; 256 CUs x 4 SIMDs at
+            # the 2.4 GHz peak clock
+            instr = 113.0
             ceil_ms = (G * C_local / 64.0) * instr * 4.0 / (256 * 4) / 2.4e9 * 1e3
             roof["viterbi"]["fp64_issue"] = {"vector_instr_per_gene_wavefront": instr, "ceiling_ms": ceil_ms,
                                              "frac": ceil_ms / kernels["viterbi"]["avg_ms"],
                                              "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TF,
-                                             "note": "share of the launch the vector pipes would need at full issue rate; the rest is the "
-                                                     "dependent chain per gene (two LDS lookups, 15 coefficient gathers at random intervals, "
-                                                     "Horner chains, max-plus step) behind two wavefronts per SIMD, and the per-lane column "
-                                                     "streams -- no single pipe paces it (DESIGN.md K4b)"}
+                                             "note": "share of the launch the vector pipes would need at full issue rate and the 2.4 GHz peak "
+                                                     "clock; at the ~2.05 GHz the chip holds under this load the counters show the pipes "
+                                                     "busy 81 % of the launch (DESIGN.md K4b)"}
         dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
         if "chain_apply" in roof:
             moved = 3 * 8 * G * n_main            # one matrix read, two written (refined below by the counters when present)

@@ -1431,58 +1431,39 @@ int icnv_states_to_proxy(const uint8_t *states, double *out, int64_t n, int32_t 
     return ICNV_OK;
 }
 
-// per-cell (sum, sd) of the listed cells -> host, through the chain kernel's per-cell statistics
-static int cells_sum_sd(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx, int64_t n_cells,
-                        std::vector<double> &cstat, void *stream) {
-    cstat.assign((size_t)std::max<int64_t>(n_cells, 0) * 2, 0.0);
-    if (n_cells == 0) return ICNV_OK;
-    icnv_chain_cfg cfg;
-    std::memset(&cfg, 0, sizeof(cfg));
-    std::vector<int32_t> cs = {0, (int32_t)G}, off = {0, (int32_t)n_cells};
-    cfg.G = G; cfg.C = C; cfg.chr_start = cs.data(); cfg.n_chr = 1; cfg.window_length = 0;
-    cfg.max_thresh = NAN; cfg.use_bounds = 1; cfg.sd_amplifier = 1.0; cfg.noise_filter = NAN;
-    cfg.stage_mask = ICNV_ST_DENOISE; cfg.ref_idx = cell_idx; cfg.ref_off = off.data(); cfg.n_ref_grp = 1;
-    icnv_chain_t *ch = nullptr;
-    int rc = icnv_chain_begin(&ch, &cfg);
+// Sum over the listed cells of: the cell's values (pass 0) or their squared deviations from `mean` (pass 1) -- one
+// streaming launch (a workgroup per cell, fixed-order tree), the per-cell partials added in long double on the host.
+static int cells_pass_sum(int pass, const double *expr, int64_t G, const int32_t *cells_dev, int64_t n_cells, double mean,
+                          DevBuf &dp, std::vector<double> &part, long double &acc, hipStream_t s) {
+    int rc = launch_block_cell_reduce(pass, expr, (int32_t)G, nullptr, (int32_t)G, cells_dev, (int32_t)n_cells, mean, dp.as<double>(), s);
     if (rc) return rc;
-    double *part = nullptr;
-    rc = icnv_chain_round_partial_dev(ch, 0, expr, &part, nullptr, stream);
-    hipStream_t s = (hipStream_t)stream;
-    if (!rc) {
-        hipError_t e = hipMemcpyAsync(cstat.data(), ch->d_cellstats.p, cstat.size() * sizeof(double),
-                                      hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) rc = hip_fail(e, "copy cell stats", __FILE__, __LINE__);
-    }
-    icnv_chain_end(ch);
-    return rc;
+    ICNV_HIP(hipMemcpyAsync(part.data(), dp.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    ICNV_HIP(hipStreamSynchronize(s));
+    acc = 0;
+    for (double v : part) acc += v;
+    return ICNV_OK;
 }
 
 // Split-phase mean / sd over ALL values of the listed cells (i3 emission parameters, R/inferCNV_i3HMM.R:17-80) for a
 // cell-sharded caller: the statistic is two dependent sums,
 //   phase 0: out3 = {sum of the values, number of values, 0}                       -> all-reduce -> mean = sum / n
 //   phase 1: out3 = {sum of (x - mean)^2 over the values, number of values, 0}     -> all-reduce -> sd = sqrt(ss / (n - 1))
-// (R's sd() is this two-pass form).  The squares are pooled exactly from the per-cell (sum, sd) pairs of the chain
-// kernel's statistics pass: sum_c [sd_c^2 (G - 1) + G (m_c - mean)^2], accumulated in long double on the host.
+// (R's sd() is this two-pass form: each phase is one pass over the listed cells at HBM speed).
 // A rank without listed cells passes n_cells = 0 and contributes zeros.
 int icnv_cells_moments_partial_dev(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx, int64_t n_cells,
                                    int32_t phase, double mean, double *out3_host, void *stream) {
-    if (!out3_host || G < 1 || n_cells < 0 || (n_cells > 0 && !expr) || (phase != 0 && phase != 1))
+    if (!out3_host || G < 1 || G > 0x7fffffff || n_cells < 0 || n_cells > 0x7fffffff || (n_cells > 0 && !expr) || (phase != 0 && phase != 1))
         ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
     int rc = validate_index_list(cell_idx, n_cells, C, "cell");
     if (rc) return rc;
-    std::vector<double> cstat;
-    if ((rc = cells_sum_sd(expr, G, C, cell_idx, n_cells, cstat, stream))) return rc;
     long double acc = 0;
-    if (phase == 0) {
-        for (int64_t i = 0; i < n_cells; ++i) acc += cstat[2 * i];
-    } else {
-        const long double mu = mean;
-        for (int64_t i = 0; i < n_cells; ++i) {
-            const long double m_i = (long double)cstat[2 * i] / (long double)G;
-            const long double sd_i = cstat[2 * i + 1];
-            acc += sd_i * sd_i * (long double)(G - 1) + (long double)G * (m_i - mu) * (m_i - mu);
-        }
+    if (n_cells > 0) {
+        hipStream_t s = (hipStream_t)stream;
+        DevBuf dc, dp;
+        if ((rc = upload(dc, cell_idx, (size_t)n_cells, s))) return rc;
+        if ((rc = dp.alloc((size_t)n_cells * sizeof(double)))) return rc;
+        std::vector<double> part((size_t)n_cells);
+        if ((rc = cells_pass_sum(phase, expr, G, dc.as<int32_t>(), n_cells, mean, dp, part, acc, s))) return rc;
     }
     out3_host[0] = (double)acc;
     out3_host[1] = (double)n_cells * (double)G;
@@ -1493,23 +1474,8 @@ int icnv_cells_moments_partial_dev(const double *expr, int64_t G, int64_t C, con
 int icnv_cells_mean_sd_dev(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx, int64_t n_cells,
                            double *out2_host, void *stream) {
     if (!expr || !out2_host || G < 1 || n_cells < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
-    // one rank: the two phases of the split form share the per-cell statistics
-    std::vector<double> cstat;
-    int rc = cells_sum_sd(expr, G, C, cell_idx, n_cells, cstat, stream);
-    if (rc) return rc;
-    long double tot = 0;
-    for (int64_t i = 0; i < n_cells; ++i) tot += cstat[2 * i];
-    const long double N = (long double)n_cells * (long double)G;
-    const long double mu = tot / N;
-    long double ss = 0;
-    for (int64_t i = 0; i < n_cells; ++i) {
-        const long double m_i = (long double)cstat[2 * i] / (long double)G;
-        const long double sd_i = cstat[2 * i + 1];
-        ss += sd_i * sd_i * (long double)(G - 1) + (long double)G * (m_i - mu) * (m_i - mu);
-    }
-    out2_host[0] = (double)mu;
-    out2_host[1] = (double)std::sqrt((double)(ss / (N - 1)));
-    return ICNV_OK;
+    // one rank: mean() then sd() over the block of all genes x the listed cells
+    return icnv_block_mean_sd_dev(expr, G, C, nullptr, 0, cell_idx, n_cells, out2_host, stream);
 }
 
 int icnv_cells_mean_sd(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx, int64_t n_cells, double *out2) {

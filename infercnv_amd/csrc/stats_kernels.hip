@@ -63,12 +63,20 @@ __global__ void block_cell_reduce_kernel(const double *__restrict__ x, int G, co
                                          double *__restrict__ out) {
     __shared__ double red[256 / 64];
     const double *src = x + (int64_t)cell_idx[blockIdx.x] * G;
-    double s = 0.0;
-    for (int j = threadIdx.x; j < n_genes; j += 256) {
-        const double v = src[gene_idx ? gene_idx[j] : j];
-        if (PASS == 0) s += v;
-        else { const double d = v - mean; s += d * d; }
+    auto term = [&](double v) -> double {
+        if (PASS == 0) return v;
+        const double d = v - mean;
+        return d * d;
+    };
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // four independent chains, combined in a fixed order
+    int j = threadIdx.x;
+    for (; j + 768 < n_genes; j += 1024) {
+        const double v0 = src[gene_idx ? gene_idx[j] : j], v1 = src[gene_idx ? gene_idx[j + 256] : j + 256];
+        const double v2 = src[gene_idx ? gene_idx[j + 512] : j + 512], v3 = src[gene_idx ? gene_idx[j + 768] : j + 768];
+        s0 += term(v0); s1 += term(v1); s2 += term(v2); s3 += term(v3);
     }
+    for (; j < n_genes; j += 256) s0 += term(src[gene_idx ? gene_idx[j] : j]);
+    double s = (s0 + s1) + (s2 + s3);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -126,6 +134,7 @@ int launch_select_genes(const double *in, int32_t G_in, int64_t C, const int32_t
 int launch_block_cell_reduce(int pass, const double *x, int32_t G, const int32_t *gene_idx_dev, int32_t n_genes,
                              const int32_t *cell_idx_dev, int32_t n_cells, double mean, double *out, hipStream_t stream) {
     if (n_cells <= 0) return ICNV_OK;
+    KernelTimer kt("cells_moments", stream);
     if (pass == 0)
         hipLaunchKernelGGL(block_cell_reduce_kernel<0>, dim3(n_cells), dim3(256), 0, stream, x, G, gene_idx_dev, n_genes,
                            cell_idx_dev, mean, out);

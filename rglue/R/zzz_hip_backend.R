@@ -40,6 +40,8 @@
     if (!is.matrix(x)) x <- as.matrix(x)                 # dgCMatrix -> dense, like R/inferCNV_ops.R:1924-1926
     if (is.unsorted(lay$perm)) x <- x[lay$perm, , drop = FALSE]
     if (storage.mode(x) != "double") storage.mode(x) <- "double"
+    ## the kernels treat NA as a NaN value; the reference strips NAs (.smooth_helper, median(na.rm = TRUE)) -- DESIGN.md section 2
+    if (anyNA(x)) stop("the hip backend does not take matrices with NA / NaN; impute them or use options(infercnv.backend = 'R')")
     x
 }
 .icnv_unpermute <- function(m, lay) if (is.null(m) || !is.unsorted(lay$perm)) m else m[order(lay$perm), , drop = FALSE]

@@ -30,3 +30,9 @@ python scripts/bench_host_path.py 20000 1 > $O/host_path.json 2> $O/host_path.er
 ICNV_CHAIN2=1 timeout 300 python $R/bench.py --no-cpu-baseline > $O/bench_chain2.json 2> $O/bench_chain2.err
 if [ -f $R/infercnv_amd/libicnv_hip_prof.so ]; then ICNV_CHAIN2=1 python $R/scripts/chain2_phase_profile.py > $O/chain2_phase_profile.txt 2>&1; fi
 tail -2 $O/bench_full.json | cut -c1-600
+# SQ / LDS counters of the fast Viterbi kernel, what the launch path costs (eager vs hipGraph replay), the other slices
+timeout 900 bash $R/scripts/pmc_viterbi_fast.sh > $O/pmc_viterbi_fast_log.txt 2>&1
+cp $R/gpurun_out/pmc_vitfast/summary.txt $O/${TAG}_pmc_viterbi_fast.txt; find $R/gpurun_out/pmc_vitfast -name "*.db" -delete
+timeout 300 python $R/scripts/graph_step.py > $O/graph_step.txt 2>&1
+timeout 600 python $R/scripts/bench_configs.py > $O/configs_slices.json 2> $O/configs_slices.err
+du -sh $R/gpurun_out

@@ -6,14 +6,11 @@ output checksums (every variant must return the product kernel's states)."""
 import os, subprocess, sys
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 src = open(os.path.join(root, "infercnv_amd", "csrc", "viterbi_fast.hip")).read()
-SPLIT = [("                sc[k] = __builtin_fma(p, tn, c01.x);\n", "                sc[k] = __builtin_fma(p, tn, c01.x);\n                if (k == 2) __builtin_amdgcn_sched_barrier(0);   // two batches of coefficient gathers in flight\n")]
-GENEBAR = [("            bpc[i * 64] = (uint16_t)word;   // (no scheduling barrier between the genes of a chunk: neighbours overlap a little)",
-            "            bpc[i * 64] = (uint16_t)word;\n            __builtin_amdgcn_sched_barrier(0);")]
-NT768 = [("constexpr int FAST_NT = 512;", "constexpr int FAST_NT = 768;")]
-NT640 = [("constexpr int FAST_NT = 512;", "constexpr int FAST_NT = 640;")]
-V = {"base": [], "split": SPLIT, "genebar": GENEBAR, "split_genebar": SPLIT + GENEBAR,
-     "nt768": NT768, "nt768_split": NT768 + SPLIT, "nt768_genebar": NT768 + GENEBAR, "nt768_split_genebar": NT768 + SPLIT + GENEBAR,
-     "nt640_split_genebar": NT640 + SPLIT + GENEBAR}
+def nt(n): return [("constexpr int FAST_NT = 1024;", f"constexpr int FAST_NT = {n};")]
+def ch(n): return [("constexpr int FAST_CH = 8; ", f"constexpr int FAST_CH = {n};")]
+def tg(n): return [("constexpr int FAST_TG = 8; ", f"constexpr int FAST_TG = {n};")]
+V = {"base": [], "nt768": nt(768), "nt512": nt(512), "ch16": ch(16), "nt768_ch16": nt(768) + ch(16), "nt768_ch16_tg16": nt(768) + ch(16) + tg(16),
+     "nt768_tg16": nt(768) + tg(16)}
 want = sys.argv[1:] or list(V)
 for name in want:
     s = src
