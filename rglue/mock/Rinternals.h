@@ -60,17 +60,6 @@ SEXP SET_VECTOR_ELT(SEXP x, R_xlen_t i, SEXP v);
 SEXP VECTOR_ELT(SEXP x, R_xlen_t i);
 char *R_alloc(size_t n, int size);
 
-/* R_ext/Rdynload.h */
-typedef void *(*DL_FUNC)(void);
-typedef struct { const char *name; DL_FUNC fun; int numArgs; } R_CallMethodDef;
-typedef struct { const char *name; DL_FUNC fun; int numArgs; void *types; } R_CMethodDef;
-typedef R_CMethodDef R_FortranMethodDef;
-typedef R_CallMethodDef R_ExternalMethodDef;
-typedef struct mock_dllinfo DllInfo;
-int R_registerRoutines(DllInfo *info, const R_CMethodDef *const c, const R_CallMethodDef *const call,
-                       const R_FortranMethodDef *const f, const R_ExternalMethodDef *const ext);
-Rboolean R_useDynamicSymbols(DllInfo *info, Rboolean value);
-
 #ifdef __cplusplus
 }
 #endif

@@ -4,6 +4,7 @@
 #include <setjmp.h>
 
 #include "Rinternals.h"
+#include "R_ext/Rdynload.h"
 
 extern char mock_r_last_error[1024];
 extern int mock_r_protect_depth;   /* PROTECT / UNPROTECT balance: must be 0 after every .Call routine returns */

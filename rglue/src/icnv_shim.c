@@ -18,6 +18,7 @@
  */
 #include <R.h>
 #include <Rinternals.h>
+#include <R_ext/Rdynload.h>
 #include <stdint.h>
 #include <string.h>
 
