@@ -45,6 +45,14 @@ STREAM_1R2W_GBS, STREAM_1R2W_SOURCE = _stream_ceiling()
 FP64_VECTOR_PEAK_TF = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 
 
+def _pmc_traffic():
+    """profiles/pmc_traffic.json (scripts/pmc_traffic.sh + pmc_summary.py): HBM bytes from separate rocprofv3 --pmc passes."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except Exception:
+        return {}
+
+
 def effective_cores():
     """CPU cores this process may actually use: the affinity mask capped by the container's CPU quota (cgroup v2
     cpu.max, cgroup v1 cfs quota).  os.cpu_count() reports the node's logical CPUs, whatever the quota."""
@@ -243,7 +251,10 @@ def run_group_config(args, world, rank):
                           "genes": G, "cells_per_gpu": args.cells, "cells_total": C_total, "subclusters_rank0": len(local),
                           "parallelism": f"whole subclusters per GPU x{world} (contiguous blocks cut at subcluster boundaries)"},
                "roofline": {"bound": "hbm", "achieved": alg / (max(ksum, 1e-9) * 1e-3) / 1e9 if kernels else None, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": (alg / (ksum * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernels and ksum > 0 else None, "traffic": None,
+                            "unit": "GB/s", "frac": (alg / (ksum * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernels and ksum > 0 else None,
+                            "traffic": (_pmc_traffic().get("config%d_bytes_per_step" % args.config) if args.cells == 50000 and G == 10000 and world == 1 else None),
+                            "traffic_source": "profiles/pmc_traffic.json: FETCH_SIZE (x2) + WRITE_SIZE of the step's kernels, separate rocprofv3 --pmc passes "
+                                              "over this workload (scripts/pmc_traffic.sh), per step; not measured in this run",
                             "algorithmic_bytes_per_step": alg, "kernel_ms_per_step": ksum,
                             "note": "all kernels of the step together (group means / Viterbi / broadcast, or the interior and edge median kernels)"},
                "kernels": kernels, "cpu_baseline": None,

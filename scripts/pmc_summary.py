@@ -8,6 +8,8 @@ import collections, csv, json, os, re, sys
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 def load(path):
     agg = collections.defaultdict(list)
+    if not os.path.exists(path):
+        return {}
     for r in csv.DictReader(open(path)):
         if "icnv" in r["Kernel_Name"]:
             m = re.search(r"::(\w+_kernel(?:<[^>]*>)?)\(", r["Kernel_Name"])
@@ -27,6 +29,32 @@ for t in ("copy", "bench"):
             elif k.startswith("viterbi_kernel") and "viterbi" not in out: out["viterbi"] = fb + wb
         else:
             out["calibration_copy_4e9_read_4e9_write"] = {"fetch_bytes_corrected": fb, "write_bytes": wb}
+# configs 4 / 5: bytes per STEP of the step's own kernels (the run is 1 warm-up + 2 steps; the chain that prepares the
+# inputs runs once and is left out)
+STEP_KERNELS = {"cfg4": ("block_cell_reduce_kernel", "group_partial_sums_kernel", "group_means_finish_kernel", "viterbi_redo_kernel",
+                         "viterbi_kernel", "viterbi_fast_kernel", "broadcast_states_kernel"),
+                "cfg5": ("median_filter9_kernel", "median_filter9_edge_kernel", "median_filter_kernel")}
+def load_all(path):
+    agg = collections.defaultdict(list)
+    if not os.path.exists(path):
+        return agg
+    for r in csv.DictReader(open(path)):
+        if "icnv" in r["Kernel_Name"]:
+            m = re.search(r"::(\w+_kernel)", r["Kernel_Name"])
+            agg[m.group(1) if m else r["Kernel_Name"][:60]].append(float(r["Counter_Value"]))
+    return agg
+for t, names in STEP_KERNELS.items():
+    fa, wa = load_all(f"{root}/FETCH_SIZE/{t}_counter_collection.csv"), load_all(f"{root}/WRITE_SIZE/{t}_counter_collection.csv")
+    if not fa:
+        continue
+    per = {}
+    for k in names:
+        if k in fa:
+            fb, wb = sum(fa[k]) * 2 * 1024 / 3.0, sum(wa.get(k, [0.0])) * 1024 / 3.0
+            per[k] = fb + wb
+            lines.append(f"{t}:{k}  launches/step {len(fa[k]) / 3.0:.2f}  fetch_bytes/step(x2 corrected) {fb:.4g}  write_bytes/step {wb:.4g}  total/step {fb + wb:.4g}")
+    out["config%s_bytes_per_step" % t[-1]] = sum(per.values())
+    out["config%s_by_kernel" % t[-1]] = per
 print("\n".join(lines))
 os.makedirs("profiles", exist_ok=True)
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
