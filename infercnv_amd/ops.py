@@ -86,11 +86,10 @@ def remove_genes(infercnv_obj: InfercnvObject, gene_indices_to_remove) -> Inferc
     drop = np.zeros(G, dtype=bool)
     drop[np.asarray(gene_indices_to_remove, dtype=np.int64)] = True
     keep = np.nonzero(~drop)[0].astype(np.int32)
-    if keep.size == 0:
-        raise ValueError("all genes removed")
     out = np.empty((keep.size, C), dtype=np.float64, order="F")
-    check(L.icnv_select_genes(x.ctypes.data_as(ct.c_void_p), G, C, keep.ctypes.data_as(ct.POINTER(ct.c_int32)), keep.size,
-                              out.ctypes.data_as(ct.c_void_p)))
+    if keep.size:                                        # (no gene left: a 0-row object, as the reference returns)
+        check(L.icnv_select_genes(x.ctypes.data_as(ct.c_void_p), G, C, keep.ctypes.data_as(ct.POINTER(ct.c_int32)), keep.size,
+                                  out.ctypes.data_as(ct.c_void_p)))
     new = _keep_gene_rows(infercnv_obj, keep)
     new.expr_data = out
     new.validate()

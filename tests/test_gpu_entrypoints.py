@@ -117,6 +117,23 @@ def test_config1_example_run_inputs_through_the_hip_path(dev, run_inputs):
         assert (samples.expr_data[np.ix_(rows, ref)] == 3).mean() > 0.9
 
 
+def test_below_min_mean_expr_cutoff_reference_literals_through_the_hip_path(dev):
+    """tests/testthat/test_infer_cnv.R:175-220 through ops.require_above_min_mean_expr_cutoff -> icnv_gene_stats /
+    icnv_select_genes: the genes the reference's literal answers list are the ones removed."""
+    from infercnv_amd import GeneOrder, InfercnvObject, ops
+    m1 = np.arange(1, 6, dtype=float).reshape(5, 1)
+    m3 = np.arange(1, 16, dtype=float).reshape(3, 5).T
+    cases = [(m1, 10, [1, 2, 3, 4, 5]), (m3, 10, [1, 2, 3, 4]), (m1, 2, [1]), (m3, 8.4, [1, 2, 3]), (m1, 0, []), (m3, 100, [1, 2, 3, 4, 5])]
+    for m, cut, below in cases:
+        obj = InfercnvObject(expr_data=m.copy(), count_data=m.copy(), gene_order=GeneOrder(chr=["chr1"] * 5),
+                             reference_grouped_cell_indices={"a": np.array([0])},
+                             observation_grouped_cell_indices={"b": np.arange(m.shape[1])})
+        keep = np.array([g for g in range(1, 6) if g not in below], dtype=np.int64)
+        o = ops.require_above_min_mean_expr_cutoff(obj, cut)      # (no gene left: a 0-row object, like remove_genes in R)
+        np.testing.assert_array_equal(o.expr_data, m[keep - 1])
+        assert o.expr_data.shape == (keep.size, m.shape[1]) and len(o.gene_order.chr) == keep.size
+
+
 def test_average_bounds_and_auto_threshold(dev):
     """icnv_average_bounds[_dev] (get_average_bounds, R/inferCNV_ops.R:2723-2742) and step 9 with threshold "auto"
     (run(): mean(abs(get_average_bounds()), :802-817)."""

@@ -338,6 +338,14 @@ def test_define_cnv_gene_regions_loop():
     assert counter == 14
 
 
+def test_below_min_mean_expr_cutoff_reference_literals():
+    """tests/testthat/test_infer_cnv.R:175-220: the six literal cases of .below_min_mean_expr_cutoff (1-based there)."""
+    cases = [(matrix_one, 10, [1, 2, 3, 4, 5]), (matrix_three, 10, [1, 2, 3, 4]), (matrix_one, 2, [1]),
+             (matrix_three, 8.4, [1, 2, 3]), (matrix_one, 0, []), (matrix_three, 100, [1, 2, 3, 4, 5])]
+    for m, cut, want in cases:
+        assert (onp.below_min_mean_expr_cutoff(m, cut) + 1).tolist() == want, (cut, want)
+
+
 def test_gene_filter_restatements():
     """R/inferCNV_ops.R:2154-2163, 2182-2184 on a hand-checkable matrix."""
     x = np.array([[0, 0, 0, 0], [1, 0, 0, 0], [2, 2, 2, 2], [0, 1, np.nan, 1], [0.3, 0.1, 0.0, 0.0]], dtype=np.float64)
