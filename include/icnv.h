@@ -190,7 +190,8 @@ int icnv_ingest_counts_dev(const icnv_counts *cnt, int64_t G, int64_t C, double 
                            double normalize_factor, int32_t *keep_idx_host, int64_t *G_out, double *expr_out_dev,
                            double *factor_used, void *stream);
 /* Split phases for a cell-sharded caller (infercnv_amd/sharded.py: ShardedIngest):
- *   gene_stats   stats2G_dev = [G sums of the counts | G numbers of cells with count > 0] as doubles -> all-reduce(sum)
+ *   gene_stats   stats2G_dev = [G sums of the counts | G numbers of cells with count > 0] as doubles -> all-reduce(sum);
+ *                a negative entry (R's NA_integer_ is INT_MIN) is ICNV_ERR_ARG: counts must be >= 0
  *   select       the filter decision from the all-reduced statistics (host arithmetic, the same on every rank)
  *   col_sums     colSums over the kept genes (keep_mask_dev: G bytes, 1 = kept)     -> all-gather, median = the factor
  *   apply        expr_out[j, c] = log2(count[keep[j], c] / col_sum[c] * factor + 1), the reference's operation order */

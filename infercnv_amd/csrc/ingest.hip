@@ -27,7 +27,7 @@ constexpr int IG_TILE = 256;
 
 // dense: part_sum[sp*G + g] = sum over the sp-th slice of cells of x[g, c] (int64, exact); part_nnz counts x > 0
 __global__ void ingest_gene_stats_dense_kernel(const int32_t *__restrict__ x, int G, int64_t C, int nsplit,
-                                               long long *__restrict__ part_sum, int32_t *__restrict__ part_nnz) {
+                                               long long *__restrict__ part_sum, int32_t *__restrict__ part_nnz, int32_t *__restrict__ neg_flag) {
     const int g = blockIdx.x * IG_TILE + threadIdx.x;
     const int sp = blockIdx.y;
     if (g >= G) return;
@@ -41,6 +41,7 @@ __global__ void ingest_gene_stats_dense_kernel(const int32_t *__restrict__ x, in
         const int32_t v = __builtin_nontemporal_load(x + c * (int64_t)G + g);
         s += v;
         n += (v > 0) ? 1 : 0;
+        if (v < 0) atomicOr(neg_flag, 1);   // not a count (R's NA_integer_ is INT_MIN): the caller is told, nothing is computed from it
     }
     part_sum[(int64_t)sp * G + g] = s;
     part_nnz[(int64_t)sp * G + g] = n;
@@ -61,10 +62,12 @@ __global__ void ingest_gene_stats_finish_kernel(const long long *__restrict__ pa
 }
 // CSC: one thread per stored entry; integer atomics are exact and commute -> deterministic
 __global__ void ingest_gene_stats_csc_kernel(const int32_t *__restrict__ rowidx, const int32_t *__restrict__ vals, int64_t nnz,
-                                             unsigned long long *__restrict__ sums, unsigned long long *__restrict__ cnt) {
+                                             unsigned long long *__restrict__ sums, unsigned long long *__restrict__ cnt,
+                                             int32_t *__restrict__ neg_flag) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) {
         const int32_t v = vals[i];
         const int32_t r = rowidx[i];
+        if (v < 0) atomicOr(neg_flag, 1);
         atomicAdd(&sums[r], (unsigned long long)(long long)v);
         if (v > 0) atomicAdd(&cnt[r], 1ull);
     }
@@ -176,6 +179,11 @@ int icnv_ingest_gene_stats_dev(const icnv_counts *cnt, int64_t G, int64_t C, dou
         ICNV_HIP(hipMemsetAsync(stats2G_dev, 0, (size_t)2 * G * sizeof(double), s));
         return ICNV_OK;
     }
+    DevBuf dneg;
+    if ((rc = dneg.alloc(sizeof(int32_t)))) return rc;
+    ICNV_HIP(hipMemsetAsync(dneg.p, 0, sizeof(int32_t), s));
+    int32_t neg = 0;
+    {
     KernelTimer kt("ingest_gene_stats", s);
     if (cnt->dense) {
         const int tiles = (int)((G + IG_TILE - 1) / IG_TILE);
@@ -184,10 +192,11 @@ int icnv_ingest_gene_stats_dev(const icnv_counts *cnt, int64_t G, int64_t C, dou
         DevBuf ps, pn;
         if ((rc = ps.alloc((size_t)ns * G * sizeof(long long))) || (rc = pn.alloc((size_t)ns * G * sizeof(int32_t)))) return rc;
         hipLaunchKernelGGL(ingest_gene_stats_dense_kernel, dim3(tiles, (unsigned)ns), dim3(IG_TILE), 0, s, cnt->dense, (int)G, C, (int)ns,
-                           ps.as<long long>(), pn.as<int32_t>());
+                           ps.as<long long>(), pn.as<int32_t>(), dneg.as<int32_t>());
         hipLaunchKernelGGL(ingest_gene_stats_finish_kernel, dim3(tiles), dim3(IG_TILE), 0, s, ps.as<long long>(), pn.as<int32_t>(), (int)G,
                            (int)ns, stats2G_dev);
         ICNV_HIP(hipGetLastError());
+        ICNV_HIP(hipMemcpyAsync(&neg, dneg.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         ICNV_HIP(hipStreamSynchronize(s));   // the partial buffers go back to the pool
     } else {
         DevBuf acc;
@@ -195,12 +204,15 @@ int icnv_ingest_gene_stats_dev(const icnv_counts *cnt, int64_t G, int64_t C, dou
         ICNV_HIP(hipMemsetAsync(acc.p, 0, (size_t)2 * G * sizeof(unsigned long long), s));
         const int grid = (int)std::min<int64_t>((cnt->nnz + 255) / 256, (int64_t)num_cus() * 16);
         hipLaunchKernelGGL(ingest_gene_stats_csc_kernel, dim3(grid), dim3(256), 0, s, cnt->rowidx, cnt->vals, cnt->nnz,
-                           acc.as<unsigned long long>(), acc.as<unsigned long long>() + G);
+                           acc.as<unsigned long long>(), acc.as<unsigned long long>() + G, dneg.as<int32_t>());
         hipLaunchKernelGGL(ingest_stats_from_i64_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, acc.as<unsigned long long>(),
                            acc.as<unsigned long long>() + G, (int)G, stats2G_dev);
         ICNV_HIP(hipGetLastError());
+        ICNV_HIP(hipMemcpyAsync(&neg, dneg.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         ICNV_HIP(hipStreamSynchronize(s));
     }
+    }
+    if (neg) ICNV_FAIL(ICNV_ERR_ARG, "icnv_counts: negative value in the count matrix (an NA_integer_ from R?): counts must be >= 0");
     return ICNV_OK;
 }
 

@@ -568,6 +568,13 @@ def test_ingest_from_integer_counts_equals_the_step_functions(dev, run_inputs, g
     # every gene removed is the reference's stop(998)
     with pytest.raises(Exception, match="All genes removed"):
         ops.ingest_counts(obj, 1e9, 0)
+    # a negative entry is not a count (R's NA_integer_ is INT_MIN): refused, dense and CSC
+    bad = x.copy()
+    bad[17, 3] = -2147483648
+    for m in (bad, sp.csc_matrix(bad)):
+        with pytest.raises(Exception, match="negative value in the count matrix"):
+            ops.ingest_counts(InfercnvObject(expr_data=m, gene_order=obj.gene_order, reference_grouped_cell_indices=run_inputs["refs"],
+                                             observation_grouped_cell_indices=run_inputs["obs"]), 1, 3)
     # device-resident flavour, explicit factor, no filters
     t = torch.from_numpy(np.ascontiguousarray(x.T.astype(np.int32))).cuda()
     e, keep, used = dev.ingest_counts(dev.DeviceCounts(x.shape[0], x.shape[1], dense=t), normalize_factor=1e5)
