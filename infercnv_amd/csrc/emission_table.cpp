@@ -101,10 +101,12 @@ int build_emission_table(int K, const double *mean, double sd, int max_intervals
     out = EmisTable();
     out.K = K;
     out.n_seg = K + 1;
-    // interval width sd / 12: eps_tab 4e-14 for the i6 model (sd / 16: 9e-15, sd / 8: 4e-13 -- all far inside the 2e-12
-    // budget); the wider the intervals, the more lanes of a wavefront share a record (LDS broadcast instead of a bank
-    // conflict): 2.5 % on the launch against sd / 16, nothing more at sd / 8
-    out.width_sigma = 1.0 / 12.0;
+    // Degree 4 on intervals of sd / 15: eps_tab 1.7e-12 for the i6 and i3 models, inside the 2e-12 budget (sd / 14: 2.5e-12,
+    // sd / 12: 5.6e-12).  Rounds 1-2 used degree 5 on sd / 12 (4e-14; sd / 16: 9e-15, sd / 8: 4e-13): one fused multiply-add per
+    // state and gene more, 240- instead of 208-byte records.  The decision band 4 (n + 1) (eps_tab + 2 eps_spec + 6 u B) is
+    // dominated by its other two terms, so the coarser table widens it by a third; the launch is 4 % shorter (A/B on one box,
+    // profiles/r03_viterbi_degree4.txt), and 727 instead of 629 intervals fit the LDS, so smaller sd stay eligible.
+    out.width_sigma = 1.0 / EMIS_WIDTH_DIV;
     const double w_target = out.width_sigma * sd;
 
     // inner segments [mean_k, mean_{k+1}): whole numbers of intervals
@@ -227,7 +229,7 @@ int build_emission_table(int K, const double *mean, double sd, int max_intervals
     }
     out.eps_tab = (double)(1.5L * max_err) + 1e-15;
     out.s_max = (double)s_max * 1.01 + 0.01;
-    if (!(out.eps_tab <= 2e-12)) { *why = "table accuracy target (2e-12) not met for these parameters"; return 1; }
+    if (!(out.eps_tab <= EMIS_EPS_MAX)) { *why = "table accuracy target (2e-12) not met for these parameters"; return 1; }
     return 0;
 }
 

@@ -19,7 +19,18 @@
 
 namespace icnv {
 
-constexpr int EMIS_DEG = 5;          // polynomial degree
+#ifndef ICNV_EMIS_DEG
+#define ICNV_EMIS_DEG 4
+#endif
+#ifndef ICNV_EMIS_EPS_MAX
+#define ICNV_EMIS_EPS_MAX 2e-12
+#endif
+constexpr int EMIS_DEG = ICNV_EMIS_DEG;   // polynomial degree (4 in the product; scripts/viterbi_variants.py builds others)
+#ifndef ICNV_EMIS_WIDTH_DIV
+#define ICNV_EMIS_WIDTH_DIV 15.0
+#endif
+constexpr double EMIS_WIDTH_DIV = ICNV_EMIS_WIDTH_DIV;   // interval width = sd / this
+constexpr double EMIS_EPS_MAX = ICNV_EMIS_EPS_MAX;   // a table whose certified error exceeds this is refused
 constexpr int EMIS_MAX_SEG = 8;      // K + 1 segments, K <= 6 (one spare)
 
 struct EmisSegment {                 // 32 bytes, one per segment, read by the kernel with one 16-B + one 8-B LDS load

@@ -36,6 +36,7 @@
 
 #include "icnv_internal.h"
 #include "emission_table.h"
+#include <type_traits>
 #include "viterbi_trace.h"
 
 #pragma clang fp contract(off)
@@ -47,12 +48,14 @@ namespace {
 // Launch geometry and chunk sizes (measured choices; experiments with other values are built as replacement translation
 // units by scripts/viterbi_variants.py / scripts/build_variant.sh, never by -D switches on this file).
 // Round 3: 1024 threads = FOUR wavefronts per SIMD at <= 128 registers.  Rounds 1-2 ran 512 threads (2 per SIMD, 256
-// registers): with the scheduler free to request the fifteen coefficient gathers of several genes at once the gene loop
+// registers): with the scheduler free to request all coefficient gathers of several genes at once the gene loop
 // needs ~250 registers, and every larger workgroup spilled (768 threads: 3.0-3.3 ms against 2.32).  The register-lean gene
 // step below (bookkeeping first, scores gathered and consumed in two batches behind fake dependences, the launch
 // descriptor re-read from the kernel-argument segment instead of living in ~60 scalar registers that spill into VGPR lanes)
 // fits 128 registers without scratch in the gene loop: 512 threads 2.47 ms (the serialisation costs when only two
-// wavefronts hide it), 768 threads 2.22, 1024 threads 2.19 ms -- the vector and the LDS pipe are then both ~70 % busy.
+// wavefronts hide it), 768 threads 2.22, 1024 threads 2.19 ms -- the vector pipe is then 81 % busy, the LDS pipe 71 %.
+// What is left is the instruction count: degree-4 polynomials on sd / 15 intervals (emission_table.cpp) instead of degree 5
+// on sd / 12 take five multiply-adds and two 16-byte gathers per gene off it (96 vector + 16 LDS instructions): -4 %.
 constexpr int FAST_NT = 1024;
 constexpr int FAST_TG = 8;    // traceback group of the non-uniform-alignment walk: 2 x 8 back-pointer lines in flight (registers)
 constexpr int FAST_TB = 16;   // genes per block of the uniform-alignment traceback (16: 2.54 ms, 32: 2.58, 64: 2.61)
@@ -60,9 +63,9 @@ constexpr int FAST_CH = 8;    // genes per observation chunk: 64 bytes per lane 
 constexpr int NCF = EMIS_DEG + 1;
 constexpr int SEG_DOUBLES = EMIS_MAX_SEG * 4 + EMIS_MAX_CELLS * 2;   // segment records + lookup cells at the start of the LDS image
 constexpr int CELL_OFF = EMIS_MAX_SEG * 4;
-// coefficient record of one interval: (K - 1) x 6 doubles (scores relative to state 1, whose row is not stored)
-// padded to an ODD number of 16-byte bank groups (the lanes' random intervals then spread over all LDS banks) --
-// the states sit at immediate offsets of one address
+// coefficient record of one interval: (K - 1) x NCF doubles (scores relative to state 1, whose row is not stored),
+// state after state, padded to an ODD number of 16-byte bank groups (the lanes' random intervals then spread over all LDS
+// banks; K = 6: 25 doubles -> 208 bytes) -- read as 16-byte pairs at immediate offsets of one address
 constexpr int rec_doubles(int K) { return (((K - 1) * NCF / 2) | 1) * 2; }
 typedef double dbl2_t __attribute__((ext_vector_type(2)));
 
@@ -218,20 +221,24 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             tn = (u - (double)fi) - 0.5;
             idx = (int)__umul24((uint32_t)(sn.x + fi), (uint32_t)REC);   // interval numbers are far below 2^24
         };
+        // Coefficients [f0, f1) of the record at cq (flat index f = (state - 1) * NCF + j, c0 first) as 16-byte pairs: for
+        // NCF = 6 a state is three pairs of its own; an odd NCF makes pairs straddle two states (all indices are static)
+        auto horner = [&](const dbl2_t *q, int p0, int base, double tn) -> double {
+            auto cf = [&](int f) -> double { return (f & 1) ? q[f / 2 - p0].y : q[f / 2 - p0].x; };
+            double p = cf(base + NCF - 1);
+#pragma unroll
+            for (int j = NCF - 2; j >= 0; --j) p = __builtin_fma(p, tn, cf(base + j));
+            return p;
+        };
         auto poly = [&](int idx, double tn, double (&sc)[K]) {
             const double *c = coef + idx;
             sc[0] = 0.0;   // the table holds s_k - s_1: a term common to all states changes no decision
+            constexpr int NP = ((K - 1) * NCF + 1) / 2;
+            dbl2_t q[NP];
 #pragma unroll
-            for (int k = 1; k < K; ++k) {
-                const double2 c01 = *reinterpret_cast<const double2 *>(c + (k - 1) * NCF);
-                const double2 c23 = *reinterpret_cast<const double2 *>(c + (k - 1) * NCF + 2);
-                const double2 c45 = *reinterpret_cast<const double2 *>(c + (k - 1) * NCF + 4);
-                double p = __builtin_fma(c45.y, tn, c45.x);
-                p = __builtin_fma(p, tn, c23.y);
-                p = __builtin_fma(p, tn, c23.x);
-                p = __builtin_fma(p, tn, c01.y);
-                sc[k] = __builtin_fma(p, tn, c01.x);
-            }
+            for (int p = 0; p < NP; ++p) q[p] = *reinterpret_cast<const dbl2_t *>(c + 2 * p);
+#pragma unroll
+            for (int k = 1; k < K; ++k) sc[k] = horner(q, 0, (k - 1) * NCF, tn);
         };
         // One step of the recurrence, on nu~_i = nu_i - i b (a shift common to all states: every decision and the
         // final arg-max are those of nu): nu~'_k = max(nu~_k, m1 + (a - b)) + s_k, m1 = max_j nu~_j.  Row k keeps itself
@@ -246,7 +253,7 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         // candidates e_k, the keep bits, the near-top word -- runs first, then the K - 1 score polynomials are gathered and
         // consumed in two batches (states 1-2, states 3-5), every score folded into its row of the recurrence as soon as it
         // exists.  Fake dependences (empty asm) keep batch B's gathers behind batch A's arithmetic and a gene behind its
-        // predecessor: left to itself the scheduler requests all fifteen gathers of several genes at once (60 registers
+        // predecessor: left to itself the scheduler requests all gathers of several genes at once (50-60 registers
         // per gene) -- the right thing with 256 registers, spills with 168 or 128.
         auto gene = [&](double xv, int i) {
             asm volatile("" : "+v"(xv) : "v"(nu[K - 1]));      // this gene starts when the previous one's last row is done
@@ -283,25 +290,21 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             bpc[i * 64] = (uint16_t)word;
             nu[0] = max_raw(nu[0], c);
             constexpr int KA = (K - 1) < 2 ? (K - 1) : 2;    // states of batch A
-            auto score_rows = [&](int k0, int k1, int idxq) {
+            auto score_rows = [&](auto k0c, auto k1c, int idxq) {
+                constexpr int k0 = decltype(k0c)::value, k1 = decltype(k1c)::value;
+                constexpr int p0 = ((k0 - 1) * NCF) / 2, p1 = (k1 * NCF + 1) / 2;   // pairs that hold the states k0..k1
                 const double *cq = coef + idxq;
+                dbl2_t q[p1 - p0];
 #pragma unroll
-                for (int k = k0; k <= k1; ++k) {
-                    const double2 c01 = *reinterpret_cast<const double2 *>(cq + (k - 1) * NCF);
-                    const double2 c23 = *reinterpret_cast<const double2 *>(cq + (k - 1) * NCF + 2);
-                    const double2 c45 = *reinterpret_cast<const double2 *>(cq + (k - 1) * NCF + 4);
-                    double p = __builtin_fma(c45.y, tn, c45.x);
-                    p = __builtin_fma(p, tn, c23.y);
-                    p = __builtin_fma(p, tn, c23.x);
-                    p = __builtin_fma(p, tn, c01.y);
-                    nu[k] = max_raw(nu[k], c) + __builtin_fma(p, tn, c01.x);
-                }
+                for (int p = p0; p < p1; ++p) q[p - p0] = *reinterpret_cast<const dbl2_t *>(cq + 2 * p);
+#pragma unroll
+                for (int k = k0; k <= k1; ++k) nu[k] = max_raw(nu[k], c) + horner(q, p0, (k - 1) * NCF, tn);
             };
-            score_rows(1, KA, idx);
+            score_rows(std::integral_constant<int, 1>{}, std::integral_constant<int, KA>{}, idx);
             if (K - 1 > KA) {
                 int idxb = idx;
                 asm volatile("" : "+v"(idxb) : "v"(nu[KA]));   // batch B's gathers behind batch A's arithmetic
-                score_rows(KA + 1, K - 1, idxb);
+                score_rows(std::integral_constant<int, (K - 1 > KA ? KA + 1 : 1)>{}, std::integral_constant<int, K - 1>{}, idxb);
             }
         };
         {
