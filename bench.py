@@ -400,24 +400,25 @@ def main():
         if "viterbi" in roof:
             st = device.viterbi_last_stats()
             roof["viterbi"]["note"] = (f"certified fast path ({st['path']}; {st['flagged']} of {st['sequences']} sequences redone exactly): "
-                                       "table-driven emission scores (degree-4 polynomials) + max-plus recurrence, 96 vector + 16 LDS-gather + 20 other instructions "
-                                       "per gene and wavefront in the forward pass (108 vector instructions per gene with the traceback), every lane "
-                                       "streaming its own column, four wavefronts per SIMD; hardware counters (profiles/r03_pmc_viterbi_fast.txt): "
-                                       "vector pipes busy 75-80 % of the launch, LDS 70 % (a third of that bank conflicts of the random coefficient "
-                                       "gathers) -- fp64 vector issue paces it, no MFMA-shaped work")
+                                       "table-driven emission scores (degree-4 polynomials on a uniform grid) + max-plus recurrence, 89 vector + 14 LDS-gather + "
+                                       "18 other instructions per gene and wavefront in the forward pass (101 vector instructions per gene with the "
+                                       "traceback), every lane streaming its own column, four wavefronts per SIMD; hardware counters "
+                                       "(profiles/r03_pmc_viterbi_fast.txt): vector pipes busy 72 % of the launch, LDS 71 % -- the 25 coefficients per lane "
+                                       "and gene are 100 of the 139 cycles a gene step takes on a CU: LDS bandwidth and fp64 issue pace it together, no "
+                                       "MFMA-shaped work")
         if "viterbi" in roof:
             # second ceiling of the Viterbi (SURVEY.md 8d asks for HBM GB/s *and* the fp64 rate): its forward pass issues
-            # 108 vector instructions per gene and wavefront (SQ_INSTS_VALU of the launch / gene steps; 96 of them in the forward
+            # 101 vector instructions per gene and wavefront (SQ_INSTS_VALU of the launch / gene steps; 89 of them in the forward
             # pass by static count, scripts/vf_asm_stats.py), every one of them 4 cycles of a 16-lane SIMD; 256 CUs x 4 SIMDs at
             # the 2.4 GHz peak clock
-            instr = 108.0
+            instr = 101.0
             ceil_ms = (G * C_local / 64.0) * instr * 4.0 / (256 * 4) / 2.4e9 * 1e3
             roof["viterbi"]["fp64_issue"] = {"vector_instr_per_gene_wavefront": instr, "ceiling_ms": ceil_ms,
                                              "frac": ceil_ms / kernels["viterbi"]["avg_ms"],
                                              "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TF,
                                              "note": "share of the launch the vector pipes would need at full issue rate and the 2.4 GHz peak "
                                                      "clock; at the ~2.05 GHz the chip holds under this load the counters show the pipes "
-                                                     "busy 75-80 % of the launch (DESIGN.md K4b)"}
+                                                     "busy 72 % of the launch, next to an LDS pipe that is 71 % busy (DESIGN.md K4b)"}
         dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
         if "chain_apply" in roof:
             moved = 3 * 8 * G * n_main            # one matrix read, two written (refined below by the counters when present)

@@ -256,9 +256,10 @@ int icnv_viterbi_cells_dev(const double *expr, uint8_t *states, int64_t G, int64
  *   icnv_viterbi_last_stats out4 = {path of the calling thread's device's last call (0 exact / 1 fast / 2 fast,
  *                           last column batch recomputed by the exact kernel), sequences, flagged sequences of
  *                           the last column batch, table intervals}; synchronises with that call
- *   icnv_hmm_emission_table host-only: the table for (K, mean, sd); meta8 = {n_intervals, x_lo, x_hi, eps_tab,
- *                           s_max, degree, n_segments, eps_spec}; seg_out [n_seg*4] = {lo, 1/width, base, n-1};
- *                           coef_out [n_intervals*K*(degree+1)] (nullable; polynomials of s_k - s_1, row k = 0 zero);
+ *   icnv_hmm_emission_table host-only: the table for (K, mean, sd); meta8 = {n_records, x_lo, x_hi, eps_tab,
+ *                           s_max, degree, 1, eps_spec}; seg_out [4] = the uniform grid {origin, 1/width, 0, grid
+ *                           intervals - 1} (n_records = grid intervals + K: an interval with a state mean has two);
+ *                           coef_out [n_records*K*(degree+1)] (nullable; polynomials of s_k - s_1, row k = 0 zero);
  *                           eps_tab bounds |table - (s_k - s_1)|, s_max bounds |s_k| and |s_k - s_1|
  *   icnv_hmm_emission_scores host-only: which = 0 the exact scores of R/inferCNV_HMM.R:1129-1133 in 80-bit
  *                           arithmetic, which = 1 the table's values through the kernel's double operations: the

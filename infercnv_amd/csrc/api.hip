@@ -1150,9 +1150,8 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
         fa.b = b;
         fa.x_lo = vc.tab.x_lo;
         fa.x_hi = vc.tab.x_hi;
-        fa.cell_lo = vc.tab.cell_lo;
-        fa.inv_wc = vc.tab.inv_wc;
-        fa.n_cells_m1 = vc.tab.n_cells - 1;
+        fa.inv_w = vc.tab.inv_w;
+        fa.n_grid = vc.tab.n_grid;
         fa.eps = vc.tab.eps_tab + 2.0 * EPS_SPEC;   // table: s_k - s_1; the exact kernel's difference carries two of its errors
         fa.b0 = dmax + std::fabs(a);
         fa.s_step = vc.tab.s_max + std::fabs(b);
@@ -1209,12 +1208,10 @@ int icnv_hmm_emission_table(int32_t K, const double *mean, double sd, double *me
     if (build_emission_table(K, mean, sd, viterbi_fast_max_intervals(K), t, &why) != 0)
         ICNV_FAIL(ICNV_ERR_UNSUPPORTED, std::string("parameters not eligible for the fast Viterbi path: ") + why);
     meta8[0] = t.n_int; meta8[1] = t.x_lo; meta8[2] = t.x_hi; meta8[3] = t.eps_tab;
-    meta8[4] = t.s_max; meta8[5] = EMIS_DEG; meta8[6] = t.n_seg; meta8[7] = EPS_SPEC;
-    if (seg_out)
-        for (int s = 0; s < t.n_seg; ++s) {
-            seg_out[4 * s] = t.seg[s].lo; seg_out[4 * s + 1] = t.seg[s].inv_w;
-            seg_out[4 * s + 2] = t.seg[s].base; seg_out[4 * s + 3] = t.seg[s].n_m1;
-        }
+    meta8[4] = t.s_max; meta8[5] = EMIS_DEG; meta8[6] = 1; meta8[7] = EPS_SPEC;
+    if (seg_out) {   // the uniform grid as one "segment": origin, 1 / width, first record, grid intervals - 1
+        seg_out[0] = t.x_lo; seg_out[1] = t.inv_w; seg_out[2] = 0; seg_out[3] = t.n_grid - 1;
+    }
     if (coef_out) {
         if ((int64_t)t.coef.size() > coef_cap) ICNV_FAIL(ICNV_ERR_ARG, "coefficient buffer too small");
         std::copy(t.coef.begin(), t.coef.end(), coef_out);

@@ -14,10 +14,13 @@ constexpr int NC = EMIS_DEG + 1;
 constexpr long double PI_L = 3.14159265358979323846264338327950288L;
 constexpr long double SQRT1_2_L = 0.70710678118654752440084436210484904L;
 
-void exact_ld(int K, const double *mean, double sd, long double x, long double *s) {
+// side[k] = 0: |x - mean_k| (the function itself); +1 / -1: the branch x >= mean_k / x < mean_k continued analytically
+// across the mean (z may then be negative: P(Z > z) > 1/2) -- what a record of the table is fitted to
+void exact_ld(int K, const double *mean, double sd, long double x, long double *s, const int *side = nullptr) {
     long double e[8], tot = 0.0L;
     for (int k = 0; k < K; ++k) {
-        const long double z = fabsl(x - (long double)mean[k]) / (long double)sd;
+        const long double d = x - (long double)mean[k];
+        const long double z = ((side && side[k]) ? (side[k] > 0 ? d : -d) : fabsl(d)) / (long double)sd;
         const long double q = 0.5L * erfcl(z * SQRT1_2_L);
         e[k] = -1.0L / logl(q);
         tot += e[k];
@@ -68,20 +71,17 @@ void emission_scores_exact(int K, const double *mean, double sd, double x, doubl
 bool emission_table_eval(const EmisTable &t, const double *mean, double x, double *s_out) {
     if (!(x >= t.x_lo && x <= t.x_hi)) return false;
     (void)mean;
-    int ci = (int)((x - t.cell_lo) * t.inv_wc);
-    if (ci > t.n_cells - 1) ci = t.n_cells - 1;
-    const int s = t.cell[ci].seg_below + ((x >= t.cell[ci].boundary) ? 1 : 0);
-    const EmisSegment &sg = t.seg[s];
-    const double u = (x - sg.lo) * sg.inv_w;
-    int fi = (int)u;   // u >= 0: truncation == floor
-    if (fi > sg.n_m1) fi = sg.n_m1;
-    if (fi < 0) fi = 0;
-    const double tn = (u - (double)fi) - 0.5;
-    const double *c = t.coef.data() + (size_t)(sg.base + fi) * t.K * NC;
+    const double u = (x - t.x_lo) * t.inv_w;
+    const int j = (int)u;   // u >= 0: truncation == floor; j <= n_grid - 1 is a property of x_hi the builder establishes
+    if (j < 0 || j >= t.n_grid) return false;
+    const EmisGridEntry &g = t.grid[(size_t)j];
+    const int r = g.rec + ((x >= g.boundary) ? 1 : 0);
+    const double tn = (u - (double)j) - 0.5;
+    const double *c = t.coef.data() + (size_t)r * t.K * NC;
     s_out[0] = 0.0;   // the table holds the scores relative to state 1
     for (int k = 1; k < t.K; ++k) {
         double p = c[k * NC + EMIS_DEG];
-        for (int j = EMIS_DEG - 1; j >= 0; --j) p = std::fma(p, tn, c[k * NC + j]);
+        for (int j2 = EMIS_DEG - 1; j2 >= 0; --j2) p = std::fma(p, tn, c[k * NC + j2]);
         s_out[k] = p;
     }
     return true;
@@ -100,132 +100,118 @@ int build_emission_table(int K, const double *mean, double sd, int max_intervals
     static const Nodes nodes;
     out = EmisTable();
     out.K = K;
-    out.n_seg = K + 1;
-    // Degree 4 on intervals of sd / 15: eps_tab 1.7e-12 for the i6 and i3 models, inside the 2e-12 budget (sd / 14: 2.5e-12,
-    // sd / 12: 5.6e-12).  Rounds 1-2 used degree 5 on sd / 12 (4e-14; sd / 16: 9e-15, sd / 8: 4e-13): one fused multiply-add per
-    // state and gene more, 240- instead of 208-byte records.  The decision band 4 (n + 1) (eps_tab + 2 eps_spec + 6 u B) is
-    // dominated by its other two terms, so the coarser table widens it by a third; the launch is 4 % shorter (A/B on one box,
-    // profiles/r03_viterbi_degree4.txt), and 727 instead of 629 intervals fit the LDS, so smaller sd stay eligible.
+    // Degree 4 on a grid of sd / 16: eps_tab <= 1.4e-12 over 400 random i3 / i6 models (sd / 15: 1.9e-12, sd / 14: 2.5e-12,
+    // sd / 12: 5.6e-12), inside the 2e-12 the builder accepts.  Rounds 1-2 used degree 5 on sd / 12 intervals anchored at
+    // the means (4e-14): one fused multiply-add per state and gene more, 240- instead of 208-byte records, two dependent
+    // LDS lookups (cell -> segment) in front of the coefficient reads instead of one.  The decision band
+    // 4 (n + 1) (eps_tab + 2 eps_spec + 6 u B) is dominated by its other two terms, so the coarser table widens it by a
+    // third (profiles/r03_viterbi_degree4.txt: -4 % on the launch, A/B on one box).
     out.width_sigma = 1.0 / EMIS_WIDTH_DIV;
-    const double w_target = out.width_sigma * sd;
-
-    // inner segments [mean_k, mean_{k+1}): whole numbers of intervals
-    int n_inner = 0;
-    int n_of[EMIS_MAX_SEG] = {0};
-    for (int s = 1; s < K; ++s) {
-        const double len = mean[s] - mean[s - 1];
-        const double nn = std::ceil(len / w_target);
-        if (!(nn >= 1.0) || nn > (double)max_intervals) { *why = "state means too far apart (in units of sd) for the table"; return 1; }
-        n_of[s] = (int)nn;
-        n_inner += n_of[s];
-    }
-    // tails: what the budget leaves, split evenly, and never further than z = 36 from the far mean
-    int n_tail = (max_intervals - n_inner) / 2;
+    const double w = out.width_sigma * sd;
+    out.inv_w = 1.0 / w;
     const double span = mean[K - 1] - mean[0];
-    const int tail_cap = (int)std::floor((36.0 * sd - span) / w_target);
+    const double inner = std::ceil(span / w) + 1.0;     // grid intervals that reach from the first to the last mean
+    if (!(inner >= 1.0) || inner + (double)K > (double)max_intervals) { *why = "state means too far apart (in units of sd) for the table"; return 1; }
+    // tails: what the budget leaves, split evenly, and never further than z = 36 from the far mean
+    int n_tail = (max_intervals - K - (int)inner) / 2;
+    const int tail_cap = (int)std::floor((36.0 * sd - span) / w);
     if (n_tail > tail_cap) n_tail = tail_cap;
     if (n_tail < 8) { *why = "not enough table budget left for the tails"; return 1; }
-    n_of[0] = n_of[K] = n_tail;
+    out.n_grid = 2 * n_tail + (int)inner;
+    out.n_int = out.n_grid + K;
+    out.x_lo = (double)((long double)mean[0] - (long double)n_tail * (long double)w);
+    // the kernel does not clamp the interval index: x_hi is the largest double whose index, computed the kernel's way, is
+    // still n_grid - 1
+    out.x_hi = (double)((long double)out.x_lo + (long double)out.n_grid * (long double)w);
+    for (int guard = 0; guard < 64 && (int)((out.x_hi - out.x_lo) * out.inv_w) > out.n_grid - 1; ++guard)
+        out.x_hi = std::nextafter(out.x_hi, -INFINITY);
+    if ((int)((out.x_hi - out.x_lo) * out.inv_w) > out.n_grid - 1 || !(out.x_hi > mean[K - 1])) { *why = "internal: table domain"; return 2; }
 
-    int base = 0;
-    for (int s = 0; s <= K; ++s) {
-        EmisSegment &sg = out.seg[s];
-        std::memset(&sg, 0, sizeof(sg));
-        if (s == 0) {
-            sg.inv_w = 1.0 / w_target;
-            sg.lo = mean[0] - (double)n_of[0] / sg.inv_w;
-        } else if (s == K) {
-            sg.inv_w = 1.0 / w_target;
-            sg.lo = mean[K - 1];
-        } else {
-            sg.lo = mean[s - 1];
-            sg.inv_w = (double)n_of[s] / (mean[s] - mean[s - 1]);
-        }
-        sg.base = base;
-        sg.n_m1 = n_of[s] - 1;
-        base += n_of[s];
+    // the grid: which interval every mean falls into (the kernel's arithmetic), the record numbers
+    int jm[8];
+    for (int k = 0; k < K; ++k) {
+        jm[k] = (int)((mean[k] - out.x_lo) * out.inv_w);
+        if (jm[k] < 0 || jm[k] >= out.n_grid) { *why = "internal: a state mean outside the grid"; return 2; }
+        if (k && jm[k] <= jm[k - 1]) { *why = "two state means share a table interval (closer than sd / 16)"; return 1; }
     }
-    out.n_int = base;
-    // the lower tail must end where segment 1 begins: (mean[0] - lo) * inv_w may round to n - epsilon or n + epsilon,
-    // the clamp of the interval index takes care of either; x_lo is nudged inside so that u >= 0 always
-    out.x_lo = std::nextafter(out.seg[0].lo, mean[0]);
-    out.x_hi = (double)((long double)out.seg[K].lo + (long double)n_of[K] / (long double)out.seg[K].inv_w);
-    out.x_hi = std::nextafter(out.x_hi, mean[K - 1]);
+    out.grid.assign((size_t)out.n_grid, EmisGridEntry{INFINITY, 0, 0});
+    for (int j = 0; j < out.n_grid; ++j) {
+        int below = 0;
+        for (int k = 0; k < K; ++k) below += (jm[k] < j) ? 1 : 0;
+        out.grid[(size_t)j].rec = j + below;
+    }
+    for (int k = 0; k < K; ++k) out.grid[(size_t)jm[k]].boundary = mean[k];
     out.coef.assign((size_t)out.n_int * K * NC, 0.0);
-    {   // segment lookup cells
-        double gap = mean[1] - mean[0];
-        for (int k = 2; k < K; ++k) gap = std::fmin(gap, mean[k] - mean[k - 1]);
-        out.cell_lo = out.seg[0].lo;
-        const double width = out.x_hi - out.cell_lo;
-        int nc = (int)std::ceil(width / (0.75 * gap)) + 1;
-        if (nc < 1) nc = 1;
-        if (nc > EMIS_MAX_CELLS) { *why = "state means too close together for the segment lookup"; return 1; }
-        out.n_cells = nc;
-        out.inv_wc = (double)nc / width;
-        for (int c = 0; c < nc; ++c) { out.cell[c].boundary = INFINITY; out.cell[c].seg_below = 0; out.cell[c].pad = 0; }
-        int ck[8];
-        for (int k = 0; k < K; ++k) {
-            ck[k] = (int)((mean[k] - out.cell_lo) * out.inv_wc);
-            if (ck[k] > nc - 1) ck[k] = nc - 1;
-            if (k && ck[k] <= ck[k - 1]) { *why = "two state means share a lookup cell"; return 1; }
-            out.cell[ck[k]].boundary = mean[k];
+
+    // the records: Chebyshev interpolation of the branch that is valid in the record's part of the interval.  Every x the
+    // kernel sends to interval j lies on one side of every mean outside it (the interval index is monotone in x and the
+    // means are placed by the same arithmetic), so each state's branch is fixed per record and analytic over the whole
+    // interval -- also where a mean sits within rounding of an interval edge
+    auto fit = [&](int j, int rec, const int *side) {
+        long double val[NC][8];
+        for (int i = 0; i < NC; ++i) {
+            const long double x = (long double)out.x_lo + (nodes.t[i] + (long double)j + 0.5L) * (long double)w;
+            exact_ld(K, mean, sd, x, val[i], side);
         }
-        for (int c = 0; c < nc; ++c) {
-            int below = 0;
-            for (int k = 0; k < K; ++k) below += (ck[k] < c) ? 1 : 0;
-            out.cell[c].seg_below = below;
+        double *c = out.coef.data() + (size_t)rec * K * NC;
+        for (int k = 0; k < K; ++k)
+            for (int q = 0; q < NC; ++q) {
+                long double acc = 0.0L;
+                for (int i = 0; i < NC; ++i) acc += nodes.vinv[q][i] * (val[i][k] - val[i][0]);
+                c[k * NC + q] = (double)acc;   // state 1's own row is all zeros
+            }
+    };
+    for (int j = 0; j < out.n_grid; ++j) {
+        int side[8], here = -1;
+        for (int k = 0; k < K; ++k) {
+            side[k] = (j > jm[k]) ? 1 : -1;
+            if (j == jm[k]) here = k;
+        }
+        const int rec = out.grid[(size_t)j].rec;
+        if (here < 0) {
+            fit(j, rec, side);
+        } else {
+            side[here] = -1;
+            fit(j, rec, side);
+            side[here] = 1;
+            fit(j, rec + 1, side);
         }
     }
 
-    // check positions: the extrema of T_{NC} (where the interpolation error peaks) and two more per gap
+    // verification through the kernel's own double arithmetic against the function itself (|x - mean_k|): the extrema of
+    // T_{NC} in every interval (where the interpolation error peaks; a check point on an edge is evaluated with whichever
+    // neighbour the kernel's index arithmetic picks), and every mean with its two neighbours
     long double chk[4 * NC + 1];
     int n_chk = 0;
-    for (int j = 0; j <= 2 * NC; ++j) chk[n_chk++] = 0.5L * cosl(PI_L * j / (2.0L * NC));
-
+    for (int q = 0; q <= 2 * NC; ++q) chk[n_chk++] = 0.5L * cosl(PI_L * q / (2.0L * NC));
     long double max_err = 0.0L, s_max = 0.0L;
-    for (int s = 0; s <= K; ++s) {
-        const EmisSegment &sg = out.seg[s];
-        for (int fi = 0; fi <= sg.n_m1; ++fi) {
-            long double val[NC][8];
-            for (int i = 0; i < NC; ++i) {
-                const long double x = (long double)sg.lo + (nodes.t[i] + (long double)fi + 0.5L) / (long double)sg.inv_w;
-                exact_ld(K, mean, sd, x, val[i]);
-            }
-            double *c = out.coef.data() + (size_t)(sg.base + fi) * K * NC;
-            for (int k = 0; k < K; ++k)
-                for (int j = 0; j < NC; ++j) {
-                    long double acc = 0.0L;
-                    for (int i = 0; i < NC; ++i) acc += nodes.vinv[j][i] * (val[i][k] - val[i][0]);
-                    c[k * NC + j] = (double)acc;   // state 1's own row is all zeros
-                }
+    auto check_at = [&](double x) -> bool {
+        if (x < out.x_lo) x = out.x_lo;
+        if (x > out.x_hi) x = out.x_hi;
+        double got[8];
+        long double want[8];
+        if (!emission_table_eval(out, mean, x, got)) return false;
+        exact_ld(K, mean, sd, (long double)x, want);
+        for (int k = 0; k < K; ++k) {
+            const long double d = want[k] - want[0];
+            const long double e = fabsl((long double)got[k] - d);
+            if (e > max_err) max_err = e;
+            if (fabsl(want[k]) > s_max) s_max = fabsl(want[k]);
+            if (fabsl(d) > s_max) s_max = fabsl(d);
         }
-    }
-    // verification through the kernel's own double arithmetic (second pass: a check point on an interval's
-    // edge is evaluated with whichever neighbour the kernel's index arithmetic picks)
-    for (int s = 0; s <= K; ++s) {
-        const EmisSegment &sg = out.seg[s];
-        for (int fi = 0; fi <= sg.n_m1; ++fi) {
-            for (int q = 0; q < n_chk; ++q) {
-                const long double xl = (long double)sg.lo + (chk[q] + (long double)fi + 0.5L) / (long double)sg.inv_w;
-                double x = (double)xl;
-                if (x < out.x_lo) x = out.x_lo;
-                if (x > out.x_hi) x = out.x_hi;
-                // stay inside this segment (the end points of inner segments are the means themselves)
-                if (s > 0 && x < mean[s - 1]) x = mean[s - 1];
-                if (s < K && x >= mean[s]) x = std::nextafter(mean[s], -INFINITY);
-                double got[8];
-                long double want[8];
-                if (!emission_table_eval(out, mean, x, got)) { *why = "internal: check point outside the domain"; return 2; }
-                exact_ld(K, mean, sd, (long double)x, want);
-                for (int k = 0; k < K; ++k) {
-                    const long double d = want[k] - want[0];
-                    const long double e = fabsl((long double)got[k] - d);
-                    if (e > max_err) max_err = e;
-                    if (fabsl(want[k]) > s_max) s_max = fabsl(want[k]);
-                    if (fabsl(d) > s_max) s_max = fabsl(d);
-                }
-            }
-        }
+        return true;
+    };
+    for (int j = 0; j < out.n_grid; ++j)
+        for (int q = 0; q < n_chk; ++q)
+            if (!check_at((double)((long double)out.x_lo + (chk[q] + (long double)j + 0.5L) * (long double)w))) { *why = "internal: check point outside the domain"; return 2; }
+    for (int k = 0; k < K; ++k) {
+        double x = mean[k];
+        for (int q = 0; q < 3; ++q) x = std::nextafter(x, -INFINITY);
+        for (int q = 0; q < 7; ++q, x = std::nextafter(x, INFINITY))
+            if (!check_at(x)) { *why = "internal: check point outside the domain"; return 2; }
+        // the far end of the shorter part of the mean's interval, where its record is used furthest from its fit's centre
+        const long double lo_edge = (long double)out.x_lo + (long double)jm[k] * (long double)w;
+        if (!check_at(std::nextafter((double)lo_edge, INFINITY)) || !check_at(std::nextafter((double)(lo_edge + (long double)w), -INFINITY))) { *why = "internal: check point outside the domain"; return 2; }
     }
     out.eps_tab = (double)(1.5L * max_err) + 1e-15;
     out.s_max = (double)s_max * 1.01 + 0.01;

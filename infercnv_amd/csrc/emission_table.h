@@ -6,8 +6,11 @@
 // kinks at every mean).  Only the differences between the states' scores enter the decisions of the
 // max-plus recurrence (a term common to all states shifts every candidate alike), so the table holds
 //     d_k(x) = s_k(x) - s_1(x) = log e_k - log e_1,   k = 2..K     (d_1 = 0 is not stored on the device)
-// for every interval of a partition of [x_lo, x_hi] whose cut points include the means: one
-// degree-DEG polynomial per state in the normalised position tn in [-0.5, 0.5] inside the interval.  It is built on the host in 80-bit long double from the
+// on a UNIFORM grid over [x_lo, x_hi] (interval j = floor((x - x_lo) / w), w = sd / 16): one degree-DEG polynomial per
+// state and grid interval in the normalised position tn in [-0.5, 0.5] inside the interval.  A grid interval that holds a
+// state mean (|x - mean_k| kinks there) carries TWO records -- the branch below the mean and the branch from the mean
+// on, each the smooth continuation of its side fitted over the whole interval -- and the kernel picks by one exact
+// comparison with the mean.  It is built on the host in 80-bit long double from the
 // mathematically exact functions (erfcl / logl) and verified against them through the very double
 // operations the kernel executes; eps_tab is the certified bound the kernel's margin test uses.
 //
@@ -27,48 +30,35 @@ namespace icnv {
 #endif
 constexpr int EMIS_DEG = ICNV_EMIS_DEG;   // polynomial degree (4 in the product; scripts/viterbi_variants.py builds others)
 #ifndef ICNV_EMIS_WIDTH_DIV
-#define ICNV_EMIS_WIDTH_DIV 15.0
+#define ICNV_EMIS_WIDTH_DIV 16.0
 #endif
 constexpr double EMIS_WIDTH_DIV = ICNV_EMIS_WIDTH_DIV;   // interval width = sd / this
 constexpr double EMIS_EPS_MAX = ICNV_EMIS_EPS_MAX;   // a table whose certified error exceeds this is refused
-constexpr int EMIS_MAX_SEG = 8;      // K + 1 segments, K <= 6 (one spare)
-
-struct EmisSegment {                 // 32 bytes, one per segment, read by the kernel with one 16-B + one 8-B LDS load
-    double lo;                       // lower end of the segment
-    double inv_w;                    // 1 / interval width inside the segment
-    int32_t base;                    // index of the segment's first interval
-    int32_t n_m1;                    // number of intervals - 1
-    int32_t pad[2];
-};
-
-// Segment lookup: [seg[0].lo, x_hi] is cut into n_cells equal cells narrower than the smallest gap between two
-// means, so a cell holds at most one mean: the segment of x is seg_below + (x >= boundary).  The cell of a mean is
-// computed with the same double operations as the cell of an observation (both are monotone in x), which makes
-// the lookup exact whatever the rounding at the cell edges.
-struct EmisCell {                    // 16 bytes
-    double boundary;                 // the mean inside this cell, +inf when there is none
-    int32_t seg_below;               // segment of the observations of this cell that are below the boundary
+// One entry per grid interval, 16 bytes, read by the kernel with one LDS load: the record of an observation x in interval
+// j is rec + (x >= boundary).  boundary = the state mean inside the interval (+inf when there is none); which interval a
+// mean falls into is computed with the very double operations the kernel applies to an observation (both are monotone
+// in x), so the lookup is exact whatever the rounding at the interval edges.
+struct EmisGridEntry {
+    double boundary;
+    int32_t rec;
     int32_t pad;
 };
-constexpr int EMIS_MAX_CELLS = 256;
 
 struct EmisTable {
     int K = 0;
-    int n_seg = 0;                   // K + 1
-    int n_int = 0;                   // total intervals
+    int n_grid = 0;                  // grid intervals
+    int n_int = 0;                   // records = n_grid + K (every mean splits its interval)
     double x_lo = 0, x_hi = 0;       // covered domain; observations outside take the exact path
+    double inv_w = 0;                // 1 / interval width: interval of x = (int)((x - x_lo) * inv_w)
     double eps_tab = 0;              // certified bound on |table value - (s_k - s_1)| over the domain
     double s_max = 0;                // max over the domain of |s_k| and |s_k - s_1| (bounds the magnitude of the DP values of both kernels)
-    double width_sigma = 0;          // target interval width in units of sd
-    EmisSegment seg[EMIS_MAX_SEG];
-    double cell_lo = 0, inv_wc = 0;  // cell index = (int)((x - cell_lo) * inv_wc), clamped to n_cells - 1
-    int n_cells = 0;
-    EmisCell cell[EMIS_MAX_CELLS];
+    double width_sigma = 0;          // interval width in units of sd
+    std::vector<EmisGridEntry> grid; // [n_grid]
     std::vector<double> coef;        // [n_int][K][EMIS_DEG + 1], c0 first; row k = 0 (state 1) is zero
 };
 
 // Build the table for K states with strictly increasing means and a shared sd.  max_intervals is the
-// LDS budget.  Returns 0 on success; non-zero (with a reason in *why) when the parameters are not
+// LDS budget in records (a grid entry rides with every record).  Returns 0 on success; non-zero (with a reason in *why) when the parameters are not
 // eligible (unsorted means, non-finite values, accuracy target not met): callers then use the exact kernel.
 int build_emission_table(int K, const double *mean, double sd, int max_intervals, EmisTable &out, const char **why);
 

@@ -199,13 +199,12 @@ struct FastViterbiArgs {
     const int32_t *chr_order;   // device, longest chromosome first
     int32_t n_chr;
     const double *table;        // device image (viterbi_fast_table_image)
-    int32_t n_int;
+    int32_t n_int, n_grid;      // records, grid intervals (emission_table.h)
     double mean[8];
     double logDelta[8];
     double a, b;                // log off-diagonal / diagonal transition probability
     double x_lo, x_hi;          // table domain
-    double cell_lo, inv_wc;     // segment lookup cells
-    int32_t n_cells_m1;
+    double inv_w;               // interval of x = (int)((x - x_lo) * inv_w)
     double eps;                 // eps_tab + eps_spec
     double b0, s_step;          // |value| bound of the recurrence: B = b0 + (n + 1) s_step
     uint16_t *bp;               // [G][ncols]
@@ -214,7 +213,7 @@ struct FastViterbiArgs {
     int32_t *flag_list;         // [2 * n_chr * ncols] (chromosome, column) pairs
 };
 size_t viterbi_fast_scratch_bytes(int32_t G, int64_t n_cols);
-size_t viterbi_fast_lds_bytes(int K, int n_int);
+size_t viterbi_fast_lds_bytes(int K, int n_int, int n_grid);
 int viterbi_fast_max_intervals(int K);
 void viterbi_fast_table_image(const EmisTable &t, std::vector<double> &img);
 int launch_viterbi_fast(const FastViterbiArgs &a, int K, hipStream_t stream);

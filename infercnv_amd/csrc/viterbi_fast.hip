@@ -61,8 +61,6 @@ constexpr int FAST_TG = 8;    // traceback group of the non-uniform-alignment wa
 constexpr int FAST_TB = 16;   // genes per block of the uniform-alignment traceback (16: 2.54 ms, 32: 2.58, 64: 2.61)
 constexpr int FAST_CH = 8;    // genes per observation chunk: 64 bytes per lane and request
 constexpr int NCF = EMIS_DEG + 1;
-constexpr int SEG_DOUBLES = EMIS_MAX_SEG * 4 + EMIS_MAX_CELLS * 2;   // segment records + lookup cells at the start of the LDS image
-constexpr int CELL_OFF = EMIS_MAX_SEG * 4;
 // coefficient record of one interval: (K - 1) x NCF doubles (scores relative to state 1, whose row is not stored),
 // state after state, padded to an ODD number of 16-byte bank groups (the lanes' random intervals then spread over all LDS
 // banks; K = 6: 25 doubles -> 208 bytes) -- read as 16-byte pairs at immediate offsets of one address
@@ -158,13 +156,13 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
     } while (0)
     extern __shared__ __attribute__((aligned(16))) double tab[];
     {
-        const int n_dbl = SEG_DOUBLES + A.n_int * rec_doubles(K);
+        const int n_dbl = A.n_int * rec_doubles(K) + 2 * A.n_grid;   // the records, then the grid entries
         const double2 *src = reinterpret_cast<const double2 *>(A.table);
         double2 *dst = reinterpret_cast<double2 *>(tab);
         for (int i = threadIdx.x; i < n_dbl / 2; i += FAST_NT) dst[i] = src[i];
     }
     __syncthreads();
-    const double *coef = tab + SEG_DOUBLES;
+    const double *coef = tab;
     const int lane = threadIdx.x & 63;
     const int64_t ncg = (A.ncols + 63) >> 6;
     const int64_t n_tasks = ncg * A.n_chr;
@@ -195,8 +193,8 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         const double thr = 4.0 * np1 * (A.eps + 0x1.8p-51 * B);
         const double ab = A.a - A.b;      // off-diagonal minus diagonal log transition
         const double t2 = -ab - thr;
-        const double x_hi_s = A.x_hi, x_lo_s = A.x_lo, cell_lo_s = A.cell_lo, inv_wc_s = A.inv_wc;
-        const int n_cells_m1_s = A.n_cells_m1;
+        const double x_hi_s = A.x_hi, x_lo_s = A.x_lo, inv_w_s = A.inv_w;
+        const double *gridp = tab + A.n_int * rec_doubles(K);   // (wave-uniform) the grid entries behind the records
 
         double nu[K];
         uint64_t seqflag = 0;   // lanes with an observation the table cannot score: the whole sequence goes to the exact kernel
@@ -208,18 +206,14 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             // clamp into the table's domain; an observation the clamp changes (NaN included) flags its sequence
             const double xs = max_raw_s(min_raw_s(xv, x_hi_s), x_lo_s);
             seqflag |= __builtin_amdgcn_ballot_w64(!(xs == xv));
-            // segment (which state means lie below xs) from the lookup cells: at most one mean per cell
-            int ci = (int)((xs - cell_lo_s) * inv_wc_s);
-            ci = ci > n_cells_m1_s ? n_cells_m1_s : ci;
-            const double2 cl = *reinterpret_cast<const double2 *>(tab + CELL_OFF + 2 * ci);   // boundary, {seg_below, pad}
-            const int seg = (int)(uint32_t)__double_as_longlong(cl.y) + ((xs >= cl.x) ? 1 : 0);
-            const double2 sg = *reinterpret_cast<const double2 *>(tab + 4 * seg);           // lo, inv_w
-            const int2 sn = *reinterpret_cast<const int2 *>(tab + 4 * seg + 2);             // base, n - 1
-            const double u = (xs - sg.x) * sg.y;
-            int fi = (int)u;
-            fi = fi > sn.y ? sn.y : fi;
-            tn = (u - (double)fi) - 0.5;
-            idx = (int)__umul24((uint32_t)(sn.x + fi), (uint32_t)REC);   // interval numbers are far below 2^24
+            // uniform grid: interval j, one 16-byte entry {the state mean inside it or +inf, the interval's record}; an
+            // interval with a mean has two records, below the mean and from the mean on (x_hi is chosen so that j needs no clamp)
+            const double u = (xs - x_lo_s) * inv_w_s;
+            const int j = (int)u;
+            const double2 ge = *reinterpret_cast<const double2 *>(gridp + 2 * j);   // boundary, {rec, pad}
+            const int r = (int)(uint32_t)__double_as_longlong(ge.y) + ((xs >= ge.x) ? 1 : 0);
+            tn = (u - (double)j) - 0.5;
+            idx = (int)__umul24((uint32_t)r, (uint32_t)REC);   // record numbers are far below 2^24
         };
         // Coefficients [f0, f1) of the record at cq (flat index f = (state - 1) * NCF + j, c0 first) as 16-byte pairs: for
         // NCF = 6 a state is three pairs of its own; an odd NCF makes pairs straddle two states (all indices are static)
@@ -398,38 +392,32 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
 size_t viterbi_fast_scratch_bytes(int32_t G, int64_t n_cols) {   // columns in blocks of 64
     return (size_t)G * (size_t)((n_cols + 63) / 64 * 64) * sizeof(uint16_t);
 }
-size_t viterbi_fast_lds_bytes(int K, int n_int) { return ((size_t)SEG_DOUBLES + (size_t)n_int * rec_doubles(K)) * sizeof(double); }
+size_t viterbi_fast_lds_bytes(int K, int n_int, int n_grid) { return ((size_t)n_int * rec_doubles(K) + 2 * (size_t)n_grid) * sizeof(double); }
 int viterbi_fast_max_intervals(int K) {
-    // leave 8 KiB of the 160 KiB for the runtime; 16-B granularity
-    return (int)((152 * 1024 - SEG_DOUBLES * sizeof(double)) / ((size_t)rec_doubles(K) * sizeof(double)));
+    // records the LDS can hold, each with its 16-byte grid entry; 8 KiB of the 160 KiB are left to the runtime
+    return (int)((152 * 1024) / ((size_t)rec_doubles(K) * sizeof(double) + 16));
 }
 
-// Device image of the table: EMIS_MAX_SEG segment records (lo, inv_w, {base, n-1}, pad) then the coefficients.
+// Device image of the table: the coefficient records, then the grid entries {boundary, {rec, 0}}.
 void viterbi_fast_table_image(const EmisTable &t, std::vector<double> &img) {
-    img.assign(SEG_DOUBLES + t.coef.size(), 0.0);
-    for (int s = 0; s < t.n_seg; ++s) {
-        img[4 * s] = t.seg[s].lo;
-        img[4 * s + 1] = t.seg[s].inv_w;
-        int32_t bn[2] = {t.seg[s].base, t.seg[s].n_m1};
-        std::memcpy(&img[4 * s + 2], bn, sizeof(bn));
-    }
-    for (int c = 0; c < t.n_cells; ++c) {
-        img[CELL_OFF + 2 * c] = t.cell[c].boundary;
-        int32_t sb[2] = {t.cell[c].seg_below, 0};
-        std::memcpy(&img[CELL_OFF + 2 * c + 1], sb, sizeof(sb));
-    }
     const int rec = rec_doubles(t.K);
-    img.resize(SEG_DOUBLES + (size_t)t.n_int * rec, 0.0);
+    img.assign((size_t)t.n_int * rec + 2 * (size_t)t.n_grid, 0.0);
     for (int i = 0; i < t.n_int; ++i)
         for (int k = 1; k < t.K; ++k)
             for (int j = 0; j < NCF; ++j)
-                img[SEG_DOUBLES + (size_t)i * rec + (k - 1) * NCF + j] = t.coef[((size_t)i * t.K + k) * NCF + j];
+                img[(size_t)i * rec + (k - 1) * NCF + j] = t.coef[((size_t)i * t.K + k) * NCF + j];
+    const size_t g0 = (size_t)t.n_int * rec;
+    for (int j = 0; j < t.n_grid; ++j) {
+        img[g0 + 2 * (size_t)j] = t.grid[(size_t)j].boundary;
+        int32_t rp[2] = {t.grid[(size_t)j].rec, 0};
+        std::memcpy(&img[g0 + 2 * (size_t)j + 1], rp, sizeof(rp));
+    }
     if (img.size() & 1) img.push_back(0.0);   // the kernel copies 16 bytes at a time
 }
 
 int launch_viterbi_fast(const FastViterbiArgs &a, int K, hipStream_t stream) {
     if (a.ncols <= 0 || a.n_chr <= 0) return ICNV_OK;
-    const size_t lds = (viterbi_fast_lds_bytes(K, a.n_int) + 15) & ~(size_t)15;
+    const size_t lds = (viterbi_fast_lds_bytes(K, a.n_int, a.n_grid) + 15) & ~(size_t)15;
     if (lds > 160 * 1024) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "emission table does not fit the LDS");
     const int64_t ncg = (a.ncols + 63) / 64;
     const int64_t tasks = ncg * a.n_chr;

@@ -64,7 +64,9 @@ def test_emission_table_meets_its_certified_bound(which):
     K = len(means)
     t = _table_meta(K, means, sd)
     rec = (((K - 1) * (t["deg"] + 1) // 2) | 1) * 16   # bytes per interval on the device (viterbi_fast.hip rec_doubles)
-    assert t["eps_tab"] <= 2e-12 and t["n_int"] * rec <= 152 * 1024
+    n_grid = int(t["seg"][0][3]) + 1
+    assert t["n_seg"] == 1 and t["n_int"] == n_grid + K                    # every state mean splits its grid interval in two records
+    assert t["eps_tab"] <= 2e-12 and t["n_int"] * rec + n_grid * 16 <= 152 * 1024
     assert t["x_lo"] < means[0] - 5 * sd and t["x_hi"] > means[-1] + 5 * sd
     rng = np.random.default_rng(11)
     # interval edges, the state means (kinks), their neighbours, and random points
