@@ -13,7 +13,7 @@ $R/scripts/ubench/stream_1r2w > $O/ubench_stream_1r2w.txt 2>&1
 $R/scripts/ubench/f64_latency > $O/ubench_f64_latency.txt 2>&1
 cp $O/ubench_stream_1r2w.txt $R/profiles/ubench_stream_1r2w.txt      # bench.py reads its ceiling from profiles/ (this run's, when present)
 timeout 300 python $R/bench.py > $O/bench_full.json 2> $O/bench_full.err
-timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof -o $TAG -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof/bench_under_rocprof.json 2> $O/prof/log.txt
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o $TAG -- python $R/bench.py --no-cpu-baseline > $O/prof/bench_under_rocprof.json 2> $O/prof/log.txt   # the default command without its CPU / host-buffer legs (they launch the same kernels on a 20 000-cell matrix and would mix into the averages)
 python $R/scripts/rocprof_summary.py $O/prof/${TAG}_results.db > $O/${TAG}_kernel_stats.txt 2>&1
 rm -f $O/prof/*.db      # (gpurun merges at most 64 MiB back: the summaries travel, the raw traces do not)
 for c in 4 5; do
