@@ -622,6 +622,7 @@ int icnv_viterbi_groups(const double *expr, uint8_t *states, int64_t G, int64_t 
 int icnv_median_filter(const double *expr_in, double *expr_out, int64_t G, int64_t C, const int32_t *chr_start, int32_t n_chr,
                        const int32_t *tile_idx, const int32_t *tile_off, int32_t n_tiles, int32_t window_size) {
     if (!expr_in || !expr_out || G < 1 || C < 0) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    if (expr_in == expr_out) ICNV_FAIL(ICNV_ERR_ARG, "median filter cannot run in place");   // (as the one-device path)
     const int nd = (int)std::max<int64_t>(1, std::min<int64_t>(g_ndev.load(), n_tiles));
     bool disjoint = true;   // tiles that share a cell keep the one-device path (its in-place order of the tiles)
     if (nd > 1) {
@@ -638,7 +639,7 @@ int icnv_median_filter(const double *expr_in, double *expr_out, int64_t G, int64
     std::vector<char> covered((size_t)std::max<int64_t>(C, 1), 0);
     for (int32_t i = 0; i < tile_off[n_tiles]; ++i) covered[(size_t)tile_idx[i]] = 1;
     for (int64_t c = 0; c < C; ++c)   // cells in no tile pass through (R/noise_reduction.R:57-86 touches the tiles only)
-        if (!covered[(size_t)c] && expr_out != expr_in) std::memcpy(expr_out + c * G, expr_in + c * G, (size_t)G * sizeof(double));
+        if (!covered[(size_t)c]) std::memcpy(expr_out + c * G, expr_in + c * G, (size_t)G * sizeof(double));
     return on_devices(nd, [&](int w, hipStream_t s, int rc0) -> int {
         if (rc0) return rc0;
         const GroupDeal &d = deal[(size_t)w];

@@ -2,7 +2,8 @@
 (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests).
 
 Cells are independent in every stage of the hot path, so each
-rank owns a contiguous block of cells and there is NO data-path collective.
+rank owns its share of the cells -- a contiguous block, a round-robin deal
+(`cyclic_cells`) or whole groups -- and there is NO data-path collective.
 The only exchange is the reference-normal statistics of the smoothing chain:
 one small all-reduce(sum) per reference round (steps 8, 12 and 22 each need
 the statistics of the *previous* stages' output on the reference cells, so the
