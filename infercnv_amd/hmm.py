@@ -37,7 +37,8 @@ def _i3HMM_get_HMM(sd_trend, t, i3_p_val=0.05, use_KS=False):
     if use_KS and sd_trend.get("KS_delta") is None:
         raise NotImplementedError(
             "use_KS=TRUE: the KS-based mean delta (get_HoneyBADGER_setGexpDev, R/inferCNV_i3HMM.R:469-493) is estimated "
-            "from rnorm() draws of R's RNG stream and stays in R; pass it as sd_trend['KS_delta']")
+            "from rnorm() draws of R's RNG stream: give its state (seed=..., as in set.seed), pass sd_trend['KS_delta'], or "
+            "use use_KS=False")
     mean_delta = sd_trend["KS_delta"] if use_KS else sd_trend["mean_delta"]
     return {"state_transitions": Pi, "delta": delta,
             "state_emission_params": {"mean": np.array([mu - mean_delta, mu, mu + mean_delta]),
@@ -330,9 +331,96 @@ def assign_HMM_states_to_proxy_expr_vals(infercnv_obj: InfercnvObject) -> Inferc
 
 
 # ------------------------------------------------------------------ i3
-def i3HMM_get_sd_trend(infercnv_obj: InfercnvObject, i3_p_val=0.05):
-    """mu / sigma / mean_delta of .i3HMM_get_sd_trend_by_num_cells_fit
-    (R/inferCNV_i3HMM.R:17-80; the KS delta is RNG-driven and stays host-side)."""
+def _ks_two_sample_p_value(x, y):
+    """`ks.test(x, y)$p.value` (two-sided) as base R computes it (src/library/stats/R/ks.test.R, src/library/stats/src/ks.c):
+    D = max |F_x - F_y|; the exact distribution of D (psmirnov2x: the lattice-path recursion) when n.x * n.y < 10000, else
+    the limiting Kolmogorov distribution at sqrt(n.x n.y / (n.x + n.y)) D (pKS2, series cut at tol = 1e-6); clipped to [0, 1].
+    Continuous samples: no ties."""
+    x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+    nx, ny = x.size, y.size
+    w = np.concatenate([x, y])
+    order = np.argsort(w, kind="stable")
+    z = np.cumsum(np.where(order < nx, 1.0 / nx, -1.0 / ny))
+    stat = float(np.abs(z).max())
+    if nx * ny < 10000:
+        m, n = (nx, ny) if nx <= ny else (ny, nx)
+        md, nd = float(m), float(n)
+        q = (0.5 + math.floor(stat * md * nd - 1e-7)) / (md * nd)
+        jn = np.arange(n + 1, dtype=np.float64) / nd
+        u = np.where(jn > q, 0.0, 1.0)
+        for i in range(1, m + 1):
+            wgt = i / (i + nd)
+            im = i / md
+            keep = ~(np.abs(im - jn) > q)
+            u0 = 0.0 if im > q else wgt * u[0]
+            # u[j] = keep[j] ? wgt * u[j] + u[j - 1] : 0, left to right (u[j - 1] is the NEW value): a first-order recurrence
+            nu = np.empty_like(u)
+            nu[0] = u0
+            acc = u0
+            for j in range(1, n + 1):
+                acc = (wgt * u[j] + acc) if keep[j] else 0.0
+                nu[j] = acc
+            u = nu
+        p = 1.0 - float(u[n])
+    else:
+        xs = math.sqrt(nx * ny / (nx + ny)) * stat
+        tol = 1e-6
+        if xs <= 0.0:
+            cdf = 0.0
+        elif xs < 1.0:
+            k_max = int(math.sqrt(2.0 - math.log(tol)))
+            zz = -(math.pi / 2.0 * math.pi / 4.0) / (xs * xs)
+            lw = math.log(xs)
+            sacc = 0.0
+            for k in range(1, k_max, 2):
+                sacc += math.exp(k * k * zz - lw)
+            cdf = sacc / 0.398942280401432677939946059934   # M_1_SQRT_2PI
+        else:
+            zz = -2.0 * xs * xs
+            sgn, k, old, new = -1.0, 1, 0.0, 1.0
+            while abs(old - new) > tol:
+                old = new
+                new += 2.0 * sgn * math.exp(zz * k * k)
+                sgn = -sgn
+                k += 1
+            cdf = new
+        p = 1.0 - cdf
+    return min(1.0, max(0.0, p))
+
+
+def get_HoneyBADGER_setGexpDev(gexp_sd, alpha, k_cells=2, n_iter=100, seed=None, rng=None):
+    """get_HoneyBADGER_setGexpDev (R/inferCNV_i3HMM.R:469-493): for dev in seq(0, sd, sd / 10) the mean over n_iter rounds of
+    ks.test(rnorm(k_cells, 0, sd), rnorm(k_cells, dev, sd))$p.value, then lm(devs ~ pvs) evaluated at pvs = alpha.  The
+    draws are R's own stream (`seed` as in set.seed(seed) right before the call; infercnv_amd/r_rng.py) -- the reference
+    never seeds, so its own value differs from session to session."""
+    from .r_rng import RRandom
+    if rng is None:
+        if seed is None:
+            raise ValueError("give the RNG state: seed (as in set.seed(seed)) or an RRandom")
+        rng = RRandom(seed)
+    k_cells = max(int(k_cells), 2)                                  # (:471-474)
+    by = gexp_sd / 10.0
+    n = int((gexp_sd - 0.0) / by + 1e-10)                           # seq.default
+    devs = np.minimum(0.0 + np.arange(n + 1, dtype=np.float64) * by, gexp_sd)
+    pvs = np.empty(devs.size)
+    for d, dev in enumerate(devs):
+        acc = []
+        for _ in range(int(n_iter)):
+            a = rng.rnorm(k_cells, 0.0, gexp_sd)                    # ks.test forces x, then y
+            b = rng.rnorm(k_cells, float(dev), gexp_sd)
+            acc.append(_ks_two_sample_p_value(a, b))
+        pvs[d] = float(np.mean(np.asarray(acc, dtype=np.longdouble)))
+    LD = np.longdouble
+    px, dy = pvs.astype(LD), devs.astype(LD)
+    mx, my = px.mean(), dy.mean()
+    slope = ((px - mx) * (dy - my)).sum() / ((px - mx) ** 2).sum()
+    return float(my - slope * mx + slope * LD(alpha))
+
+
+def i3HMM_get_sd_trend(infercnv_obj: InfercnvObject, i3_p_val=0.05, seed=None, rng=None):
+    """.i3HMM_get_sd_trend_by_num_cells_fit (R/inferCNV_i3HMM.R:17-80): mu and sigma over all values of the reference
+    cells (the device), mean_delta = |qnorm(p, 0, sigma)|, and -- when the RNG state is given (`seed` as in
+    set.seed(seed) before the call) -- KS_delta = get_HoneyBADGER_setGexpDev(sigma, p, k_cells = number of those cells)."""
     idx = (infercnv_obj.get_reference_grouped_cell_indices() if infercnv_obj.has_reference_cells()
            else np.concatenate([np.asarray(v) for v in infercnv_obj.observation_grouped_cell_indices.values()]))
     L = _lib.load()
@@ -341,12 +429,16 @@ def i3HMM_get_sd_trend(infercnv_obj: InfercnvObject, i3_p_val=0.05):
     buf = (ct.c_double * 2)()
     check(L.icnv_cells_mean_sd(x.ctypes.data_as(ct.c_void_p), x.shape[0], x.shape[1], cp, ci.size, buf))   # mean / sd on the device
     mu, sigma = float(buf[0]), float(buf[1])
-    return {"mu": mu, "sigma": sigma, "mean_delta": determine_mean_delta_via_Z(sigma, i3_p_val), "KS_delta": None}
+    ks = None
+    if seed is not None or rng is not None:
+        ks = get_HoneyBADGER_setGexpDev(sigma, i3_p_val, k_cells=int(ci.size), seed=seed, rng=rng)
+    return {"mu": mu, "sigma": sigma, "mean_delta": determine_mean_delta_via_Z(sigma, i3_p_val), "KS_delta": ks}
 
 
-def i3HMM_predict_CNV_via_HMM_on_indiv_cells(infercnv_obj, i3_p_val=0.05, sd_trend=None, t=1e-6, use_KS=False):
-    """R/inferCNV_i3HMM.R:180-225."""
-    sd_trend = sd_trend or i3HMM_get_sd_trend(infercnv_obj, i3_p_val)
+def i3HMM_predict_CNV_via_HMM_on_indiv_cells(infercnv_obj, i3_p_val=0.05, sd_trend=None, t=1e-6, use_KS=True, seed=None):
+    """R/inferCNV_i3HMM.R:180-225 (use_KS = TRUE is the reference's default; it needs the RNG state: `seed`, or a
+    sd_trend that carries KS_delta)."""
+    sd_trend = sd_trend or i3HMM_get_sd_trend(infercnv_obj, i3_p_val, seed=seed if use_KS else None)
     hmm = _i3HMM_get_HMM(sd_trend, t, i3_p_val, use_KS)
     perm, chr_start, x = _layout(infercnv_obj)
     pm = hmm["state_emission_params"]
@@ -354,8 +446,8 @@ def i3HMM_predict_CNV_via_HMM_on_indiv_cells(infercnv_obj, i3_p_val=0.05, sd_tre
     return _states_obj(infercnv_obj, st, perm)
 
 
-def _predict_groups_i3(obj, groups, i3_p_val, sd_trend, t, use_KS):
-    sd_trend = sd_trend or i3HMM_get_sd_trend(obj, i3_p_val)
+def _predict_groups_i3(obj, groups, i3_p_val, sd_trend, t, use_KS, seed=None):
+    sd_trend = sd_trend or i3HMM_get_sd_trend(obj, i3_p_val, seed=seed if use_KS else None)
     hmm = _i3HMM_get_HMM(sd_trend, t, i3_p_val, use_KS)
     perm, chr_start, x = _layout(obj)
     pm = hmm["state_emission_params"]
@@ -365,17 +457,17 @@ def _predict_groups_i3(obj, groups, i3_p_val, sd_trend, t, use_KS):
 
 
 def i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples(infercnv_obj, cluster_by_groups, i3_p_val=0.05, sd_trend=None,
-                                                     t=1e-6, use_KS=False):
+                                                     t=1e-6, use_KS=True, seed=None):
     """R/inferCNV_i3HMM.R:332-389."""
     return _predict_groups_i3(infercnv_obj, _whole_sample_groups(infercnv_obj, cluster_by_groups), i3_p_val, sd_trend,
-                              t, use_KS)
+                              t, use_KS, seed)
 
 
-def i3HMM_predict_CNV_via_HMM_on_tumor_subclusters(infercnv_obj, i3_p_val=0.05, sd_trend=None, t=1e-6, use_KS=False):
+def i3HMM_predict_CNV_via_HMM_on_tumor_subclusters(infercnv_obj, i3_p_val=0.05, sd_trend=None, t=1e-6, use_KS=True, seed=None):
     """R/inferCNV_i3HMM.R:249-308."""
     if infercnv_obj.tumor_subclusters is None:
-        return i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples(infercnv_obj, True, i3_p_val, sd_trend, t, use_KS)
-    return _predict_groups_i3(infercnv_obj, _flatten_subclusters(infercnv_obj), i3_p_val, sd_trend, t, use_KS)
+        return i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples(infercnv_obj, True, i3_p_val, sd_trend, t, use_KS, seed)
+    return _predict_groups_i3(infercnv_obj, _flatten_subclusters(infercnv_obj), i3_p_val, sd_trend, t, use_KS, seed)
 
 
 def i3HMM_assign_HMM_states_to_proxy_expr_vals(infercnv_obj: InfercnvObject) -> InfercnvObject:

@@ -104,3 +104,69 @@ class RRandom:
             m -= 1
             x[j] = x[m]
         return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# rnorm() and qnorm(): what get_HoneyBADGER_setGexpDev (R/inferCNV_i3HMM.R:469-493) draws its samples with.
+#   * src/nmath/snorm.c, norm_rand() with N01_kind = INVERSION (R's default): BIG = 2^27;
+#       u = unif_rand(); u = (int)(BIG * u) + unif_rand(); return qnorm5(u / BIG, 0, 1, TRUE, FALSE)
+#     (two uniforms per normal deviate: the first supplies the high 27 bits).
+#   * src/nmath/qnorm.c: Wichura's algorithm AS 241 (Appl. Statist. 37, 1988), routine PPND16 -- the published
+#     coefficients below; the branch R >= 4.3 adds for |log p| beyond r = 27 cannot be reached from u / BIG.
+_AS241_A = (3.3871328727963666080e0, 1.3314166789178437745e+2, 1.9715909503065514427e+3, 1.3731693765509461125e+4,
+            4.5921953931549871457e+4, 6.7265770927008700853e+4, 3.3430575583588128105e+4, 2.5090809287301226727e+3)
+_AS241_B = (1.0, 4.2313330701600911252e+1, 6.8718700749205790830e+2, 5.3941960214247511077e+3, 2.1213794301586595867e+4,
+            3.9307895800092710610e+4, 2.8729085735721942674e+4, 5.2264952788528545610e+3)
+_AS241_C = (1.42343711074968357734e0, 4.63033784615654529590e0, 5.76949722146069140550e0, 3.64784832476320460504e0,
+            1.27045825245236838258e0, 2.41780725177450611770e-1, 2.27238449892691845833e-2, 7.74545014278341407640e-4)
+_AS241_D = (1.0, 2.05319162663775882187e0, 1.67638483018380384940e0, 6.89767334985100004550e-1, 1.48103976427480074590e-1,
+            1.51986665636164571966e-2, 5.47593808499534494600e-4, 1.05075007164441684324e-9)
+_AS241_E = (6.65790464350110377720e0, 5.46378491116411436990e0, 1.78482653991729133580e0, 2.96560571828504891230e-1,
+            2.65321895265761230930e-2, 1.24266094738807843860e-3, 2.71155556874348757815e-5, 2.01033439929228813265e-7)
+_AS241_F = (1.0, 5.99832206555887937690e-1, 1.36929880922735805310e-1, 1.48753612908506148525e-2, 7.86869131145613259100e-4,
+            1.84631831751005468180e-5, 1.42151175831644588870e-7, 2.04426310338993978564e-15)
+
+
+def _horner(c, r):
+    p = np.full_like(r, c[-1])
+    for v in c[-2::-1]:
+        p = p * r + v
+    return p
+
+
+def qnorm(p):
+    """qnorm(p) (lower tail, mean 0, sd 1) by AS 241 / PPND16, vectorised; p in (0, 1)."""
+    p = np.asarray(p, dtype=np.float64)
+    q = p - 0.5
+    out = np.empty_like(p)
+    mid = np.abs(q) <= 0.425
+    r = 0.180625 - q[mid] * q[mid]
+    out[mid] = q[mid] * _horner(_AS241_A, r) / _horner(_AS241_B, r)
+    rest = ~mid
+    if rest.any():
+        qq = q[rest]
+        r = np.sqrt(-np.log(np.where(qq < 0, p[rest], 1.0 - p[rest])))
+        val = np.empty_like(r)
+        lo = r <= 5.0
+        rl = r[lo] - 1.6
+        val[lo] = _horner(_AS241_C, rl) / _horner(_AS241_D, rl)
+        rh = r[~lo] - 5.0
+        val[~lo] = _horner(_AS241_E, rh) / _horner(_AS241_F, rh)
+        out[rest] = np.where(qq < 0, -val, val)
+    return out
+
+
+def _norm_rand(self, n: int) -> np.ndarray:
+    """n draws of norm_rand() (INVERSION)."""
+    u = self.unif_rand(2 * int(n)).reshape(int(n), 2)
+    big = 134217728.0
+    return qnorm((np.floor(big * u[:, 0]) + u[:, 1]) / big)
+
+
+def _rnorm(self, n: int, mean: float = 0.0, sd: float = 1.0) -> np.ndarray:
+    """rnorm(n, mean, sd) = mean + sd * norm_rand()  (src/nmath/rnorm.c)."""
+    return mean + sd * self.norm_rand(n)
+
+
+RRandom.norm_rand = _norm_rand
+RRandom.rnorm = _rnorm

@@ -187,9 +187,14 @@ class ShardedGroupHMM:
         mu, sigma = sharded_mean_sd(lambda ph, m: self.engine.moments_partial(x_local, ref_local, ph, m), self.pg, self.device)
         return mu, sigma, abs(statistics.NormalDist(0.0, sigma).inv_cdf(i3_p_val))
 
-    def run_i3(self, x_local, chr_start, groups_local, ref_local, t=1e-6, i3_p_val=0.05):
-        """i3HMM_predict_CNV_via_HMM_on_tumor_subclusters (R/inferCNV_i3HMM.R:249-308): states of this rank's cells."""
+    def run_i3(self, x_local, chr_start, groups_local, ref_local, t=1e-6, i3_p_val=0.05, ks_delta=None):
+        """i3HMM_predict_CNV_via_HMM_on_tumor_subclusters (R/inferCNV_i3HMM.R:249-308): states of this rank's cells.
+        The state means sit at mu +- delta: the Z-based delta of use_KS = FALSE, or `ks_delta` -- the KS-based one of the
+        reference's default use_KS = TRUE, a function of (sigma, p, number of reference cells, RNG state) alone
+        (hmm.get_HoneyBADGER_setGexpDev), so every rank computes the same value from the all-reduced sigma."""
         mu, sigma, delta = self.i3_params(x_local, ref_local, i3_p_val)
+        if ks_delta is not None:
+            delta = float(ks_delta(sigma)) if callable(ks_delta) else float(ks_delta)
         Pi = np.full((3, 3), t)
         np.fill_diagonal(Pi, 1.0 - 5.0 * t)               # the reference's 1 - 5t diagonal with three states (:108-112)
         d0 = np.array([t, 1.0 - 5.0 * t, t])

@@ -20,6 +20,8 @@ Pinning status
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 
 LD = np.longdouble  # R accumulates sum()/mean() in long double (x86-64: 80-bit)
@@ -757,6 +759,78 @@ class RMersenne:
                 v &= (1 << bits) - 1
             if v < dn:
                 return v
+
+
+def r_norm_rand(rng):
+    """norm_rand() of base R with N01_kind = INVERSION (src/nmath/snorm.c): BIG = 2^27; u = unif_rand();
+    u = (int)(BIG * u) + unif_rand(); qnorm5(u / BIG, 0, 1, 1, 0).  qnorm5 is Wichura's AS 241 (PPND16) -- the routine CPython's
+    statistics.NormalDist.inv_cdf implements too, used here as the independent evaluation."""
+    import statistics
+    u = float(int(134217728.0 * rng.unif_rand())) + rng.unif_rand()
+    return statistics.NormalDist().inv_cdf(u / 134217728.0)
+
+
+def r_rnorm(rng, n, mean, sd):
+    return np.array([mean + sd * r_norm_rand(rng) for _ in range(n)], dtype=np.float64)
+
+
+def r_ks_test_p_value(x, y):
+    """ks.test(x, y)$p.value, two-sided, no ties (src/library/stats/R/ks.test.R; C code src/library/stats/src/ks.c:
+    psmirnov2x for n.x * n.y < 10000, pKS2 with tol = 1e-6 otherwise) -- scalar loops, test infrastructure."""
+    nx, ny = len(x), len(y)
+    tagged = sorted([(v, 0) for v in x] + [(v, 1) for v in y])
+    z, stat = 0.0, 0.0
+    for _, which in tagged:
+        z += (1.0 / nx) if which == 0 else (-1.0 / ny)
+        stat = max(stat, abs(z))
+    if nx * ny < 10000:
+        m, n = min(nx, ny), max(nx, ny)
+        md, nd = float(m), float(n)
+        q = (0.5 + math.floor(stat * md * nd - 1e-7)) / (md * nd)
+        u = [0.0 if (j / nd) > q else 1.0 for j in range(n + 1)]
+        for i in range(1, m + 1):
+            w = i / (i + nd)
+            u[0] = 0.0 if (i / md) > q else w * u[0]
+            for j in range(1, n + 1):
+                u[j] = 0.0 if abs(i / md - j / nd) > q else w * u[j] + u[j - 1]
+        p = 1.0 - u[n]
+    else:
+        xs = math.sqrt(nx * ny / (nx + ny)) * stat
+        if xs <= 0:
+            cdf = 0.0
+        elif xs < 1:
+            k_max = int(math.sqrt(2 - math.log(1e-6)))
+            cdf = sum(math.exp(k * k * (-(math.pi / 2 * math.pi / 4) / (xs * xs)) - math.log(xs)) for k in range(1, k_max, 2)) \
+                / 0.398942280401432677939946059934
+        else:
+            s, k, old, new = -1.0, 1, 0.0, 1.0
+            while abs(old - new) > 1e-6:
+                old = new
+                new += 2 * s * math.exp(-2.0 * xs * xs * k * k)
+                s, k = -s, k + 1
+            cdf = new
+        p = 1.0 - cdf
+    return min(1.0, max(0.0, p))
+
+
+def honeybadger_set_gexp_dev(gexp_sd, alpha, k_cells, seed, n_iter=100):
+    """get_HoneyBADGER_setGexpDev (R/inferCNV_i3HMM.R:469-493) after set.seed(seed): scalar restatement (RMersenne stream)."""
+    rng = RMersenne(seed)
+    k_cells = max(int(k_cells), 2)
+    by = gexp_sd / 10.0
+    n = int(gexp_sd / by + 1e-10)
+    devs = [min(i * by, gexp_sd) for i in range(n + 1)]
+    pvs = []
+    for dev in devs:
+        acc = 0.0
+        for _ in range(n_iter):
+            a = r_rnorm(rng, k_cells, 0.0, gexp_sd)
+            b = r_rnorm(rng, k_cells, dev, gexp_sd)
+            acc += r_ks_test_p_value(a, b)
+        pvs.append(acc / n_iter)
+    px, dy = np.asarray(pvs), np.asarray(devs)
+    slope = ((px - px.mean()) * (dy - dy.mean())).sum() / ((px - px.mean()) ** 2).sum()
+    return float(dy.mean() - slope * px.mean() + slope * alpha)
 
 
 def hspike_sd_trend_fit(expr_vals_by_level, seed, nrounds=100, max_cells=100):

@@ -211,19 +211,19 @@ def test_i3_wrappers_and_sd_trend(dev):
     Pi, delta = onp.get_HMM_i3(1e-6)
     assert abs(Pi[0].sum() - (1 - 3e-6)) < 1e-15                 # the reference's 1 - 5t diagonal with three states
     # per cell
-    got = hmm.i3HMM_predict_CNV_via_HMM_on_indiv_cells(obj, 0.05)
+    got = hmm.i3HMM_predict_CNV_via_HMM_on_indiv_cells(obj, 0.05, use_KS=False)
     want, _ = oc.viterbi_cells(pre, cs, m3, tr["sigma"], np.log(Pi), np.log(delta))
     np.testing.assert_array_equal(got.expr_data, want)
     assert set(np.unique(want)) == {1, 2, 3}
     # subclusters and whole samples: Viterbi on the group means (the GPU's own means as the oracle's input), broadcast
     xd = to_dev(pre)
-    for fn, groups in ((lambda: hmm.i3HMM_predict_CNV_via_HMM_on_tumor_subclusters(obj, 0.05),
+    for fn, groups in ((lambda: hmm.i3HMM_predict_CNV_via_HMM_on_tumor_subclusters(obj, 0.05, use_KS=False),
                         [np.asarray(v) for g in sub["subclusters"].values() for v in g.values()]),
-                       (lambda: hmm.i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples(obj, True, 0.05),
+                       (lambda: hmm.i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples(obj, True, 0.05, use_KS=False),
                         [obs[q] for q in range(4)] + list(refs)),
                        # cluster_by_groups = FALSE: the reference's c(all_observations = unlist(.), refs) makes every
                        # observation cell a sample of its own (R/inferCNV_i3HMM.R:355) -- its own profile, not a mean
-                       (lambda: hmm.i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples(obj, False, 0.05),
+                       (lambda: hmm.i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples(obj, False, 0.05, use_KS=False),
                         [np.array([c]) for c in np.concatenate(obs)] + list(refs))):
         got = fn().expr_data
         gm = to_host(dev.group_means(xd, groups))
@@ -239,12 +239,22 @@ def test_i3_wrappers_and_sd_trend(dev):
     # no subclusters -> whole samples (R/inferCNV_i3HMM.R:262-266)
     obj2 = obj.copy()
     obj2.tumor_subclusters = None
-    np.testing.assert_array_equal(hmm.i3HMM_predict_CNV_via_HMM_on_tumor_subclusters(obj2, 0.05).expr_data,
-                                  hmm.i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples(obj, True, 0.05).expr_data)
-    # the KS-based delta draws from R's RNG stream (R/inferCNV_i3HMM.R:469-493): refused, not a TypeError
+    np.testing.assert_array_equal(hmm.i3HMM_predict_CNV_via_HMM_on_tumor_subclusters(obj2, 0.05, use_KS=False).expr_data,
+                                  hmm.i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples(obj, True, 0.05, use_KS=False).expr_data)
+    # use_KS = TRUE is the reference's default: the KS-based delta draws from R's RNG stream (R/inferCNV_i3HMM.R:469-493), so
+    # without its state the call is refused (not a TypeError) ...
     with pytest.raises(NotImplementedError, match="use_KS"):
-        hmm.i3HMM_predict_CNV_via_HMM_on_indiv_cells(obj, 0.05, use_KS=True)
-    # ... unless the caller brings the KS delta computed in R
+        hmm.i3HMM_predict_CNV_via_HMM_on_indiv_cells(obj, 0.05)
+    # ... with a seed (as in set.seed(seed) before the call) it is get_HoneyBADGER_setGexpDev on R's own stream: product
+    # against the oracle's independent restatement, k_cells = the number of reference cells
+    tr11 = hmm.i3HMM_get_sd_trend(obj, 0.05, seed=11)
+    ks = onp.honeybadger_set_gexp_dev(tr["sigma"], 0.05, len(np.concatenate(refs)), 11)
+    assert abs(tr11["KS_delta"] - ks) < 1e-12 and 0.0 < ks < 3 * tr["sigma"]
+    m3k = np.array([tr["mu"] - ks, tr["mu"], tr["mu"] + ks])
+    want, _ = oc.viterbi_cells(pre, cs, m3k, tr["sigma"], np.log(Pi), np.log(delta))
+    np.testing.assert_array_equal(hmm.i3HMM_predict_CNV_via_HMM_on_indiv_cells(obj, 0.05, seed=11).expr_data, want)
+    np.testing.assert_array_equal(hmm.i3HMM_predict_CNV_via_HMM_on_indiv_cells(obj, 0.05, sd_trend=tr11).expr_data, want)
+    # ... or the caller brings the KS delta computed in R
     tr_ks = dict(tr, KS_delta=0.07)
     got = hmm.i3HMM_predict_CNV_via_HMM_on_indiv_cells(obj, 0.05, sd_trend=tr_ks, use_KS=True)
     m3k = np.array([tr["mu"] - 0.07, tr["mu"], tr["mu"] + 0.07])

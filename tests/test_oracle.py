@@ -404,3 +404,36 @@ def test_r_rng_restatements_reproduce_known_r_outputs():
     got = np.concatenate([b.unif_index(37, 3000), b.unif_index(70000, 1500), b.unif_index(1000003, 800)])
     assert np.array_equal(np.array(want), got)
     assert abs(a.unif_rand() - b.unif_rand(1)[0]) == 0.0                              # and both stand at the same place afterwards
+    # rnorm (inversion: two uniforms per deviate through qnorm = AS 241): set.seed(42); rnorm(5), set.seed(123); rnorm(3),
+    # set.seed(1); rnorm(3) as every R session prints them
+    known_n = {42: [1.37095845, -0.56469817, 0.36312841, 0.63286260, 0.40426832], 123: [-0.56047565, -0.23017749, 1.55870831],
+               1: [-0.6264538, 0.1836433, -0.8356286]}
+    for seed, want in known_n.items():
+        assert np.abs(RRandom(seed).rnorm(len(want)) - want).max() < 5e-8
+        assert np.abs(onp.r_rnorm(onp.RMersenne(seed), len(want), 0.0, 1.0) - want).max() < 5e-8
+    assert np.array_equal(RRandom(9).rnorm(500, 0.3, 0.2), onp.r_rnorm(onp.RMersenne(9), 500, 0.3, 0.2))   # NumPy AS 241 == CPython's
+
+
+def test_ks_test_and_honeybadger_delta_restatements():
+    """`ks.test(x, y)$p.value` as base R computes it (exact lattice-path recursion below n.x n.y = 10000, the limiting
+    distribution with R's 1e-6 series cut above) in the product (infercnv_amd/hmm.py) and in the oracle, against SciPy's
+    independent exact algorithm and its limiting distribution; and get_HoneyBADGER_setGexpDev (R/inferCNV_i3HMM.R:469-493:
+    the KS-based mean delta of the i3 HMM, use_KS = TRUE being the reference's default) product vs oracle on one RNG stream."""
+    from scipy import stats
+    from infercnv_amd import hmm
+    assert abs(hmm._ks_two_sample_p_value([1.0, 2.0], [3.0, 4.0]) - 1.0 / 3.0) < 1e-15          # ks.test(c(1,2), c(3,4))$p.value = 0.3333
+    rng = np.random.default_rng(3)
+    for a, b in ((2, 2), (5, 7), (40, 40), (30, 60), (99, 99)):
+        x, y = rng.normal(size=a), rng.normal(0.3, 1.0, size=b)
+        want = stats.ks_2samp(x, y, method="exact").pvalue
+        assert abs(hmm._ks_two_sample_p_value(x, y) - want) < 1e-12 and abs(onp.r_ks_test_p_value(x, y) - want) < 1e-12
+    for a, b, shift in ((100, 100, 0.2), (150, 400, 0.1), (300, 300, 0.0)):
+        x, y = rng.normal(size=a), rng.normal(shift, 1.0, size=b)
+        want = stats.kstwobign.sf(np.sqrt(a * b / (a + b)) * stats.ks_2samp(x, y).statistic)
+        got = hmm._ks_two_sample_p_value(x, y)
+        assert abs(got - want) < 2e-6 and got == onp.r_ks_test_p_value(x, y)                   # (R cuts the series at 1e-6)
+    for k, seed, n_iter in ((2, 42, 30), (13, 5, 20), (42, 42, 10), (120, 7, 4)):
+        got = hmm.get_HoneyBADGER_setGexpDev(0.24, 0.05, k_cells=k, n_iter=n_iter, seed=seed)
+        want = onp.honeybadger_set_gexp_dev(0.24, 0.05, k, seed, n_iter=n_iter)
+        assert abs(got - want) < 1e-13, (k, got, want)
+    assert hmm.get_HoneyBADGER_setGexpDev(0.24, 0.05, k_cells=1, n_iter=5, seed=3) == hmm.get_HoneyBADGER_setGexpDev(0.24, 0.05, k_cells=2, n_iter=5, seed=3)
