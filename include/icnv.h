@@ -115,6 +115,11 @@ typedef struct icnv_chain_cfg {
     double sd_amplifier;     /* step 22 (clear_noise_via_ref_mean_sd)              */
     double noise_filter;     /* step 22: NaN = sd-based; else clear_noise(threshold) */
     uint32_t stage_mask;     /* ICNV_ST_* bits                                     */
+    int32_t noise_logistic;  /* step 22 with noise_logistic = TRUE (R/inferCNV_ops.R:2249-2252, 2326-2330;
+                                .apply_logistic_val_adj, R/inferCNV_heatmap.R:2791-2810): instead of the select,
+                                x <- m +- p |x - m|, p = 1 / (1 + exp(-20 (|x - m| - s))), m and s = the select's centre
+                                and half width.  Sits in the padding after stage_mask: zero-initialised
+                                configurations keep their meaning */
     const int32_t *ref_idx;  /* HOST packed LOCAL reference cell indices (or, with */
     const int32_t *ref_off;  /* no references, one group of all observation cells, */
     int32_t n_ref_grp;       /* R/inferCNV_ops.R:1686-1688); HOST n_ref_grp+1      */

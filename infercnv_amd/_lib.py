@@ -44,6 +44,7 @@ class ChainCfg(ct.Structure):
         ("sd_amplifier", ct.c_double),
         ("noise_filter", ct.c_double),
         ("stage_mask", ct.c_uint32),
+        ("noise_logistic", ct.c_int32),
         ("ref_idx", ct.POINTER(ct.c_int32)),
         ("ref_off", ct.POINTER(ct.c_int32)),
         ("n_ref_grp", ct.c_int32),
@@ -177,7 +178,7 @@ class Cfg:
     """Owns the numpy arrays a ChainCfg points to."""
 
     def __init__(self, G, C, chr_start, ref_groups, window_length=101, max_thresh=3.0, use_bounds=True,
-                 sd_amplifier=1.5, noise_filter=None, stage_mask=ST_ALL, inv_log=False):
+                 sd_amplifier=1.5, noise_filter=None, stage_mask=ST_ALL, inv_log=False, noise_logistic=False):
         self.chr_start, cp = i32(chr_start)
         idx, off = pack_groups(list(ref_groups) if ref_groups is not None else [])
         self.ref_idx, ip = i32(idx)
@@ -192,6 +193,7 @@ class Cfg:
         c.sd_amplifier = float(sd_amplifier)
         c.noise_filter = float("nan") if noise_filter is None else float(noise_filter)
         c.stage_mask = int(stage_mask)
+        c.noise_logistic = int(bool(noise_logistic))
         c.ref_idx, c.ref_off = ip, op
         c.n_ref_grp = len(off) - 1
         self.c = c

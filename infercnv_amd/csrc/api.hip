@@ -604,22 +604,28 @@ int icnv_chain_round_finish_dev(icnv_chain_t *ch, int round, void *stream) {
                                    ch->cfg.inv_log, bounds, s);
 }
 
-int icnv_chain_apply_dev(icnv_chain_t *ch, const double *expr_in, double *expr_out, double *pre_denoise,
-                         void *stream) {
-    if (!ch || !expr_in || !expr_out) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
-    hipStream_t s = (hipStream_t)stream;
-    int rc = chain_upload(ch, s);
-    if (rc) return rc;
-    if (ch->large) return large_apply(ch, expr_in, expr_out, pre_denoise, s);
+// the apply pass with the stage mask `amask` (the chain's own, or -- noise_logistic -- the chain's without step 22)
+static int chain_apply_masked(icnv_chain_t *ch, uint32_t amask, const double *expr_in, double *expr_out, double *pre_denoise,
+                              hipStream_t s) {
+    int rc;
+    if (ch->large) {
+        const uint32_t keep = ch->mask;
+        ch->mask = amask;
+        rc = large_apply(ch, expr_in, expr_out, (amask & ICNV_ST_DENOISE) ? pre_denoise : nullptr, s);
+        ch->mask = keep;
+        if (!rc && pre_denoise && !(amask & ICNV_ST_DENOISE))
+            ICNV_HIP(hipMemcpyAsync(pre_denoise, expr_out, (size_t)ch->cfg.G * ch->cfg.C * sizeof(double), hipMemcpyDeviceToDevice, s));
+        return rc;
+    }
     ChainArgs a = chain_args(ch, expr_in);
-    a.mask = ch->mask;
+    a.mask = amask;
     a.out = expr_out;
     a.pre_out = pre_denoise;
     a.cells = nullptr;
     a.n_cells = (int32_t)ch->cfg.C;
     // The reference cells continue from the cache the rounds left (same matrix, stages a prefix of this chain's);
     // all other cells run the whole chain.  The cache is consumed: an apply without fresh rounds recomputes.
-    const bool from_cache = ch->cache_in == expr_in && ch->cache_mask != 0 && (ch->cache_mask & ~ch->mask) == 0;
+    const bool from_cache = ch->cache_in == expr_in && ch->cache_mask != 0 && (ch->cache_mask & ~amask) == 0;
     const uint32_t cached = ch->cache_mask;
     ch->cache_in = nullptr;
     auto run = [&](ChainArgs args) -> int {
@@ -634,10 +640,10 @@ int icnv_chain_apply_dev(icnv_chain_t *ch, const double *expr_in, double *expr_o
         args.in_by_pos = 1;
         args.cells = ch->d_ref.as<int32_t>();
         args.n_cells = (int32_t)ch->ref_idx.size();
-        args.mask = ch->mask & ~cached;
+        args.mask = amask & ~cached;
         return launch_chain(args, MODE_APPLY, s);
     };
-    if (pre_denoise && !(ch->mask & ICNV_ST_DENOISE)) {
+    if (pre_denoise && !(amask & ICNV_ST_DENOISE)) {
         // no denoise stage: the "pre-denoise" matrix is the output itself
         a.pre_out = nullptr;
         if ((rc = run(a))) return rc;
@@ -646,6 +652,22 @@ int icnv_chain_apply_dev(icnv_chain_t *ch, const double *expr_in, double *expr_o
         return ICNV_OK;
     }
     return run(a);
+}
+
+int icnv_chain_apply_dev(icnv_chain_t *ch, const double *expr_in, double *expr_out, double *pre_denoise,
+                         void *stream) {
+    if (!ch || !expr_in || !expr_out) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = chain_upload(ch, s);
+    if (rc) return rc;
+    if ((ch->mask & ICNV_ST_DENOISE) && ch->cfg.noise_logistic) {
+        // noise_logistic = TRUE (R/inferCNV_ops.R:2249-2252, 2326-2330): the rounds have produced the centre and half width
+        // of step 22 as for the select; the matrix before step 22 comes out of the pass, the logistic adjustment
+        // (.apply_logistic_val_adj, R/inferCNV_heatmap.R:2791-2810) runs over it in place
+        if ((rc = chain_apply_masked(ch, ch->mask & ~(uint32_t)ICNV_ST_DENOISE, expr_in, expr_out, pre_denoise, s))) return rc;
+        return launch_logistic_denoise(expr_out, ch->cfg.G * ch->cfg.C, ch->d_den.as<double>(), s);
+    }
+    return chain_apply_masked(ch, ch->mask, expr_in, expr_out, pre_denoise, s);
 }
 
 int icnv_chain_get_denoise(icnv_chain_t *ch, double *mu_s, void *stream) {

@@ -84,12 +84,34 @@ __global__ void block_cell_reduce_kernel(const double *__restrict__ x, int G, co
     if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// step 22 with noise_logistic = TRUE (.apply_logistic_val_adj, R/inferCNV_heatmap.R:2791-2810), in place: den = {m, s}
+__global__ void logistic_denoise_kernel(double *__restrict__ x, int64_t n, const double *__restrict__ den) {
+    const double m = den[0], s = den[1];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = x[i];
+        const double val = fabs(v - m);
+        const double p = 1.0 / (1.0 + exp(-20.0 * (val - s)));   // .logistic(val, delta_midpt, slope = 20)
+        double r = v;
+        if (v > m) r = m + p * val;
+        else if (v < m) r = m - p * val;
+        x[i] = r;
+    }
+}
 // out[i] = x[offsets[i]]: the resampling of the hidden spike-in's residuals (R/inferCNV_HMM.R:164) on the resident matrix
 __global__ void gather_values_kernel(const double *__restrict__ x, const int64_t *__restrict__ offsets, int64_t n, double *__restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = x[offsets[i]];
 }
 
 }  // namespace
+
+int launch_logistic_denoise(double *x, int64_t n, const double *mu_s_dev, hipStream_t stream) {
+    if (n <= 0) return ICNV_OK;
+    KernelTimer kt("logistic_denoise", stream);
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)num_cus() * 16);
+    hipLaunchKernelGGL(logistic_denoise_kernel, dim3(grid), dim3(256), 0, stream, x, n, mu_s_dev);
+    ICNV_HIP(hipGetLastError());
+    return ICNV_OK;
+}
 
 int launch_gather_values(const double *x, const int64_t *offsets_dev, int64_t n, double *out, hipStream_t stream) {
     if (n <= 0) return ICNV_OK;

@@ -24,13 +24,13 @@ def _as_f(a):
 
 
 def _run_chain(obj: InfercnvObject, stage_mask, *, window_length=101, max_thresh=None, use_bounds=True,
-               sd_amplifier=1.5, noise_filter=None, want_pre_denoise=False, inv_log=False):
+               sd_amplifier=1.5, noise_filter=None, want_pre_denoise=False, inv_log=False, noise_logistic=False):
     L = _lib.load()
     perm, chr_start = obj.chr_layout()
     x = _as_f(obj.expr_data if perm is None else obj.expr_data[perm])
     G, C = x.shape
     cfg = Cfg(G, C, chr_start, obj.ref_groups_or_proxy(), window_length, max_thresh, use_bounds, sd_amplifier,
-              noise_filter, stage_mask, inv_log)
+              noise_filter, stage_mask, inv_log, noise_logistic)
     out = np.empty_like(x, order="F")
     pre = np.empty_like(x, order="F") if want_pre_denoise else None
     check(L.icnv_smooth_chain(x.ctypes.data_as(ct.c_void_p), out.ctypes.data_as(ct.c_void_p),
@@ -256,26 +256,24 @@ def invert_log2(infercnv_obj: InfercnvObject) -> InfercnvObject:
 
 # ------------------------------------------------------------------ step 22
 def clear_noise_via_ref_mean_sd(infercnv_obj: InfercnvObject, sd_amplifier=1.5, noise_logistic=False) -> InfercnvObject:
-    """R/inferCNV_ops.R:2302-2346.  hspike is NOT mirrored (commented out in the reference, :2340-2343)."""
-    if noise_logistic:
-        raise NotImplementedError("noise_logistic=TRUE lives in the plotting code (R/inferCNV_heatmap.R:2783-2810)")
-    out, _ = _run_chain(infercnv_obj, _lib.ST_DENOISE, sd_amplifier=sd_amplifier)
+    """R/inferCNV_ops.R:2302-2346.  hspike is NOT mirrored (commented out in the reference, :2340-2343).
+    noise_logistic: depress_log_signal_midpt_val around the same centre with the same half width (:2326-2330;
+    .apply_logistic_val_adj, R/inferCNV_heatmap.R:2791-2810) instead of the select."""
+    out, _ = _run_chain(infercnv_obj, _lib.ST_DENOISE, sd_amplifier=sd_amplifier, noise_logistic=noise_logistic)
     return _with_expr(infercnv_obj, out)
 
 
 def clear_noise(infercnv_obj: InfercnvObject, threshold, noise_logistic=False) -> InfercnvObject:
-    """R/inferCNV_ops.R:2232-2262 (threshold == 0 -> unchanged)."""
-    if noise_logistic:
-        raise NotImplementedError("noise_logistic=TRUE lives in the plotting code (R/inferCNV_heatmap.R:2783-2810)")
+    """R/inferCNV_ops.R:2232-2262 (threshold == 0 -> unchanged; noise_logistic as in clear_noise_via_ref_mean_sd)."""
     if threshold == 0:
         return infercnv_obj
-    out, _ = _run_chain(infercnv_obj, _lib.ST_DENOISE, noise_filter=float(threshold))
+    out, _ = _run_chain(infercnv_obj, _lib.ST_DENOISE, noise_filter=float(threshold), noise_logistic=noise_logistic)
     return _with_expr(infercnv_obj, out)
 
 
 # ------------------------------------------------------------------ fused entry
 def hip_smooth_chain(infercnv_obj: InfercnvObject, window_length=101, max_centered_threshold=3.0,
-                     sd_amplifier=1.5, noise_filter=None, denoise=True, return_hmm_input=False):
+                     sd_amplifier=1.5, noise_filter=None, denoise=True, return_hmm_input=False, noise_logistic=False):
     """Steps 8,9,10,11,12,14(,22) of run() back to back in one fused device pass
     (SURVEY.md 8b.1).  Equivalent to calling the stand-alone wrappers in run()'s
     order.  With return_hmm_input=True also returns the object before step 22
@@ -293,7 +291,8 @@ def hip_smooth_chain(infercnv_obj: InfercnvObject, window_length=101, max_center
         mask &= ~_lib.ST_MAX_THRESH
         thr = None
     out, pre = _run_chain(infercnv_obj, mask, window_length=window_length, max_thresh=thr,
-                          sd_amplifier=sd_amplifier, noise_filter=noise_filter, want_pre_denoise=return_hmm_input)
+                          sd_amplifier=sd_amplifier, noise_filter=noise_filter, want_pre_denoise=return_hmm_input,
+                          noise_logistic=noise_logistic)
     hs = None
     if infercnv_obj.hspike is not None:
         # the hspike mirrors steps 8..14 but not the denoise (reference: commented out)

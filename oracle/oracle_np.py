@@ -156,17 +156,37 @@ def clear_noise_bounds(expr, center, halfwidth):
     return out
 
 
-def clear_noise_via_ref_mean_sd(expr, ref_idx, sd_amplifier=1.5):
-    """R/inferCNV_ops.R:2302-2346 (noise_logistic=FALSE)."""
+def apply_logistic_val_adj(expr, expr_mean, delta_midpt, slope=20.0):
+    """.apply_logistic_val_adj (R/inferCNV_heatmap.R:2791-2810; .logistic, R/SplatterScrape.R:210-212) element by element:
+    val = |x - mean|, p = 1 / (1 + exp(-slope (val - midpt))), x -> mean + p val above the mean, mean - p val below it."""
+    out = np.ascontiguousarray(expr, dtype=np.float64).copy()
+    flat = out.reshape(-1)                      # a view: C-contiguous by construction
+    for i in range(flat.size):
+        x = flat[i]
+        val = abs(x - expr_mean)
+        p = 1.0 / (1.0 + math.exp(-slope * (val - delta_midpt)))
+        if x > expr_mean:
+            flat[i] = expr_mean + p * val
+        elif x < expr_mean:
+            flat[i] = expr_mean - p * val
+    return out
+
+
+def clear_noise_via_ref_mean_sd(expr, ref_idx, sd_amplifier=1.5, noise_logistic=False):
+    """R/inferCNV_ops.R:2302-2346."""
     mu, s = clear_noise_params_via_ref_mean_sd(expr, ref_idx, sd_amplifier)
+    if noise_logistic:
+        return apply_logistic_val_adj(expr, mu, s)            # depress_log_signal_midpt_val(obj, mean_ref_vals, threshold), :2326-2330
     return clear_noise_bounds(expr, mu, s)
 
 
-def clear_noise(expr, ref_idx, threshold):
-    """R/inferCNV_ops.R:2232-2262 (noise_logistic=FALSE)."""
+def clear_noise(expr, ref_idx, threshold, noise_logistic=False):
+    """R/inferCNV_ops.R:2232-2262."""
     if threshold == 0:
         return expr.copy()
     mu = float(r_mean(expr[:, np.asarray(ref_idx, dtype=np.int64)]))
+    if noise_logistic:
+        return apply_logistic_val_adj(expr, mu, threshold)   # :2249-2252
     return clear_noise_bounds(expr, mu, threshold)
 
 

@@ -47,13 +47,15 @@
 .icnv_unpermute <- function(m, lay) if (is.null(m) || !is.unsorted(lay$perm)) m else m[order(lay$perm), , drop = FALSE]
 
 .icnv_chain <- function(infercnv_obj, mask, window_length = 101L, max_thresh = NA_real_, use_bounds = TRUE,
-                        sd_amplifier = 1.5, noise_filter = NA_real_, want_pre = FALSE, inv_log = FALSE) {
+                        sd_amplifier = 1.5, noise_filter = NA_real_, want_pre = FALSE, inv_log = FALSE,
+                        noise_logistic = FALSE) {
     lay <- .icnv_chr_layout(infercnv_obj)
     ref <- .icnv_pack(.icnv_ref_groups(infercnv_obj))
     x <- .icnv_matrix(infercnv_obj, lay)
     res <- .Call("icnv_R_smooth_chain", x, lay$chr_start, ref$idx, ref$off, as.integer(window_length),
                  as.numeric(max_thresh), as.logical(use_bounds), as.numeric(sd_amplifier),
-                 as.numeric(noise_filter), as.integer(sum(mask)), as.logical(want_pre), as.logical(inv_log))
+                 as.numeric(noise_filter), as.integer(sum(mask)), as.logical(want_pre), as.logical(inv_log),
+                 as.logical(noise_logistic))
     lapply(res, .icnv_unpermute, lay = lay)
 }
 
@@ -104,15 +106,15 @@ hip_invert_log2 <- function(infercnv_obj) {
 }
 
 hip_clear_noise_via_ref_mean_sd <- function(infercnv_obj, sd_amplifier = 1.5, noise_logistic = FALSE) {
-    if (noise_logistic) stop("noise_logistic=TRUE is not offered by the hip backend")
-    infercnv_obj@expr.data <- .icnv_chain(infercnv_obj, .icnv_ST["denoise"], sd_amplifier = sd_amplifier)[[1]]
+    infercnv_obj@expr.data <- .icnv_chain(infercnv_obj, .icnv_ST["denoise"], sd_amplifier = sd_amplifier,
+                                          noise_logistic = noise_logistic)[[1]]
     infercnv_obj
 }
 
 hip_clear_noise <- function(infercnv_obj, threshold, noise_logistic = FALSE) {
-    if (noise_logistic) stop("noise_logistic=TRUE is not offered by the hip backend")
     if (threshold == 0) return(infercnv_obj)
-    infercnv_obj@expr.data <- .icnv_chain(infercnv_obj, .icnv_ST["denoise"], noise_filter = threshold)[[1]]
+    infercnv_obj@expr.data <- .icnv_chain(infercnv_obj, .icnv_ST["denoise"], noise_filter = threshold,
+                                          noise_logistic = noise_logistic)[[1]]
     infercnv_obj
 }
 

@@ -26,8 +26,9 @@
 #define S8 S6, SEXP, SEXP
 #define S9 S8, SEXP
 #define S12 S8, SEXP, SEXP, SEXP, SEXP
+#define S13 S12, SEXP
 #define ARITY(fn, n, ...) _Static_assert(__builtin_types_compatible_p(__typeof__(&fn), SEXP (*)(__VA_ARGS__)), #fn " does not take " #n " SEXPs");
-ARITY(icnv_R_smooth_chain, 12, S12)
+ARITY(icnv_R_smooth_chain, 13, S13)
 ARITY(icnv_R_average_bounds, 1, S1)
 ARITY(icnv_R_viterbi_cells, 6, S6)
 ARITY(icnv_R_viterbi_groups, 8, S8)
@@ -38,7 +39,7 @@ ARITY(icnv_R_state_consensus_overwrite, 3, S3)
 ARITY(icnv_R_ingest_counts, 9, S9)
 ARITY(icnv_R_init, 2, S2)
 static const struct { const char *name; int n; } expected[] = {
-    {"icnv_R_smooth_chain", 12}, {"icnv_R_average_bounds", 1}, {"icnv_R_viterbi_cells", 6}, {"icnv_R_viterbi_groups", 8},
+    {"icnv_R_smooth_chain", 13}, {"icnv_R_average_bounds", 1}, {"icnv_R_viterbi_cells", 6}, {"icnv_R_viterbi_groups", 8},
     {"icnv_R_median_filter", 5}, {"icnv_R_cell_distances", 2}, {"icnv_R_states_to_proxy", 2},
     {"icnv_R_state_consensus_overwrite", 3}, {"icnv_R_ingest_counts", 9}, {"icnv_R_init", 2}};
 
@@ -72,7 +73,7 @@ static int run_cpu(void) {
     CHECK(strncmp(mock_r_last_error, "libicnv_hip error", 17) == 0);
     /* argument checks of the shim itself come before any library call */
     SEXP notm = mock_r_reals((const double[]){1.0, 2.0}, 2);
-    mock_r_try(raised, (void)icnv_R_smooth_chain(notm, m, m, m, m, m, m, m, m, m, m, m));
+    mock_r_try(raised, (void)icnv_R_smooth_chain(notm, m, m, m, m, m, m, m, m, m, m, m, m));
     CHECK(raised == 1 && strstr(mock_r_last_error, "numeric matrix") != NULL);
     mock_r_reset();
     printf("SHIM_CPU_OK\n");
@@ -96,7 +97,7 @@ static int run_gpu(void) {
     /* ---- smooth chain: all stages, pre-denoise matrix wanted ---- */
     SEXP res = NULL;
     mock_r_try(raised, res = icnv_R_smooth_chain(x, cs, ri, ro, mock_r_int(101), mock_r_real(3.0), mock_r_lgl(1), mock_r_real(1.5),
-                                                  mock_r_real(NA_REAL), mock_r_int(0x7F), mock_r_lgl(1), mock_r_lgl(0)));
+                                                  mock_r_real(NA_REAL), mock_r_int(0x7F), mock_r_lgl(1), mock_r_lgl(0), mock_r_lgl(0)));
     CHECK(raised == 0 && mock_r_protect_depth == 0);
     CHECK(XLENGTH(res) == 2);
     SEXP out = VECTOR_ELT(res, 0), pre = VECTOR_ELT(res, 1);
@@ -112,10 +113,10 @@ static int run_gpu(void) {
     CHECK(memcmp(o2, REAL(out), sizeof(double) * G * C) == 0 && memcmp(p2, REAL(pre), sizeof(double) * G * C) == 0);
     /* without the pre-denoise matrix the second element is NULL; an even window is the library's error, raised by the shim */
     mock_r_try(raised, res = icnv_R_smooth_chain(x, cs, ri, ro, mock_r_int(101), mock_r_real(3.0), mock_r_lgl(1), mock_r_real(1.5),
-                                                  mock_r_real(NA_REAL), mock_r_int(0x3F), mock_r_lgl(0), mock_r_lgl(0)));
+                                                  mock_r_real(NA_REAL), mock_r_int(0x3F), mock_r_lgl(0), mock_r_lgl(0), mock_r_lgl(0)));
     CHECK(raised == 0 && VECTOR_ELT(res, 1) == R_NilValue && mock_r_protect_depth == 0);
     mock_r_try(raised, res = icnv_R_smooth_chain(x, cs, ri, ro, mock_r_int(100), mock_r_real(3.0), mock_r_lgl(1), mock_r_real(1.5),
-                                                  mock_r_real(NA_REAL), mock_r_int(0x7F), mock_r_lgl(0), mock_r_lgl(0)));
+                                                  mock_r_real(NA_REAL), mock_r_int(0x7F), mock_r_lgl(0), mock_r_lgl(0), mock_r_lgl(0)));
     CHECK(raised == 1 && strstr(mock_r_last_error, "odd") != NULL && mock_r_protect_depth == 0);
     /* ---- per-cell i6 Viterbi on the pre-denoise matrix ---- */
     const double mean6[6] = {0.01, 0.5, 1.0, 1.5, 2.0, 3.0};

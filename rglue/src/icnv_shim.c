@@ -26,12 +26,12 @@
 
 static void fail(int rc) { Rf_error("libicnv_hip error %d: %s", rc, icnv_last_error()); }
 
-/* .Call("icnv_R_smooth_chain", expr, chr_start, ref_idx, ref_off, window, max_thresh, use_bounds,  [.., inv_log last]
- *       sd_amplifier, noise_filter, stage_mask, want_pre)  ->  list(expr, pre | NULL)
+/* .Call("icnv_R_smooth_chain", expr, chr_start, ref_idx, ref_off, window, max_thresh, use_bounds,
+ *       sd_amplifier, noise_filter, stage_mask, want_pre, inv_log, noise_logistic)  ->  list(expr, pre | NULL)
  * expr: REALSXP matrix genes x cells (column-major == cell-major); indices 0-based INTSXP. */
 SEXP icnv_R_smooth_chain(SEXP expr, SEXP chr_start, SEXP ref_idx, SEXP ref_off, SEXP window, SEXP max_thresh,
                          SEXP use_bounds, SEXP sd_amplifier, SEXP noise_filter, SEXP stage_mask, SEXP want_pre,
-                         SEXP inv_log) {
+                         SEXP inv_log, SEXP noise_logistic) {
     if (!Rf_isReal(expr) || !Rf_isMatrix(expr)) Rf_error("expr must be a numeric matrix");
     icnv_chain_cfg cfg;
     memset(&cfg, 0, sizeof(cfg));
@@ -46,6 +46,7 @@ SEXP icnv_R_smooth_chain(SEXP expr, SEXP chr_start, SEXP ref_idx, SEXP ref_off, 
     cfg.sd_amplifier = Rf_asReal(sd_amplifier);
     cfg.noise_filter = Rf_asReal(noise_filter);
     cfg.stage_mask = (uint32_t)Rf_asInteger(stage_mask);
+    cfg.noise_logistic = Rf_asLogical(noise_logistic) == TRUE;   /* step 22 as depress_log_signal_midpt_val */
     cfg.ref_idx = (const int32_t *)INTEGER(ref_idx);
     cfg.ref_off = (const int32_t *)INTEGER(ref_off);
     cfg.n_ref_grp = (int32_t)(XLENGTH(ref_off) - 1);
@@ -225,7 +226,7 @@ SEXP icnv_R_init(SEXP devices, SEXP residency) {
 }
 
 static const R_CallMethodDef call_methods[] = {
-    {"icnv_R_smooth_chain", (DL_FUNC)&icnv_R_smooth_chain, 12},
+    {"icnv_R_smooth_chain", (DL_FUNC)&icnv_R_smooth_chain, 13},
     {"icnv_R_average_bounds", (DL_FUNC)&icnv_R_average_bounds, 1},
     {"icnv_R_viterbi_cells", (DL_FUNC)&icnv_R_viterbi_cells, 6},
     {"icnv_R_viterbi_groups", (DL_FUNC)&icnv_R_viterbi_groups, 8},

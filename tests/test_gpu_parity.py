@@ -771,6 +771,41 @@ def test_host_mirror_runs_reference_workflow(dev, example):
     np.testing.assert_array_equal(mf.expr_data, wmf)
 
 
+def test_noise_logistic_denoise_vs_oracle(dev, example):
+    """Step 22 with noise_logistic = TRUE (R/inferCNV_ops.R:2249-2252, 2326-2330 -> depress_log_signal_midpt_val ->
+    .apply_logistic_val_adj, R/inferCNV_heatmap.R:2791-2810): the stand-alone step functions on the golden object's step-14
+    matrix, the fused chain, and the three-pass chain, against the oracle's element-by-element restatement."""
+    from infercnv_amd import GeneOrder, InfercnvObject, ops
+    levels = example["chr_levels"][example["chr_codes"]]
+    refs = example["ref_normal"]
+    obj = InfercnvObject(expr_data=example["log"], gene_order=GeneOrder(chr=levels),
+                         reference_grouped_cell_indices={"normal": refs}, observation_grouped_cell_indices={"tumor": example["obs_tumor"]})
+    _, pre, (mu, s) = oc.smooth_chain(example["log"], example["chr_start"], [refs], want_pre_denoise=True)
+    o14 = obj.copy()
+    o14.expr_data = pre
+    want = onp.clear_noise_via_ref_mean_sd(pre, refs, 1.5, noise_logistic=True)
+    got = ops.clear_noise_via_ref_mean_sd(o14, 1.5, noise_logistic=True).expr_data
+    assert np.abs(got - want).max() < 1e-12
+    assert np.abs(want - pre).max() > 0.01 and np.abs(want - onp.clear_noise_via_ref_mean_sd(pre, refs, 1.5)).max() > 0.01   # it does something, and not the select
+    # every value moves towards the centre and stays on its side of it; the further out, the less it moves
+    assert (np.abs(got - mu) <= np.abs(pre - mu) + 1e-15).all()
+    assert ((got > mu) == (pre > mu)).all() and ((got < mu) == (pre < mu)).all()
+    far = np.abs(pre - mu) > s + 0.3
+    assert far.any() and (np.abs(got[far] - pre[far]) < 3e-3 * np.abs(pre[far] - mu)).all()      # 1 - p < exp(-20 * 0.3)
+    want_t = onp.clear_noise(pre, refs, 0.1, noise_logistic=True)
+    assert np.abs(ops.clear_noise(o14, 0.1, noise_logistic=True).expr_data - want_t).max() < 1e-12
+    # fused: steps 8..14 + logistic step 22 in one call; the HMM input is the matrix before step 22
+    fused, hmm_in = ops.hip_smooth_chain(obj, return_hmm_input=True, noise_logistic=True)
+    assert np.abs(hmm_in.expr_data - pre).max() < 1e-12
+    assert np.abs(fused.expr_data - onp.apply_logistic_val_adj(hmm_in.expr_data, mu, s)).max() < 1e-11
+    os.environ["ICNV_CHAIN_LARGE"] = "1"
+    try:
+        f2, h2 = ops.hip_smooth_chain(obj, return_hmm_input=True, noise_logistic=True)
+    finally:
+        del os.environ["ICNV_CHAIN_LARGE"]
+    assert np.abs(f2.expr_data - fused.expr_data).max() < 1e-11 and np.abs(h2.expr_data - pre).max() < 1e-11
+
+
 def test_split_phase_equals_one_call(dev):
     """The multi-GPU split-phase API on one rank must equal the one-call form, and
     two 'ranks' emulated on one GPU (partials summed by hand) must equal it too."""
