@@ -437,28 +437,32 @@ print("MULTI_OK")
     assert res.returncode == 0 and "MULTI_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
 
 
-def test_bench_two_ranks_equal_one_rank(dev):
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_two_ranks_equal_one_rank(dev, world):
     """The N > 1 path of bench.py (one process per rank, torch.distributed, reference statistics all-reduced between the
-    rounds) on the hardware at hand: two ranks on ONE GPU over gloo (ICNV_BENCH_ONE_DEVICE=1), 2 x 12 000 cells dealt
-    round-robin, against one rank holding all 24 000 cells -- per-rank sums of the denoised matrix, the HMM input and the
-    state calls.  (RCCL on N GPUs needs a multi-GPU node: that is the driver's scaling run.)"""
+    rounds) on the hardware at hand: 2 and 8 ranks (the driver's launches) on ONE GPU over gloo (ICNV_BENCH_ONE_DEVICE=1),
+    cells dealt round-robin, against one rank holding all of them -- per-rank sums of the denoised matrix, the HMM input
+    and the state calls.  (RCCL on N GPUs needs a multi-GPU node: that is the driver's scaling run.)"""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ICNV_BENCH_ONE_DEVICE="1", ICNV_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    common = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-kernel-timing", "--checksum", "2"]
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--cells", "12000"] + common,
-                         env=env, capture_output=True, text=True, timeout=900, cwd=root)
-    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
-    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--cells", "24000"] + common,
+    per_rank = 12000 if world == 2 else 3000
+    common = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-kernel-timing", "--checksum", str(world)]
+    many = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                           "127.0.0.1", "--master-port", str(29533 + world), os.path.join(root, "bench.py"), "--gpus", str(world),
+                           "--cells", str(per_rank)] + common,
+                          env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert many.returncode == 0, many.stdout[-2000:] + many.stderr[-4000:]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--cells", str(per_rank * world)] + common,
                          env=dict(os.environ), capture_output=True, text=True, timeout=900, cwd=root)
     assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
     line = lambda r: json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    a, b = line(two), line(one)
-    assert a["n_gpus"] == 2 and b["n_gpus"] == 1 and a["config"]["cells_total"] == b["config"]["cells_total"] == 24000
-    for r in range(2):
+    a, b = line(many), line(one)
+    assert a["n_gpus"] == world and b["n_gpus"] == 1 and a["config"]["cells_total"] == b["config"]["cells_total"] == per_rank * world
+    assert a["scaling"] == "weak" and a["config"]["cells_per_gpu"] == per_rank
+    for r in range(world):
         (o2, p2, s2), (o1, p1, s1) = a["checksums"]["per_part"][r], b["checksums"]["per_part"][r]
         assert abs(p2 - p1) <= 1e-9 * abs(p1)          # reference sums are added in a different order: rounding only
         assert abs(o2 - o1) <= 1e-6 * abs(o1)          # (a denoise select within rounding of its bound may flip)
