@@ -403,9 +403,9 @@ def main():
                                        "table-driven emission scores (degree-4 polynomials on a uniform grid) + max-plus recurrence, 89 vector + 14 LDS-gather + "
                                        "18 other instructions per gene and wavefront in the forward pass (101 vector instructions per gene with the "
                                        "traceback), every lane streaming its own column, four wavefronts per SIMD; hardware counters "
-                                       "(profiles/r03_pmc_viterbi_fast.txt): vector pipes busy 72 % of the launch, LDS 71 % -- the 25 coefficients per lane "
-                                       "and gene are 100 of the 139 cycles a gene step takes on a CU: LDS bandwidth and fp64 issue pace it together, no "
-                                       "MFMA-shaped work")
+                                       "(profiles/r03_pmc_viterbi_fast.txt): vector pipes busy 72 % of the launch, LDS 71 % -- the 14 random 16-byte gathers per "
+                                       "lane and gene cost 99 LDS cycles (43 % of them bank conflicts) of the 139 cycles a gene step takes on a CU: "
+                                       "the LDS and fp64 issue pace it together, no MFMA-shaped work")
         if "viterbi" in roof:
             # second ceiling of the Viterbi (SURVEY.md 8d asks for HBM GB/s *and* the fp64 rate): its forward pass issues
             # 101 vector instructions per gene and wavefront (SQ_INSTS_VALU of the launch / gene steps; 89 of them in the forward
