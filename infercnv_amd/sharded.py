@@ -73,14 +73,15 @@ class ShardedChain:
     """Drives one rank's engine through the reference rounds with an all-reduce
     between `round_partial` and `round_finish`, then the fused apply pass."""
 
-    def __init__(self, engine, process_group=None, world_size=None):
+    def __init__(self, engine, process_group=None, world_size=None, always_reduce=False):
         self.engine = engine
         self.pg = process_group
         self.world = world_size
+        self.always_reduce = always_reduce      # issue the collective on a communicator of one rank too (bench.py's RCCL smoke)
 
     def _all_reduce(self, buf):
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.pg) > 1 or self.always_reduce):
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
 
     def run(self, x_local, out=None, want_pre_denoise=False):

@@ -469,6 +469,33 @@ def test_bench_two_ranks_equal_one_rank(dev, world):
         assert abs(s2 - s1) <= 50, (s2, s1)            # state calls: identical but for a decision within 1e-16 of a tie
 
 
+def test_bench_collectives_over_rccl_with_one_rank(dev):
+    """bench.py's N > 1 code path -- process group on the nccl (= RCCL) backend, barriers, the three all-reduces of the
+    reference statistics on the library's own buffers, the all-reduce / all-gather of the timing and the checksums -- with
+    ICNV_BENCH_FORCE_DIST=1 on a communicator of ONE rank: what a single-GPU box can run of it.  Same numbers as the plain
+    one-rank run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--gpus", "1", "--cells", "6000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing", "--checksum", "1"]
+    line = lambda r: json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    forced = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common,
+                            env=dict(os.environ, ICNV_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577"),
+                            capture_output=True, text=True, timeout=600, cwd=root)
+    assert forced.returncode == 0, forced.stdout[-2000:] + forced.stderr[-4000:]
+    plain = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, env=dict(os.environ),
+                           capture_output=True, text=True, timeout=600, cwd=root)
+    assert plain.returncode == 0, plain.stdout[-2000:] + plain.stderr[-4000:]
+    a, b = line(forced), line(plain)
+    assert a["checksums"]["per_part"] == b["checksums"]["per_part"] and a["n_gpus"] == 1
+    for c in ("4", "5"):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", c, "--genes", "4000"] + common[:-2],
+                           env=dict(os.environ, ICNV_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29578"),
+                           capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0 and line(r)["n_gpus"] == 1, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_i6_whole_samples_without_cluster_by_groups_is_one_sample_per_observation_cell(dev):
     """predict_CNV_via_HMM_on_whole_tumor_samples(cluster_by_groups = FALSE): the reference's
     `c(all_observations = unlist(obs), reference_grouped_cell_indices)` (R/inferCNV_HMM.R:532) is a list with one element
