@@ -292,6 +292,7 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if os.environ.get("ICNV_BENCH_ONE_DEVICE"):          # smoke-test the N>1 code path on a single GPU
         local_rank = 0
+    local_rank %= max(torch.cuda.device_count(), 1)      # (a launcher that shows every rank only its own GPU: that one is device 0)
     torch.cuda.set_device(local_rank)
     device.init(local_rank)
     # ICNV_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, barriers, all-reduces, all-gathers) with ONE rank --
