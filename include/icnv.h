@@ -169,6 +169,15 @@ void icnv_chain_end(icnv_chain_t *chain);
 int icnv_average_bounds(const double *expr, int64_t G, int64_t C, double *out2);
 int icnv_average_bounds_dev(const double *expr, int64_t G, int64_t C, double *out2_host, void *stream);
 
+/* remove_outliers_norm (step 16 of run(), R/inferCNV_ops.R:1969-2054; between the chain and the HMM when prune_outliers
+ * is set): values below / above the bounds are set to the bounds.  Both bounds given (not NaN) = hard thresholds
+ * (:2017-2022); otherwise out_method = "average_bound", the bounds of icnv_average_bounds over the input (:2029-2033).
+ * bounds_used2 (nullable, host) receives {lower, upper}.  expr_out may alias expr_in in the _dev form. */
+int icnv_remove_outliers(const double *expr_in, double *expr_out, int64_t G, int64_t C, double lower_bound, double upper_bound,
+                         double *bounds_used2);
+int icnv_remove_outliers_dev(const double *expr_in, double *expr_out, int64_t G, int64_t C, double lower_bound,
+                             double upper_bound, double *bounds_used2, void *stream);
+
 /* ---- ingest from the raw COUNT matrix: steps 2, 3, 4 of run() in one call ------------------
  * Replaces require_above_min_mean_expr_cutoff + require_above_min_cells_ref (R/inferCNV_ops.R:2128-2213; run() :560-566),
  * normalize_counts_by_seq_depth (:3064-3111) and log2xplus1 (:2756-2769).  The counts cross PCIe once as integers --

@@ -82,6 +82,8 @@ PROTOTYPES = {
     "icnv_chain_end": (None, [_vp]),
     "icnv_average_bounds": (ct.c_int, [_vp, _i64, _i64, _dp]),
     "icnv_average_bounds_dev": (ct.c_int, [_vp, _i64, _i64, _dp, _vp]),
+    "icnv_remove_outliers": (ct.c_int, [_vp, _vp, _i64, _i64, _dbl, _dbl, _dp]),
+    "icnv_remove_outliers_dev": (ct.c_int, [_vp, _vp, _i64, _i64, _dbl, _dbl, _dp, _vp]),
     "icnv_col_sums_dev": (ct.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "icnv_normalize_log2_dev": (ct.c_int, [_vp, _vp, _i64, _i64, _vp, _dbl, _i32, _i32, _vp]),
     "icnv_normalize_log2": (ct.c_int, [_vp, _vp, _i64, _i64, _dbl, _i32, _i32, _dp]),

@@ -734,6 +734,35 @@ int icnv_average_bounds(const double *expr, int64_t G, int64_t C, double *out2) 
     return icnv_average_bounds_dev(in.dev, G, C, out2, nullptr);
 }
 
+// ------------------------------------------------------------------ step 16: remove_outliers_norm (R/inferCNV_ops.R:1969-2054)
+// Hard thresholds when both bounds are given (:2017-2022), else out_method = "average_bound": .get_average_bounds of the
+// input (:2029-2033).  bounds_used2 (nullable, host) receives {lower, upper}.
+int icnv_remove_outliers_dev(const double *expr_in, double *expr_out, int64_t G, int64_t C, double lower_bound, double upper_bound,
+                             double *bounds_used2, void *stream) {
+    if (!expr_in || !expr_out || G < 1 || C < 1) ICNV_FAIL(ICNV_ERR_ARG, "Error, something is wrong with the data, either null or no rows or columns");
+    double b[2] = {lower_bound, upper_bound};
+    if (std::isnan(lower_bound) || std::isnan(upper_bound)) {
+        int rc = icnv_average_bounds_dev(expr_in, G, C, b, stream);
+        if (rc) return rc;
+    }
+    if (bounds_used2) { bounds_used2[0] = b[0]; bounds_used2[1] = b[1]; }
+    return launch_clamp_bounds(expr_in, expr_out, G * C, b[0], b[1], (hipStream_t)stream);
+}
+
+int icnv_remove_outliers(const double *expr_in, double *expr_out, int64_t G, int64_t C, double lower_bound, double upper_bound,
+                         double *bounds_used2) {
+    if (!expr_in || !expr_out || G < 1 || C < 1) ICNV_FAIL(ICNV_ERR_ARG, "Error, something is wrong with the data, either null or no rows or columns");
+    MatrixLease in;
+    DevBuf dout;
+    int rc;
+    const size_t bytes = (size_t)G * (size_t)C * sizeof(double);
+    if ((rc = acquire_input(expr_in, G * C, nullptr, in)) || (rc = dout.alloc(bytes))) return rc;
+    if ((rc = icnv_remove_outliers_dev(in.dev, dout.as<double>(), G, C, lower_bound, upper_bound, bounds_used2, nullptr))) return rc;
+    ICNV_HIP(hipMemcpy(expr_out, dout.p, bytes, hipMemcpyDeviceToHost));
+    publish_output(expr_out, G * C, std::move(dout));
+    return ICNV_OK;
+}
+
 // ------------------------------------------------------------------ ingest (steps 3-4)
 int icnv_col_sums_dev(const double *expr, int64_t G, int64_t C, double *sums_dev, void *stream) {
     if (!expr || !sums_dev || G < 1 || C < 0 || G > 0x7fffffff) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");

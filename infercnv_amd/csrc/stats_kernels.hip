@@ -84,6 +84,16 @@ __global__ void block_cell_reduce_kernel(const double *__restrict__ x, int G, co
     if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// step 16, .remove_outliers_norm (R/inferCNV_ops.R:2049-2051): data[data < lower] <- lower; data[data > upper] <- upper
+__global__ void clamp_bounds_kernel(const double *__restrict__ in, double *__restrict__ out, int64_t n, double lo, double hi) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double v = in[i];
+        if (v < lo) v = lo;
+        if (v > hi) v = hi;      // (R applies the second assignment to the result of the first; a NaN fails both tests)
+        out[i] = v;
+    }
+}
+
 // step 22 with noise_logistic = TRUE (.apply_logistic_val_adj, R/inferCNV_heatmap.R:2791-2810), in place: den = {m, s}
 __global__ void logistic_denoise_kernel(double *__restrict__ x, int64_t n, const double *__restrict__ den) {
     const double m = den[0], s = den[1];
@@ -103,6 +113,15 @@ __global__ void gather_values_kernel(const double *__restrict__ x, const int64_t
 }
 
 }  // namespace
+
+int launch_clamp_bounds(const double *in, double *out, int64_t n, double lo, double hi, hipStream_t stream) {
+    if (n <= 0) return ICNV_OK;
+    KernelTimer kt("remove_outliers", stream);
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)num_cus() * 16);
+    hipLaunchKernelGGL(clamp_bounds_kernel, dim3(grid), dim3(256), 0, stream, in, out, n, lo, hi);
+    ICNV_HIP(hipGetLastError());
+    return ICNV_OK;
+}
 
 int launch_logistic_denoise(double *x, int64_t n, const double *mu_s_dev, hipStream_t stream) {
     if (n <= 0) return ICNV_OK;

@@ -124,6 +124,20 @@ def _wrap_f64(ptr, n, device):
     return torch.as_tensor(_DevView(ptr, n), device=device)
 
 
+def remove_outliers(x, lower=None, upper=None, out=None):
+    """remove_outliers_norm (R/inferCNV_ops.R:1969-2054) on a device-resident (C, G) matrix; bounds None = "average_bound".
+    Returns (matrix, (lower, upper) used)."""
+    L = _lib.load()
+    C, G = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    used = (ct.c_double * 2)()
+    nan = float("nan")
+    check(L.icnv_remove_outliers_dev(_ptr(x), _ptr(out), G, C, nan if lower is None else float(lower),
+                                     nan if upper is None else float(upper), used, _stream()))
+    return out, (used[0], used[1])
+
+
 def average_bounds(x):
     """get_average_bounds (R/inferCNV_ops.R:2723-2742) -> (lower, upper)."""
     L = _lib.load()

@@ -207,6 +207,28 @@ def get_average_bounds(infercnv_obj: InfercnvObject):
     return out[0], out[1]
 
 
+def remove_outliers_norm(infercnv_obj: InfercnvObject, out_method="average_bound", lower_bound=None, upper_bound=None) -> InfercnvObject:
+    """Step 16 of run() (R/inferCNV_ops.R:1969-2054, prune_outliers): clamp to [lower, upper]; both bounds given = hard
+    thresholds, otherwise out_method "average_bound" (.get_average_bounds of the matrix); mirrored on the hspike (:1985-1988)."""
+    na = lambda v: v is None or (isinstance(v, float) and math.isnan(v))
+    if na(lower_bound) or na(upper_bound):
+        if na(out_method):
+            raise ValueError("must specify outmethod or define exact bounds")            # stop(992)
+        if out_method != "average_bound":
+            raise ValueError("please provide an approved method for outlier removal")    # stop(991)
+        lower_bound = upper_bound = float("nan")
+    L = _lib.load()
+    x = _as_f(infercnv_obj.expr_data)
+    out = np.empty_like(x, order="F")
+    check(L.icnv_remove_outliers(x.ctypes.data_as(ct.c_void_p), out.ctypes.data_as(ct.c_void_p), x.shape[0], x.shape[1],
+                                 float(lower_bound), float(upper_bound), None))
+    hs = None
+    if infercnv_obj.hspike is not None:
+        hs = remove_outliers_norm(infercnv_obj.hspike, out_method, None if math.isnan(lower_bound) else lower_bound,
+                                  None if math.isnan(upper_bound) else upper_bound)
+    return _with_expr(infercnv_obj, out, hs)
+
+
 def apply_max_threshold_bounds(infercnv_obj: InfercnvObject, threshold) -> InfercnvObject:
     """R/inferCNV_ops.R:2970-2983; threshold may be "auto" like run()'s
     max_centered_threshold (:802-817: mean(abs(get_average_bounds())))."""

@@ -156,6 +156,18 @@ def clear_noise_bounds(expr, center, halfwidth):
     return out
 
 
+def remove_outliers_norm(data, out_method="average_bound", lower_bound=None, upper_bound=None):
+    """.remove_outliers_norm (R/inferCNV_ops.R:1998-2054)."""
+    data = np.asarray(data, dtype=np.float64)
+    if lower_bound is None or upper_bound is None:
+        assert out_method == "average_bound"
+        lower_bound, upper_bound = get_average_bounds(data)
+    out = data.copy()
+    out[out < lower_bound] = lower_bound
+    out[out > upper_bound] = upper_bound
+    return out
+
+
 def apply_logistic_val_adj(expr, expr_mean, delta_midpt, slope=20.0):
     """.apply_logistic_val_adj (R/inferCNV_heatmap.R:2791-2810; .logistic, R/SplatterScrape.R:210-212) element by element:
     val = |x - mean|, p = 1 / (1 + exp(-slope (val - midpt))), x -> mean + p val above the mean, mean - p val below it."""

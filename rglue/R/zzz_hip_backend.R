@@ -75,6 +75,22 @@ hip_get_average_bounds <- function(infercnv_obj) {
     .Call("icnv_R_average_bounds", x)
 }
 
+## step 16 (prune_outliers): R/inferCNV_ops.R:1969-2054; NA bounds = out_method "average_bound"
+hip_remove_outliers_norm <- function(infercnv_obj, out_method = "average_bound", lower_bound = NA, upper_bound = NA) {
+    if (is.na(lower_bound) || is.na(upper_bound)) {
+        if (is.na(out_method)) stop(992)
+        if (out_method != "average_bound") stop(991)
+        lower_bound <- upper_bound <- NA_real_
+    }
+    x <- infercnv_obj@expr.data
+    if (!is.matrix(x)) x <- as.matrix(x)
+    if (storage.mode(x) != "double") storage.mode(x) <- "double"
+    infercnv_obj@expr.data <- .Call("icnv_R_remove_outliers", x, as.numeric(lower_bound), as.numeric(upper_bound))
+    if (!is.null(infercnv_obj@.hspike))
+        infercnv_obj@.hspike <- hip_remove_outliers_norm(infercnv_obj@.hspike, out_method, lower_bound, upper_bound)
+    infercnv_obj
+}
+
 hip_apply_max_threshold_bounds <- function(infercnv_obj, threshold) {
     if (is.character(threshold) && threshold == "auto")       # run() resolves "auto" itself; accepted here as well
         threshold <- mean(abs(hip_get_average_bounds(infercnv_obj)))
@@ -321,6 +337,7 @@ hip_ingest_counts <- function(infercnv_obj, min_mean_expr_cutoff, min_cells_per_
     swap <- c(subtract_ref_expr_from_obs = "hip_subtract_ref_expr_from_obs",
               get_average_bounds = "hip_get_average_bounds",
               apply_max_threshold_bounds = "hip_apply_max_threshold_bounds",
+              remove_outliers_norm = "hip_remove_outliers_norm",
               smooth_by_chromosome = "hip_smooth_by_chromosome",
               center_cell_expr_across_chromosome = "hip_center_cell_expr_across_chromosome",
               invert_log2 = "hip_invert_log2",

@@ -30,6 +30,7 @@
 #define ARITY(fn, n, ...) _Static_assert(__builtin_types_compatible_p(__typeof__(&fn), SEXP (*)(__VA_ARGS__)), #fn " does not take " #n " SEXPs");
 ARITY(icnv_R_smooth_chain, 13, S13)
 ARITY(icnv_R_average_bounds, 1, S1)
+ARITY(icnv_R_remove_outliers, 3, S3)
 ARITY(icnv_R_viterbi_cells, 6, S6)
 ARITY(icnv_R_viterbi_groups, 8, S8)
 ARITY(icnv_R_median_filter, 5, S5)
@@ -39,7 +40,7 @@ ARITY(icnv_R_state_consensus_overwrite, 3, S3)
 ARITY(icnv_R_ingest_counts, 9, S9)
 ARITY(icnv_R_init, 2, S2)
 static const struct { const char *name; int n; } expected[] = {
-    {"icnv_R_smooth_chain", 13}, {"icnv_R_average_bounds", 1}, {"icnv_R_viterbi_cells", 6}, {"icnv_R_viterbi_groups", 8},
+    {"icnv_R_smooth_chain", 13}, {"icnv_R_average_bounds", 1}, {"icnv_R_remove_outliers", 3}, {"icnv_R_viterbi_cells", 6}, {"icnv_R_viterbi_groups", 8},
     {"icnv_R_median_filter", 5}, {"icnv_R_cell_distances", 2}, {"icnv_R_states_to_proxy", 2},
     {"icnv_R_state_consensus_overwrite", 3}, {"icnv_R_ingest_counts", 9}, {"icnv_R_init", 2}};
 
@@ -200,6 +201,26 @@ static int run_gpu(void) {
     mock_r_try(raised, ab = icnv_R_average_bounds(x));
     double ab2[2];
     CHECK(raised == 0 && icnv_average_bounds(REAL(x), G, C, ab2) == 0 && REAL(ab)[0] == ab2[0] && REAL(ab)[1] == ab2[1]);
+    /* ---- step 16: the reference's own literal case (tests/testthat/test_infer_cnv.R:405-433): average bounds -0.5 / 17.75 ---- */
+    {
+        SEXP m = Rf_allocMatrix(REALSXP, 15, 4);
+        for (int c = 0; c < 4; c++)
+            for (int g = 0; g < 15; g++) REAL(m)[g + 15 * c] = g + 1;
+        const double col2[15] = {-5, -4, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 21, 26};
+        for (int g = 0; g < 15; g++) REAL(m)[g + 15] = col2[g];
+        SEXP ro = NULL;
+        mock_r_try(raised, ro = icnv_R_remove_outliers(m, mock_r_real(NA_REAL), mock_r_real(NA_REAL)));
+        CHECK(raised == 0 && mock_r_protect_depth == 0 && Rf_nrows(ro) == 15 && Rf_ncols(ro) == 4);
+        for (int c = 0; c < 4; c++)
+            for (int g = 0; g < 15; g++) {
+                double want = REAL(m)[g + 15 * c];
+                if (c == 1 && g < 2) want = -0.5;
+                if (c == 1 && g >= 13) want = 17.75;
+                CHECK(REAL(ro)[g + 15 * c] == want);
+            }
+        mock_r_try(raised, ro = icnv_R_remove_outliers(m, mock_r_real(5.0), mock_r_real(10.0)));   /* hard thresholds */
+        CHECK(raised == 0 && REAL(ro)[0] == 5.0 && REAL(ro)[14] == 10.0 && REAL(ro)[7] == 8.0);
+    }
     free(o2); free(p2); free(s2);
     mock_r_reset();
     printf("SHIM_GPU_OK\n");

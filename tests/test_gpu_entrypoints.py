@@ -134,6 +134,48 @@ def test_below_min_mean_expr_cutoff_reference_literals_through_the_hip_path(dev)
         assert o.expr_data.shape == (keep.size, m.shape[1]) and len(o.gene_order.chr) == keep.size
 
 
+def test_remove_outliers_norm_reference_literals_through_the_hip_path(dev):
+    """Step 16 of run() (remove_outliers_norm, R/inferCNV_ops.R:1969-2054): the reference's three literal cases
+    (tests/testthat/test_infer_cnv.R:404-433) through ops.remove_outliers_norm -> icnv_remove_outliers, the hspike mirror,
+    the refusals, and a random matrix against the oracle (host buffers and device-resident)."""
+    from infercnv_amd import GeneOrder, InfercnvObject, ops
+
+    def obj_of(m, hspike=None):
+        return InfercnvObject(expr_data=np.array(m, dtype=np.float64), gene_order=GeneOrder(chr=["chr1"] * m.shape[0]),
+                              reference_grouped_cell_indices={"a": np.array([0])},
+                              observation_grouped_cell_indices={"b": np.arange(1, m.shape[1])}, hspike=hspike)
+    in1 = np.arange(1, 21, dtype=float).reshape(4, 5).T
+    np.testing.assert_array_equal(ops.remove_outliers_norm(obj_of(in1), lower_bound=-1, upper_bound=30).expr_data, in1)
+    out1 = np.array([5] * 5 + list(range(6, 15)) + [15] * 6, dtype=float).reshape(4, 5).T
+    np.testing.assert_array_equal(ops.remove_outliers_norm(obj_of(in1), lower_bound=5, upper_bound=15).expr_data, out1)
+    col = np.arange(1, 16, dtype=float)
+    in2 = np.stack([col, np.array([-5, -4] + list(range(3, 14)) + [21, 26], dtype=float), col, col], axis=1)
+    out2 = in2.copy()
+    out2[:2, 1] = -0.5
+    out2[13:, 1] = 17.75
+    got = ops.remove_outliers_norm(obj_of(in2, hspike=obj_of(in1)), out_method="average_bound")
+    np.testing.assert_array_equal(got.expr_data, out2)
+    np.testing.assert_array_equal(got.hspike.expr_data, onp.remove_outliers_norm(in1))          # mirrored with ITS own average bounds
+    with pytest.raises(ValueError):
+        ops.remove_outliers_norm(obj_of(in1), out_method="quantile")
+    with pytest.raises(ValueError):
+        ops.remove_outliers_norm(obj_of(in1), out_method=None)
+    rng = np.random.default_rng(8)
+    x = np.asfortranarray(rng.normal(1.0, 0.3, size=(3001, 257)))
+    x[5, 7] = np.nan                                                                             # a NaN passes through both tests
+    want = onp.remove_outliers_norm(np.nan_to_num(x, nan=1.0))
+    got = ops.remove_outliers_norm(obj_of(np.nan_to_num(x, nan=1.0))).expr_data
+    np.testing.assert_array_equal(got, want)
+    xd = to_dev(np.nan_to_num(x, nan=1.0))
+    outd, (lo, hi) = dev.remove_outliers(xd)
+    wlo, whi = onp.get_average_bounds(np.nan_to_num(x, nan=1.0))
+    assert abs(lo - wlo) < 1e-15 and abs(hi - whi) < 1e-15
+    np.testing.assert_array_equal(to_host(outd), want)
+    outd2, _ = dev.remove_outliers(to_dev(x), 0.8, 1.2)
+    h = to_host(outd2)
+    assert np.isnan(h[5, 7]) and np.nanmin(h) == 0.8 and np.nanmax(h) == 1.2
+
+
 def test_average_bounds_and_auto_threshold(dev):
     """icnv_average_bounds[_dev] (get_average_bounds, R/inferCNV_ops.R:2723-2742) and step 9 with threshold "auto"
     (run(): mean(abs(get_average_bounds()), :802-817)."""

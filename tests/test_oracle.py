@@ -338,6 +338,20 @@ def test_define_cnv_gene_regions_loop():
     assert counter == 14
 
 
+def test_remove_outliers_norm_reference_literals():
+    """tests/testthat/test_infer_cnv.R:404-433: the three literal cases of .remove_outliers_norm (step 16 of run())."""
+    in1 = np.arange(1, 21, dtype=float).reshape(4, 5).T
+    np.testing.assert_array_equal(onp.remove_outliers_norm(in1, lower_bound=-1, upper_bound=30), in1)
+    out1 = np.array([5] * 5 + list(range(6, 15)) + [15] * 6, dtype=float).reshape(4, 5).T
+    np.testing.assert_array_equal(onp.remove_outliers_norm(in1, lower_bound=5, upper_bound=15), out1)
+    col = np.arange(1, 16, dtype=float)
+    in2 = np.stack([col, np.array([-5, -4] + list(range(3, 14)) + [21, 26], dtype=float), col, col], axis=1)
+    out2 = in2.copy()
+    out2[:2, 1] = -0.5
+    out2[13:, 1] = 17.75
+    np.testing.assert_array_equal(onp.remove_outliers_norm(in2, out_method="average_bound"), out2)
+
+
 def test_below_min_mean_expr_cutoff_reference_literals():
     """tests/testthat/test_infer_cnv.R:175-220: the six literal cases of .below_min_mean_expr_cutoff (1-based there)."""
     cases = [(matrix_one, 10, [1, 2, 3, 4, 5]), (matrix_three, 10, [1, 2, 3, 4]), (matrix_one, 2, [1]),
