@@ -207,6 +207,36 @@ def get_average_bounds(infercnv_obj: InfercnvObject):
     return out[0], out[1]
 
 
+def _remove_tails(chr_idx, tail_length):
+    """.remove_tails (R/inferCNV_ops.R:2370-2386): the first and last tail_length positions of a chromosome's gene index
+    vector (0-based here); nothing when the tail or the chromosome is shorter than 3; a chromosome shorter than two
+    tails loses floor(n / 3) genes at either end."""
+    chr_idx = np.asarray(chr_idx, dtype=np.int64)
+    n = chr_idx.size
+    if tail_length < 3 or n < 3:
+        return np.zeros(0, dtype=np.int64)
+    if n < tail_length * 2:
+        tail_length = n // 3
+    tail_length = int(tail_length)
+    return np.concatenate([chr_idx[:tail_length], chr_idx[n - tail_length:]])
+
+
+def remove_genes_at_ends_of_chromosomes(infercnv_obj: InfercnvObject, window_length) -> InfercnvObject:
+    """Step 13 of run() (R/inferCNV_ops.R:3000-3033; remove_genes_at_chr_ends, off by default): drops (window_length - 1) / 2
+    genes at either end of every chromosome through remove_genes (the row selection runs on the device)."""
+    contig_tail = (window_length - 1) / 2
+    chrs = np.asarray(infercnv_obj.gene_order.chr)
+    drop = []
+    seen = []
+    for c in chrs:                                       # unique(), order of first appearance
+        if c not in seen:
+            seen.append(c)
+    for c in seen:
+        drop.append(_remove_tails(np.nonzero(chrs == c)[0], contig_tail))
+    drop = np.concatenate(drop) if drop else np.zeros(0, dtype=np.int64)
+    return remove_genes(infercnv_obj, drop) if drop.size else infercnv_obj
+
+
 def remove_outliers_norm(infercnv_obj: InfercnvObject, out_method="average_bound", lower_bound=None, upper_bound=None) -> InfercnvObject:
     """Step 16 of run() (R/inferCNV_ops.R:1969-2054, prune_outliers): clamp to [lower, upper]; both bounds given = hard
     thresholds, otherwise out_method "average_bound" (.get_average_bounds of the matrix); mirrored on the hspike (:1985-1988)."""

@@ -156,6 +156,18 @@ def clear_noise_bounds(expr, center, halfwidth):
     return out
 
 
+def remove_tails(chr_idx_1based, tail_length):
+    """.remove_tails (R/inferCNV_ops.R:2370-2386), 1-based like the reference's tests."""
+    chr_idx = list(chr_idx_1based)
+    n = len(chr_idx)
+    if tail_length < 3 or n < 3:
+        return []
+    if n < tail_length * 2:
+        tail_length = n // 3
+    tail_length = int(tail_length)
+    return chr_idx[:tail_length] + chr_idx[n - tail_length:]
+
+
 def remove_outliers_norm(data, out_method="average_bound", lower_bound=None, upper_bound=None):
     """.remove_outliers_norm (R/inferCNV_ops.R:1998-2054)."""
     data = np.asarray(data, dtype=np.float64)

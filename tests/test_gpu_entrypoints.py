@@ -176,6 +176,24 @@ def test_remove_outliers_norm_reference_literals_through_the_hip_path(dev):
     assert np.isnan(h[5, 7]) and np.nanmin(h) == 0.8 and np.nanmax(h) == 1.2
 
 
+def test_remove_genes_at_ends_of_chromosomes(dev):
+    """Step 13 of run() (R/inferCNV_ops.R:3000-3033): (window_length - 1) / 2 genes off either end of every chromosome, a
+    short chromosome loses a third at either end, one shorter than 3 genes nothing; rows selected on the device."""
+    from infercnv_amd import GeneOrder, InfercnvObject, ops
+    sizes = {"chr1": 30, "chr2": 7, "chr3": 2, "chr4": 12}
+    chrs = np.concatenate([[k] * n for k, n in sizes.items()])
+    G = chrs.size
+    x = np.arange(G * 3, dtype=np.float64).reshape(3, G).T.copy()
+    obj = InfercnvObject(expr_data=x, gene_order=GeneOrder(chr=chrs), reference_grouped_cell_indices={"a": np.array([0])},
+                         observation_grouped_cell_indices={"b": np.array([1, 2])})
+    got = ops.remove_genes_at_ends_of_chromosomes(obj, 11)          # tail 5
+    # chr1 (30 genes): 5 off either end; chr2 (7 < 2 * 5): floor(7 / 3) = 2 off either end; chr3 (2 genes): untouched; chr4 (12): 5 off either end
+    keep = list(range(5, 25)) + list(range(32, 35)) + [37, 38] + list(range(39 + 5, 39 + 7))
+    np.testing.assert_array_equal(got.expr_data, x[keep])
+    assert list(got.gene_order.chr) == list(chrs[keep])
+    assert ops.remove_genes_at_ends_of_chromosomes(obj, 5) is obj   # tail 2 < 3: nothing to remove
+
+
 def test_average_bounds_and_auto_threshold(dev):
     """icnv_average_bounds[_dev] (get_average_bounds, R/inferCNV_ops.R:2723-2742) and step 9 with threshold "auto"
     (run(): mean(abs(get_average_bounds()), :802-817)."""

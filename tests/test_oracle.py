@@ -338,6 +338,18 @@ def test_define_cnv_gene_regions_loop():
     assert counter == 14
 
 
+def test_remove_tails_reference_literals():
+    """tests/testthat/test_infer_cnv.R:263-305: the five literal cases of .remove_tails (step 13 of run()), oracle and the
+    host mirror's index logic (0-based)."""
+    from infercnv_amd import ops
+    cases = [(range(1, 6), 0, []), (range(1, 21), 5, list(range(1, 6)) + list(range(16, 21))),
+             (range(2, 18), 5, list(range(2, 7)) + list(range(13, 18))), (range(5, 16), 5, list(range(5, 10)) + list(range(11, 16))),
+             (range(1, 6), 100, [1, 5])]
+    for chr_idx, tail, want in cases:
+        assert onp.remove_tails(chr_idx, tail) == want
+        assert (ops._remove_tails(np.array(list(chr_idx)) - 1, tail) + 1).tolist() == want
+
+
 def test_remove_outliers_norm_reference_literals():
     """tests/testthat/test_infer_cnv.R:404-433: the three literal cases of .remove_outliers_norm (step 16 of run())."""
     in1 = np.arange(1, 21, dtype=float).reshape(4, 5).T
