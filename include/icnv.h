@@ -169,6 +169,12 @@ void icnv_chain_end(icnv_chain_t *chain);
 int icnv_average_bounds(const double *expr, int64_t G, int64_t C, double *out2);
 int icnv_average_bounds_dev(const double *expr, int64_t G, int64_t C, double *out2_host, void *stream);
 
+/* scale_infercnv_expr (step 5 of run(), scale_data, off by default; R/inferCNV_ops.R:3174-3185): t(scale(t(x))) -- every
+ * gene minus its mean over the cells, divided by sqrt(sum(centred^2) / max(1, C - 1)) (a constant gene becomes NaN, as in R).
+ * expr_out may alias expr_in in the _dev form. */
+int icnv_scale_genes(const double *expr_in, double *expr_out, int64_t G, int64_t C);
+int icnv_scale_genes_dev(const double *expr_in, double *expr_out, int64_t G, int64_t C, void *stream);
+
 /* remove_outliers_norm (step 16 of run(), R/inferCNV_ops.R:1969-2054; between the chain and the HMM when prune_outliers
  * is set): values below / above the bounds are set to the bounds.  Both bounds given (not NaN) = hard thresholds
  * (:2017-2022); otherwise out_method = "average_bound", the bounds of icnv_average_bounds over the input (:2029-2033).

@@ -82,6 +82,8 @@ PROTOTYPES = {
     "icnv_chain_end": (None, [_vp]),
     "icnv_average_bounds": (ct.c_int, [_vp, _i64, _i64, _dp]),
     "icnv_average_bounds_dev": (ct.c_int, [_vp, _i64, _i64, _dp, _vp]),
+    "icnv_scale_genes": (ct.c_int, [_vp, _vp, _i64, _i64]),
+    "icnv_scale_genes_dev": (ct.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "icnv_remove_outliers": (ct.c_int, [_vp, _vp, _i64, _i64, _dbl, _dbl, _dp]),
     "icnv_remove_outliers_dev": (ct.c_int, [_vp, _vp, _i64, _i64, _dbl, _dbl, _dp, _vp]),
     "icnv_col_sums_dev": (ct.c_int, [_vp, _i64, _i64, _vp, _vp]),

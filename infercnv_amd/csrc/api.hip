@@ -734,6 +734,34 @@ int icnv_average_bounds(const double *expr, int64_t G, int64_t C, double *out2) 
     return icnv_average_bounds_dev(in.dev, G, C, out2, nullptr);
 }
 
+// ------------------------------------------------------------------ step 5: scale_infercnv_expr (R/inferCNV_ops.R:3174-3185)
+int icnv_scale_genes_dev(const double *expr_in, double *expr_out, int64_t G, int64_t C, void *stream) {
+    if (!expr_in || !expr_out || G < 1 || C < 1 || G > 0x7fffffff) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles = (int)((G + 255) / 256);
+    int64_t ns = (4096 + tiles - 1) / tiles;
+    ns = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ns, C), 1024));
+    DevBuf part, ms;
+    int rc;
+    if ((rc = part.alloc((size_t)ns * G * sizeof(double))) || (rc = ms.alloc((size_t)2 * G * sizeof(double)))) return rc;
+    if ((rc = launch_scale_genes(expr_in, expr_out, (int32_t)G, C, (int)ns, part.as<double>(), ms.as<double>(), s))) return rc;
+    ICNV_HIP(hipStreamSynchronize(s));   // the workspace goes back to the pool
+    return ICNV_OK;
+}
+
+int icnv_scale_genes(const double *expr_in, double *expr_out, int64_t G, int64_t C) {
+    if (!expr_in || !expr_out || G < 1 || C < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    MatrixLease in;
+    DevBuf dout;
+    int rc;
+    const size_t bytes = (size_t)G * (size_t)C * sizeof(double);
+    if ((rc = acquire_input(expr_in, G * C, nullptr, in)) || (rc = dout.alloc(bytes))) return rc;
+    if ((rc = icnv_scale_genes_dev(in.dev, dout.as<double>(), G, C, nullptr))) return rc;
+    ICNV_HIP(hipMemcpy(expr_out, dout.p, bytes, hipMemcpyDeviceToHost));
+    publish_output(expr_out, G * C, std::move(dout));
+    return ICNV_OK;
+}
+
 // ------------------------------------------------------------------ step 16: remove_outliers_norm (R/inferCNV_ops.R:1969-2054)
 // Hard thresholds when both bounds are given (:2017-2022), else out_method = "average_bound": .get_average_bounds of the
 // input (:2029-2033).  bounds_used2 (nullable, host) receives {lower, upper}.

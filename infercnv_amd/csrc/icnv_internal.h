@@ -168,6 +168,7 @@ int launch_select_genes(const double *in, int32_t G_in, int64_t C, const int32_t
                         hipStream_t stream);
 int launch_block_cell_reduce(int pass, const double *x, int32_t G, const int32_t *gene_idx_dev, int32_t n_genes,
                              const int32_t *cell_idx_dev, int32_t n_cells, double mean, double *out, hipStream_t stream);
+int launch_scale_genes(const double *in, double *out, int32_t G, int64_t C, int nsplit, double *part, double *mean_sd, hipStream_t stream);
 int launch_clamp_bounds(const double *in, double *out, int64_t n, double lo, double hi, hipStream_t stream);
 int launch_logistic_denoise(double *x, int64_t n, const double *mu_s_dev, hipStream_t stream);
 int launch_gather_values(const double *x, const int64_t *offsets_dev, int64_t n, double *out, hipStream_t stream);

@@ -46,6 +46,44 @@ __global__ void gene_stats_finish_kernel(const double *__restrict__ part_sum, co
     nnz[g] = n;
 }
 
+// scale_infercnv_expr (R/inferCNV_ops.R:3174-3185): t(scale(t(x))) -- every gene centred on its mean over the cells and divided
+// by sqrt(sum(centred^2) / max(1, C - 1)) (scale.default).  Three kernels over the cell-major matrix, lanes along the genes:
+// per-slice sums -> means; per-slice sums of squared deviations -> scales; the elementwise apply.
+__global__ void gene_moment_partial_kernel(const double *__restrict__ x, int G, int64_t C, int nsplit, const double *__restrict__ mean,
+                                           double *__restrict__ part) {
+    const int g = blockIdx.x * GS_TILE + threadIdx.x;
+    const int sp = blockIdx.y;
+    if (g >= G) return;
+    const int64_t per = (C + nsplit - 1) / nsplit;
+    const int64_t lo = sp * per;
+    int64_t hi = lo + per;
+    if (hi > C) hi = C;
+    const double m = mean ? mean[g] : 0.0;
+    double s = 0.0;
+    for (int64_t c = lo; c < hi; ++c) {
+        const double v = x[c * (int64_t)G + g];
+        if (mean) { const double d = v - m; s += d * d; }
+        else s += v;
+    }
+    part[(int64_t)sp * G + g] = s;
+}
+// pass 0: out[g] = sum / C;  pass 1: out[g] = sqrt(sum / max(1, C - 1))
+__global__ void gene_moment_finish_kernel(const double *__restrict__ part, int G, int nsplit, int64_t C, int pass, double *__restrict__ out) {
+    const int g = blockIdx.x * GS_TILE + threadIdx.x;
+    if (g >= G) return;
+    double s = 0.0;
+    for (int sp = 0; sp < nsplit; ++sp) s += part[(int64_t)sp * G + g];
+    out[g] = pass == 0 ? s / (double)C : sqrt(s / (double)(C > 1 ? C - 1 : 1));
+}
+__global__ void __launch_bounds__(256) scale_genes_kernel(const double *__restrict__ in, double *__restrict__ out, int G, int64_t C,
+                                                          const double *__restrict__ mean, const double *__restrict__ sdv) {
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        const double *src = in + c * (int64_t)G;
+        double *dst = out + c * (int64_t)G;
+        for (int g = threadIdx.x; g < G; g += 256) dst[g] = (src[g] - mean[g]) / sdv[g];
+    }
+}
+
 // out[j, c] = in[keep[j], c]  (remove_genes: rows dropped, cell-major layout => a per-cell gather)
 __global__ void select_genes_kernel(const double *__restrict__ in, int G_in, int64_t C, const int32_t *__restrict__ keep,
                                     int G_out, double *__restrict__ out) {
@@ -158,6 +196,20 @@ int launch_gene_stats(const double *x, int32_t G, int64_t C, int nsplit, double 
                        part_nnz);
     hipLaunchKernelGGL(gene_stats_finish_kernel, dim3(tiles), dim3(GS_TILE), 0, stream, part_sum, part_nnz, G, nsplit, sums,
                        nnz);
+    ICNV_HIP(hipGetLastError());
+    return ICNV_OK;
+}
+
+// mean_sd: [G means | G scales] (device); part: nsplit * G doubles of workspace
+int launch_scale_genes(const double *in, double *out, int32_t G, int64_t C, int nsplit, double *part, double *mean_sd, hipStream_t stream) {
+    if (C <= 0) return ICNV_OK;
+    KernelTimer kt("scale_genes", stream);
+    const int tiles = (G + GS_TILE - 1) / GS_TILE;
+    hipLaunchKernelGGL(gene_moment_partial_kernel, dim3(tiles, nsplit), dim3(GS_TILE), 0, stream, in, G, C, nsplit, (const double *)nullptr, part);
+    hipLaunchKernelGGL(gene_moment_finish_kernel, dim3(tiles), dim3(GS_TILE), 0, stream, part, G, nsplit, C, 0, mean_sd);
+    hipLaunchKernelGGL(gene_moment_partial_kernel, dim3(tiles, nsplit), dim3(GS_TILE), 0, stream, in, G, C, nsplit, (const double *)mean_sd, part);
+    hipLaunchKernelGGL(gene_moment_finish_kernel, dim3(tiles), dim3(GS_TILE), 0, stream, part, G, nsplit, C, 1, mean_sd + G);
+    hipLaunchKernelGGL(scale_genes_kernel, dim3((unsigned)(C < 8192 ? C : 8192)), dim3(256), 0, stream, in, out, G, C, mean_sd, mean_sd + G);
     ICNV_HIP(hipGetLastError());
     return ICNV_OK;
 }

@@ -207,6 +207,16 @@ def get_average_bounds(infercnv_obj: InfercnvObject):
     return out[0], out[1]
 
 
+def scale_infercnv_expr(infercnv_obj: InfercnvObject) -> InfercnvObject:
+    """Step 5 of run() (scale_data, off by default; R/inferCNV_ops.R:3174-3185): t(scale(t(expr.data))), mirrored on the hspike."""
+    L = _lib.load()
+    x = _as_f(infercnv_obj.expr_data)
+    out = np.empty_like(x, order="F")
+    check(L.icnv_scale_genes(x.ctypes.data_as(ct.c_void_p), out.ctypes.data_as(ct.c_void_p), x.shape[0], x.shape[1]))
+    hs = scale_infercnv_expr(infercnv_obj.hspike) if infercnv_obj.hspike is not None else None
+    return _with_expr(infercnv_obj, out, hs)
+
+
 def _remove_tails(chr_idx, tail_length):
     """.remove_tails (R/inferCNV_ops.R:2370-2386): the first and last tail_length positions of a chromosome's gene index
     vector (0-based here); nothing when the tail or the chromosome is shorter than 3; a chromosome shorter than two

@@ -156,6 +156,19 @@ def clear_noise_bounds(expr, center, halfwidth):
     return out
 
 
+def scale_rows(expr):
+    """t(scale(t(x))) (R/inferCNV_ops.R:3177; base R scale.default: centre = colMeans, scale = sqrt(sum(centred^2) / max(1, n - 1)),
+    R's long-double accumulation)."""
+    x = np.asarray(expr, dtype=np.float64)
+    LD = np.longdouble
+    n = x.shape[1]
+    m = np.asarray(x.astype(LD).sum(axis=1) / LD(n), dtype=np.float64)
+    cen = x - m[:, None]
+    sc = np.asarray(np.sqrt((cen.astype(LD) ** 2).sum(axis=1) / LD(max(1, n - 1))), dtype=np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return cen / sc[:, None]
+
+
 def remove_tails(chr_idx_1based, tail_length):
     """.remove_tails (R/inferCNV_ops.R:2370-2386), 1-based like the reference's tests."""
     chr_idx = list(chr_idx_1based)

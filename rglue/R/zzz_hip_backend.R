@@ -75,6 +75,16 @@ hip_get_average_bounds <- function(infercnv_obj) {
     .Call("icnv_R_average_bounds", x)
 }
 
+## step 5 (scale_data): R/inferCNV_ops.R:3174-3185
+hip_scale_infercnv_expr <- function(infercnv_obj) {
+    x <- infercnv_obj@expr.data
+    if (!is.matrix(x)) x <- as.matrix(x)
+    if (storage.mode(x) != "double") storage.mode(x) <- "double"
+    infercnv_obj@expr.data <- .Call("icnv_R_scale_genes", x)
+    if (!is.null(infercnv_obj@.hspike)) infercnv_obj@.hspike <- hip_scale_infercnv_expr(infercnv_obj@.hspike)
+    infercnv_obj
+}
+
 ## step 16 (prune_outliers): R/inferCNV_ops.R:1969-2054; NA bounds = out_method "average_bound"
 hip_remove_outliers_norm <- function(infercnv_obj, out_method = "average_bound", lower_bound = NA, upper_bound = NA) {
     if (is.na(lower_bound) || is.na(upper_bound)) {
@@ -338,6 +348,7 @@ hip_ingest_counts <- function(infercnv_obj, min_mean_expr_cutoff, min_cells_per_
               get_average_bounds = "hip_get_average_bounds",
               apply_max_threshold_bounds = "hip_apply_max_threshold_bounds",
               remove_outliers_norm = "hip_remove_outliers_norm",
+              scale_infercnv_expr = "hip_scale_infercnv_expr",
               smooth_by_chromosome = "hip_smooth_by_chromosome",
               center_cell_expr_across_chromosome = "hip_center_cell_expr_across_chromosome",
               invert_log2 = "hip_invert_log2",

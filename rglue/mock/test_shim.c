@@ -31,6 +31,7 @@
 ARITY(icnv_R_smooth_chain, 13, S13)
 ARITY(icnv_R_average_bounds, 1, S1)
 ARITY(icnv_R_remove_outliers, 3, S3)
+ARITY(icnv_R_scale_genes, 1, S1)
 ARITY(icnv_R_viterbi_cells, 6, S6)
 ARITY(icnv_R_viterbi_groups, 8, S8)
 ARITY(icnv_R_median_filter, 5, S5)
@@ -40,7 +41,7 @@ ARITY(icnv_R_state_consensus_overwrite, 3, S3)
 ARITY(icnv_R_ingest_counts, 9, S9)
 ARITY(icnv_R_init, 2, S2)
 static const struct { const char *name; int n; } expected[] = {
-    {"icnv_R_smooth_chain", 13}, {"icnv_R_average_bounds", 1}, {"icnv_R_remove_outliers", 3}, {"icnv_R_viterbi_cells", 6}, {"icnv_R_viterbi_groups", 8},
+    {"icnv_R_smooth_chain", 13}, {"icnv_R_average_bounds", 1}, {"icnv_R_remove_outliers", 3}, {"icnv_R_scale_genes", 1}, {"icnv_R_viterbi_cells", 6}, {"icnv_R_viterbi_groups", 8},
     {"icnv_R_median_filter", 5}, {"icnv_R_cell_distances", 2}, {"icnv_R_states_to_proxy", 2},
     {"icnv_R_state_consensus_overwrite", 3}, {"icnv_R_ingest_counts", 9}, {"icnv_R_init", 2}};
 
@@ -220,6 +221,11 @@ static int run_gpu(void) {
             }
         mock_r_try(raised, ro = icnv_R_remove_outliers(m, mock_r_real(5.0), mock_r_real(10.0)));   /* hard thresholds */
         CHECK(raised == 0 && REAL(ro)[0] == 5.0 && REAL(ro)[14] == 10.0 && REAL(ro)[7] == 8.0);
+        /* step 5: every gene (row) of t(scale(t(m))) has mean 0 and sample sd 1; row 0 of m is (1, -5, 1, 1) */
+        SEXP sc = NULL;
+        mock_r_try(raised, sc = icnv_R_scale_genes(m));
+        CHECK(raised == 0 && mock_r_protect_depth == 0 && Rf_nrows(sc) == 15 && Rf_ncols(sc) == 4);
+        CHECK(fabs(REAL(sc)[0] - 0.5) < 1e-14 && fabs(REAL(sc)[15] + 1.5) < 1e-14);              /* (1 - (-0.5)) / 3, (-5 + 0.5) / 3 */
     }
     free(o2); free(p2); free(s2);
     mock_r_reset();

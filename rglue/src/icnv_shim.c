@@ -75,6 +75,18 @@ SEXP icnv_R_average_bounds(SEXP expr) {
     return r;
 }
 
+/* .Call("icnv_R_scale_genes", expr) -> matrix: t(scale(t(expr))) (scale_infercnv_expr, step 5 of run(), R/inferCNV_ops.R:3174-3185) */
+SEXP icnv_R_scale_genes(SEXP expr) {
+    if (!Rf_isReal(expr) || !Rf_isMatrix(expr)) Rf_error("expr must be a numeric matrix");
+    const int64_t G = Rf_nrows(expr), C = Rf_ncols(expr);
+    SEXP out = PROTECT(Rf_allocMatrix(REALSXP, (int)G, (int)C));
+    int rc = icnv_scale_genes(REAL(expr), REAL(out), G, C);
+    if (rc) { UNPROTECT(1); fail(rc); }
+    Rf_setAttrib(out, R_DimNamesSymbol, Rf_getAttrib(expr, R_DimNamesSymbol));
+    UNPROTECT(1);
+    return out;
+}
+
 /* .Call("icnv_R_remove_outliers", expr, lower_bound, upper_bound) -> matrix; NA bounds = out_method "average_bound"
  * (remove_outliers_norm, step 16 of run(), R/inferCNV_ops.R:1969-2054) */
 SEXP icnv_R_remove_outliers(SEXP expr, SEXP lower_bound, SEXP upper_bound) {
@@ -242,6 +254,7 @@ static const R_CallMethodDef call_methods[] = {
     {"icnv_R_smooth_chain", (DL_FUNC)&icnv_R_smooth_chain, 13},
     {"icnv_R_average_bounds", (DL_FUNC)&icnv_R_average_bounds, 1},
     {"icnv_R_remove_outliers", (DL_FUNC)&icnv_R_remove_outliers, 3},
+    {"icnv_R_scale_genes", (DL_FUNC)&icnv_R_scale_genes, 1},
     {"icnv_R_viterbi_cells", (DL_FUNC)&icnv_R_viterbi_cells, 6},
     {"icnv_R_viterbi_groups", (DL_FUNC)&icnv_R_viterbi_groups, 8},
     {"icnv_R_median_filter", (DL_FUNC)&icnv_R_median_filter, 5},

@@ -176,6 +176,27 @@ def test_remove_outliers_norm_reference_literals_through_the_hip_path(dev):
     assert np.isnan(h[5, 7]) and np.nanmin(h) == 0.8 and np.nanmax(h) == 1.2
 
 
+def test_scale_infercnv_expr_vs_oracle(dev):
+    """Step 5 of run() (scale_data; R/inferCNV_ops.R:3174-3185): t(scale(t(x))) through ops.scale_infercnv_expr ->
+    icnv_scale_genes against the oracle's restatement of scale.default; the hspike mirror; a constant gene becomes NaN as in R."""
+    from infercnv_amd import GeneOrder, InfercnvObject, ops
+    rng = np.random.default_rng(4)
+    x = np.asfortranarray(rng.lognormal(0.5, 0.8, size=(2501, 333)))
+    x[17] = 2.5                                                                           # constant gene: 0 / 0
+    hs = InfercnvObject(expr_data=x[:40, :9].copy() + 1.0, gene_order=GeneOrder(chr=["c"] * 40),
+                        reference_grouped_cell_indices={"a": np.array([0])}, observation_grouped_cell_indices={"b": np.arange(1, 9)})
+    obj = InfercnvObject(expr_data=x, gene_order=GeneOrder(chr=["c"] * x.shape[0]), reference_grouped_cell_indices={"a": np.array([0])},
+                         observation_grouped_cell_indices={"b": np.arange(1, x.shape[1])}, hspike=hs)
+    got = ops.scale_infercnv_expr(obj)
+    want = onp.scale_rows(x)
+    assert np.isnan(got.expr_data[17]).all() and np.isnan(want[17]).all()
+    ok = np.arange(x.shape[0]) != 17
+    assert np.abs(got.expr_data[ok] - want[ok]).max() < 1e-12
+    assert np.abs(got.expr_data[ok].mean(axis=1)).max() < 1e-13 and np.abs(got.expr_data[ok].std(axis=1, ddof=1) - 1.0).max() < 1e-12
+    whs = onp.scale_rows(hs.expr_data)                                                    # (gene 17 is constant there too)
+    assert np.array_equal(np.isnan(got.hspike.expr_data), np.isnan(whs)) and np.nanmax(np.abs(got.hspike.expr_data - whs)) < 1e-12
+
+
 def test_remove_genes_at_ends_of_chromosomes(dev):
     """Step 13 of run() (R/inferCNV_ops.R:3000-3033): (window_length - 1) / 2 genes off either end of every chromosome, a
     short chromosome loses a third at either end, one shorter than 3 genes nothing; rows selected on the device."""
