@@ -1186,7 +1186,10 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
     }
     // the scratch holds the exact kernel's 4-byte back-pointer words; the fast kernel's 2-byte words use its first half
     // (the exact kernel only runs after the fast kernel of the same batch has finished with them)
-    int64_t scratch_budget = (int64_t)4 << 30;   // back-pointer scratch per column batch
+    // back-pointer scratch per column batch: 16 GiB = 429 000 cells at 10 000 genes in ONE launch (a second, small launch
+    // balances its (chromosome, 64 columns) tasks badly over the 4 096 wavefronts: 125 000 cells as 107 000 + 18 000 took
+    // 5.9 ms where one launch takes 5.3); HBM is 288 GB
+    int64_t scratch_budget = (int64_t)16 << 30;
     if (const char *e = std::getenv("ICNV_VITERBI_SCRATCH_MB")) {   // developer switch: small batches for the tests
         const long v = std::atol(e);
         if (v > 0) scratch_budget = (int64_t)v << 20;
