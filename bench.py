@@ -74,36 +74,58 @@ def effective_cores():
     return max(1.0, eff), n, quota
 
 
-def cpu_baseline(G, target_seconds=12.0):
+def cpu_baseline(G, target_seconds=12.0, on_gpu=True):
     """The plain-C oracle (oracle/icnv_oracle.c, OpenMP over cells) timed on this
     host's cores over a bounded sample of the same synthetic workload.  R is not
-    installed in the image, so the reference itself cannot be timed: kind="port"."""
+    installed in the image, so the reference itself cannot be timed: kind="port".
+
+    Returns (cpu_baseline, parity).  The oracle's outputs for the sample are not thrown away: the HIP path runs over the
+    very same sample matrix (outside every timed region) and `parity` reports the comparison -- chain max |delta| on the
+    pre-denoise matrix, the step-22 selects that fall on a bound (each one checked to be a legal flip of the strict
+    select, R/inferCNV_ops.R:2335), and the number of differing i6 state calls, end to end (GPU chain -> GPU Viterbi
+    against oracle chain -> oracle Viterbi)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
     import oracle_c as oc
     from infercnv_amd import synth
     oc.build()
     eff, affinity, quota = effective_cores()
     cores = max(1, int(round(eff)))            # OpenMP threads = the cores the quota lets us keep busy
     oc.set_num_threads(cores)
-    means, sd, logPi, logDelta = synth.hmm_params_i6()
+    hmm = synth.hmm_params_i6()
+    means, sd, logPi, logDelta = hmm
+    if on_gpu:
+        import torch
+        from infercnv_amd import device
 
-    def run(C):
+    def sample(C):
+        """(host matrix (G, C) column-major, chr_start, device copy or None): generated in HBM and downloaded when a GPU
+        is there (the same splitmix64 / Box-Muller generator as the bench matrix; seconds instead of a minute)."""
+        if on_gpu:
+            xd, cs = synth.make_matrix_torch(G, C, "cuda")
+            return xd.cpu().numpy().T, cs, xd
         x, cs = synth.make_matrix_np(G, C)
+        return x, cs, None
+
+    def run(C, keep=False):
+        x, cs, xd = sample(C)
         refs, _ = synth.groups(C)
         t0 = time.perf_counter()
-        _, pre, _ = oc.smooth_chain(x, cs, refs, want_pre_denoise=True)
-        oc.viterbi_cells(pre, cs, means, sd, logPi, logDelta)
-        return time.perf_counter() - t0
+        out, pre, musd = oc.smooth_chain(x, cs, refs, want_pre_denoise=True)
+        st, _ = oc.viterbi_cells(pre, cs, means, sd, logPi, logDelta)
+        t = time.perf_counter() - t0
+        return (t, (xd, cs, refs, out, pre, musd, st)) if keep else (t, None)
 
     # pilot sized so that every thread gets several cells, then scale to ~target_seconds of CPU work
     pilot_c = max(512, 8 * cores)
     run(pilot_c)                                   # first call also pays thread start-up / page faults
-    t_pilot = run(pilot_c)
+    t_pilot, _ = run(pilot_c)
     C = int(min(60000, max(pilot_c, pilot_c * target_seconds / max(t_pilot, 1e-3))))
-    t = run(C)
+    t, kept = run(C, keep=True)
     if t < 0.6 * target_seconds and C < 60000:     # the pilot under-estimated the parallel speed: one larger sample
         C = int(min(60000, C * target_seconds / max(t, 1e-3)))
-        t = run(C)
+        kept = None
+        t, kept = run(C, keep=True)
     res = {"value": C / t, "unit": "cells/s", "cores": oc.num_threads(), "cores_note": (
                f"{oc.num_threads()} OpenMP threads = the CPU quota of this container ({quota:.1f} cores) "
                f"of {os.cpu_count()} logical CPUs on the node" if quota else
@@ -111,15 +133,48 @@ def cpu_baseline(G, target_seconds=12.0):
            "kind": "port",
            "sample": f"{G} genes x {C} cells of the same synthetic generator, smooth chain + i6 Viterbi, "
                      f"oracle/icnv_oracle.c with OpenMP over cells, {t:.1f} s"}
+    parity = None
+    if on_gpu:
+        xd, cs, refs, ref_out, ref_pre, (mu, s), ref_st = kept
+        out, pre = device.smooth_chain(xd, cs, refs, want_pre_denoise=True)
+        st, bad = device.viterbi_cells(pre, cs, means, sd, logPi, logDelta)
+        torch.cuda.synchronize()
+        r_pre = torch.from_numpy(ref_pre.T).cuda()             # (C, G) views of the oracle's column-major matrices
+        r_out = torch.from_numpy(ref_out.T).cuda()
+        tol = 1e-11 * max(1.0, float(r_pre.abs().max()))
+        chain_max_abs = float((pre - r_pre).abs().max())
+        diff = (out - r_out).abs() > tol
+        flips = int(diff.sum())
+        legal = True
+        if flips:                                              # every differing select sits on a bound and holds a legal value
+            p, g = r_pre[diff], out[diff]
+            on_bound = torch.minimum((p - (mu - s)).abs(), (p - (mu + s)).abs()) <= 2.0 * tol
+            legal = bool((on_bound & (((g - mu).abs() <= tol) | ((g - p).abs() <= tol))).all())
+        r_st = torch.from_numpy(ref_st.T).cuda()
+        bad_cells = torch.nonzero((st != r_st).any(dim=1)).flatten()
+        mism = int((st != r_st).sum())
+        same_input = 0
+        if mism:                                               # the contract is bit-exactness on IDENTICAL inputs: redo those cells
+            want, _ = oc.viterbi_cells(pre[bad_cells].cpu().numpy().T, cs, means, sd, logPi, logDelta)
+            same_input = int((st[bad_cells].cpu().numpy().T != want).sum())
+        parity = {"cells": C, "genes": G, "chain_max_abs": chain_max_abs, "chain_tolerance_abs": 1e-11,
+                  "chain_max_rel": chain_max_abs / max(float(r_pre.abs().max()), 1e-300), "north_star_rel_tolerance": 1e-5,
+                  "denoise_flips": flips, "denoise_flips_all_on_a_bound_and_legal": legal,
+                  "state_calls": C * G, "state_mismatches": mism, "state_mismatches_on_identical_inputs": same_input,
+                  "viterbi_sequences_redone_exactly": int(device.viterbi_last_stats()["flagged"]),
+                  "ok": bool(chain_max_abs <= 1e-11 and legal and same_input == 0 and int(bad.item()) == 0),
+                  "what": "HIP path (C ABI, device-resident) vs the oracle's outputs for the cpu_baseline sample: the same matrix, "
+                          "every cell; outside the timed region"}
+        del kept, xd, out, pre, st, r_pre, r_out, r_st
     # the reference's own structure is serial R: one core of the same port, a few seconds
     oc.set_num_threads(1)
     c1 = 512
-    t1 = run(c1)
+    t1, _ = run(c1)
     oc.set_num_threads(cores)
     res["single_thread"] = {"value": c1 / t1, "unit": "cells/s", "cores": 1,
                             "sample": f"{G} genes x {c1} cells, same code on one core, {t1:.1f} s"}
     res["parallel_speedup_over_one_core"] = res["value"] / res["single_thread"]["value"]
-    return res
+    return res, parity
 
 
 def host_path_rate(x_dev, chr_start, refs, hmm, cells=20000):
@@ -479,7 +534,8 @@ def main():
                 res["host_path"] = host_path_rate(x, chr_start, refs_local, (means, sd, logPi, logDelta))
             except Exception as e:          # a reported side figure must not take the bench line down
                 res["host_path"] = {"error": str(e)[:200]}
-            res["cpu_baseline"] = cpu_baseline(G)
+            del x, out, states, chain, plan        # the bench tensors: the parity leg below holds its own sample in HBM
+            res["cpu_baseline"], res["parity"] = cpu_baseline(G)
         elif not args.no_cpu_baseline:
             res["cpu_baseline"] = None
         print(json.dumps(res))

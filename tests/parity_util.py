@@ -32,3 +32,24 @@ def check_denoise_flips(got_out, ref_out, ref_pre, mu, s, tol=1e-11, expect=None
     if expect is not None:
         assert n == expect, (label, n, expect)
     return n
+
+
+def check_denoise_flips_t(got_out, ref_out, ref_pre, mu, s, tol=1e-11, expect=None, label=""):
+    """`check_denoise_flips` on torch tensors (CUDA or CPU) of any shape: the same rule, evaluated where the tensors
+    live -- the full-size tests compare 5e8 elements per matrix and do it on the GPU."""
+    import torch
+    scale = max(1.0, float(ref_pre.abs().max())) if ref_pre.numel() else 1.0
+    atol = tol * scale
+    diff = (got_out - ref_out).abs() > atol
+    n = int(diff.sum())
+    if n:
+        lo, hi = mu - s, mu + s
+        p = ref_pre[diff]
+        dist = torch.minimum((p - lo).abs(), (p - hi).abs())
+        assert bool((dist <= 2.0 * atol).all()), (label, n, float(dist.max()))
+        g = got_out[diff]
+        assert bool((((g - mu).abs() <= atol) | ((g - p).abs() <= atol)).all()), (label, n)
+    print(f"[denoise flips] {label or 'chain'}: {n} of {got_out.numel()} elements differ in the strict select")
+    if expect is not None:
+        assert n == expect, (label, n, expect)
+    return n
