@@ -1197,7 +1197,7 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
     int64_t batch = scratch_budget / ((int64_t)G * 4);
     batch = std::max<int64_t>(64, (batch / 64) * 64);
     batch = std::min(batch, ((ncols + 63) / 64) * 64);
-    if ((rc = d_bp.alloc((size_t)G * (size_t)batch * 4))) return rc;
+    if ((rc = d_bp.alloc(std::max((size_t)G * (size_t)batch * 4, fast ? viterbi_fast_scratch_bytes((int32_t)G, n_chr, batch) : (size_t)0)))) return rc;
     if (fast) {
         if ((rc = d_list.alloc((size_t)2 * n_chr * batch * sizeof(int32_t)))) return rc;
         if ((rc = d_redo.alloc(viterbi_redo_scratch_bytes(max_len)))) return rc;

@@ -210,12 +210,12 @@ struct FastViterbiArgs {
     double inv_w;               // interval of x = (int)((x - x_lo) * inv_w)
     double eps;                 // eps_tab + eps_spec
     double b0, s_step;          // |value| bound of the recurrence: B = b0 + (n + 1) s_step
-    uint16_t *bp;               // [G][ncols]
+    uint16_t *bp;               // [G][ncols] words, then [(G >> 4) + 3 n_chr][ncols] block summaries (viterbi_fast_scratch_bytes)
     int32_t *task_counter;      // zeroed before the launch
     int32_t *flag_count;        // zeroed before the launch
     int32_t *flag_list;         // [2 * n_chr * ncols] (chromosome, column) pairs
 };
-size_t viterbi_fast_scratch_bytes(int32_t G, int64_t n_cols);
+size_t viterbi_fast_scratch_bytes(int32_t G, int32_t n_chr, int64_t n_cols);
 size_t viterbi_fast_lds_bytes(int K, int n_int, int n_grid);
 int viterbi_fast_max_intervals(int K);
 void viterbi_fast_table_image(const EmisTable &t, std::vector<double> &img);

@@ -187,6 +187,15 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         // back-pointers of this task: n rows of 64 lanes, contiguous (one 128-byte line per gene and wavefront, the
         // rows of a task next to each other in memory -- the forward pass writes and the traceback reads a stream)
         uint16_t *bpc = A.bp + ((int64_t)s0 * (ncg * 64) + (task % ncg) * 64 * (int64_t)n + lane);
+        // block summaries (viterbi_trace.h: viterbi_traceback_blocks): behind the G rows of words, chromosome c owns the rows
+        // [(s0 >> 4) + 3 c, (s0_next >> 4) + 3 (c + 1)) -- at least (n >> 4) + 3 of them, a task touches at most (n >> 4) + 2
+        // aligned 16-gene blocks -- laid out like the words: the rows of a task next to each other
+        const int sum_rows = ((s0 + n) >> 4) - (s0 >> 4) + 3;
+        uint16_t *bsum = A.bp + ((int64_t)A.G + (s0 >> 4) + 3 * chr) * (ncg * 64) + ((task % ncg) * 64 * (int64_t)sum_rows + lane);
+        // byte position of gene 0 inside its 16-byte word of the state column: wave-uniform whenever G is a multiple of 16
+        const int a0 = (int)((uintptr_t)st & 15u);
+        const int a0u = __builtin_amdgcn_readfirstlane(a0);
+        const bool a0_uniform = __builtin_amdgcn_ballot_w64(a0 != a0u) == 0;
             // decision band of this task: 4 (n + 1) (eps + 6 u B), B = |logDelta|max + |a| + (n + 1)(s_max + |b|)
         const double np1 = (double)(n + 1);
         const double B = A.b0 + np1 * A.s_step;
@@ -197,6 +206,7 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         const double *gridp = tab + A.n_int * rec_doubles(K);   // (wave-uniform) the grid entries behind the records
 
         double nu[K];
+        uint32_t sacc = 0;      // OR of the back-pointer words of the current 16-gene block
         uint64_t seqflag = 0;   // lanes with an observation the table cannot score: the whole sequence goes to the exact kernel
         // Scores of one observation from the table, in two stages so that the LDS round trips of several genes
         // overlap: locate() finds the interval (lookup cell -> segment record -> interval index) and the position
@@ -282,6 +292,7 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
                 }
             }
             bpc[i * 64] = (uint16_t)word;
+            sacc |= word;
             nu[0] = max_raw(nu[0], c);
             constexpr int KA = (K - 1) < 2 ? (K - 1) : 2;    // states of batch A
             auto score_rows = [&](auto k0c, auto k1c, int idxq) {
@@ -299,6 +310,13 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
                 int idxb = idx;
                 asm volatile("" : "+v"(idxb) : "v"(nu[KA]));   // batch B's gathers behind batch A's arithmetic
                 score_rows(std::integral_constant<int, (K - 1 > KA ? KA + 1 : 1)>{}, std::integral_constant<int, K - 1>{}, idxb);
+            }
+        };
+        auto gene_s = [&](double xv, int i) {   // a gene outside the chunk loop: it may close a block
+            gene(xv, i);
+            if (((a0u + i) & 15) == 15) {
+                bsum[((a0u + i) >> 4) * 64] = (uint16_t)sacc;
+                sacc = 0;
             }
         };
         {
@@ -330,8 +348,11 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             constexpr uint32_t AL = CH * 8;
             int peel = (int)(((AL - (uint32_t)(a0 & (AL - 1))) & (AL - 1)) >> 3);
             peel = __builtin_amdgcn_readfirstlane(peel);
-            for (; peel > 0 && i < n; --peel, ++i) gene(xc[i], i);
+            for (; peel > 0 && i < n; --peel, ++i) gene_s(xc[i], i);
         }
+        // the chunks are whole halves of the 16-gene blocks when the observations' 64-byte alignment and the states' 16-byte
+        // alignment go together (always, for G a multiple of 16 and aligned matrices): a block then ends with a chunk
+        const bool use_sum = a0_uniform && ((a0u + i) & 7) == 0;
         if (i + CH <= n) {
             double xcur[CH], xnext[CH];
             load_chunk(xc + i, xcur);
@@ -340,13 +361,17 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
                 if (more) load_chunk(xc + i + CH, xnext);
 #pragma unroll
                 for (int j = 0; j < CH; ++j) gene(xcur[j], i + j);
+                if (use_sum && ((a0u + i) & 8)) {
+                    bsum[((a0u + i) >> 4) * 64] = (uint16_t)sacc;
+                    sacc = 0;
+                }
                 if (more) {
 #pragma unroll
                     for (int j = 0; j < CH; ++j) xcur[j] = xnext[j];
                 }
             }
         }
-        for (; i < n; ++i) gene(xc[i], i);
+        for (; i < n; ++i) gene_s(xc[i], i);
         ARGS_HERE();
         // last row: R's which.max
         double m1 = nu[0], m2 = -__builtin_inf();
@@ -370,9 +395,10 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
                 uacc |= tsh;
                 return (tsh & 1u) ? (int)((w >> 6) & 7u) : c;
             };
-            const int a0 = (int)((uintptr_t)st & 15u);
-            const int a0u = __builtin_amdgcn_readfirstlane(a0);
-            if (__builtin_amdgcn_ballot_w64(a0 != a0u) == 0) viterbi_traceback_uniform<FAST_TB>(st, n, cur, a0u, load_bp, step_bp);
+            auto load_sum = [&](int b) { return (uint32_t)bsum[b * 64]; };
+            auto note_sum = [&](uint32_t S, int c) { uacc |= S >> c; };
+            if (use_sum) viterbi_traceback_blocks(st, n, cur, a0u, load_bp, load_sum, step_bp, note_sum);
+            else if (a0_uniform) viterbi_traceback_uniform<FAST_TB>(st, n, cur, a0u, load_bp, step_bp);
             else viterbi_traceback<FAST_TG>(st, n, cur, load_bp, step_bp);
             unsure |= (uacc >> 9) & 1u;
         }
@@ -389,8 +415,9 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
 
 }  // namespace
 
-size_t viterbi_fast_scratch_bytes(int32_t G, int64_t n_cols) {   // columns in blocks of 64
-    return (size_t)G * (size_t)((n_cols + 63) / 64 * 64) * sizeof(uint16_t);
+size_t viterbi_fast_scratch_bytes(int32_t G, int32_t n_chr, int64_t n_cols) {   // columns in blocks of 64
+    // G rows of back-pointer words, then the block summaries: (G >> 4) + 3 n_chr rows (see the kernel)
+    return ((size_t)G + (size_t)(G >> 4) + 3 * (size_t)n_chr + 1) * (size_t)((n_cols + 63) / 64 * 64) * sizeof(uint16_t);
 }
 size_t viterbi_fast_lds_bytes(int K, int n_int, int n_grid) { return ((size_t)n_int * rec_doubles(K) + 2 * (size_t)n_grid) * sizeof(double); }
 int viterbi_fast_max_intervals(int K) {

@@ -106,4 +106,60 @@ __device__ inline void viterbi_traceback_uniform(uint8_t *st, int n, int cur, in
     }
 }
 
+// Traceback over BLOCK SUMMARIES (certified fast kernel, wave-uniform alignment a0 as above).  The forward pass also writes,
+// for every aligned block of 16 genes, the OR of the block's back-pointer words.  Bit `cur` of a summary clear means
+// "row cur kept itself at every gene of the block": the traced path stays in `cur` for all 16 genes, whatever the other
+// rows did -- 16 output bytes from one 2-byte load and a handful of instructions instead of 16 loads and 16 dependent
+// steps.  A path changes its state a few times per sequence, so nearly every block takes that road; the per-gene words
+// are read only for a block in which some lane's row did not keep itself (wave-uniform test), and for the partial blocks
+// at either end.
+// load_sum(b) -> summary of block b = (a0 + gene) >> 4;  note_sum(S, cur): account the summary's "inside the band" bits
+template <class Load, class LoadSum, class Step, class NoteSum>
+__device__ inline void viterbi_traceback_blocks(uint8_t *st, int n, int cur, int a0, Load load, LoadSum load_sum, Step step,
+                                                NoteSum note_sum) {
+    constexpr int TB = 16;
+    int g = n - 1;
+    while (g >= 0 && ((a0 + g) & 15) != 15) {   // top partial word
+        st[g] = (uint8_t)(cur + 1);
+        if (g > 0) cur = step(load(g), cur);
+        --g;
+    }
+    uint32_t Sn = 0;
+    if (g >= TB) Sn = load_sum((a0 + g) >> 4);
+    while (g >= TB) {   // genes g .. g-15 fill one aligned 16-byte word, all of them have a predecessor
+        const uint32_t S = Sn;
+        if (g - TB >= TB) Sn = load_sum((a0 + g - TB) >> 4);   // the next block's summary, a block ahead
+        uint4 *dst = reinterpret_cast<uint4 *>(st + g - (TB - 1));
+        if (__builtin_amdgcn_ballot_w64(((S >> cur) & 1u) != 0) == 0) {
+            note_sum(S, cur);
+            const uint32_t v = (uint32_t)(cur + 1) * 0x01010101u;
+            uint4 o;
+            o.x = v; o.y = v; o.z = v; o.w = v;
+            *dst = o;
+        } else {
+            uint32_t W[TB];
+#pragma unroll
+            for (int j = 0; j < TB; ++j) W[j] = load(g - j);
+            uint32_t d[TB / 4];
+#pragma unroll
+            for (int q = 0; q < TB / 4; ++q) d[q] = 0;
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                const int byte = TB - 1 - j;
+                d[byte >> 2] |= (uint32_t)cur << (8 * (byte & 3));
+                cur = step(W[j], cur);
+            }
+            uint4 o;
+            o.x = d[0] + 0x01010101u; o.y = d[1] + 0x01010101u; o.z = d[2] + 0x01010101u; o.w = d[3] + 0x01010101u;
+            *dst = o;
+        }
+        g -= TB;
+    }
+    while (g >= 0) {   // bottom partial block and gene 0's group
+        st[g] = (uint8_t)(cur + 1);
+        if (g > 0) cur = step(load(g), cur);
+        --g;
+    }
+}
+
 }  // namespace icnv

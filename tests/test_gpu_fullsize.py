@@ -61,7 +61,7 @@ def run50k(dev):
 def oracle_slices(r):
     """For every block of observation cells: (global cell indices of the rows to compare, oracle denoised, oracle
     pre-denoise -- both as (cells, G) CUDA tensors of those rows --, (mu, s), the slice's full host pre-denoise matrix
-    (G, n_ref + block) and the position of the compared rows inside the slice).  The first slice also yields the
+    (G, n_ref + block), the position of the compared rows inside the slice and the block's observation cells [a, b)).  The first slice also yields the
     reference cells."""
     n_ref, x = r["n_ref"], r["x"]
     ref_rows = torch.arange(n_ref, device="cuda")
@@ -74,7 +74,7 @@ def oracle_slices(r):
         lo = 0 if first else n_ref
         cmp_rows = rows[lo:]
         yield (cmp_rows, torch.from_numpy(ref_out.T[lo:]).cuda(), torch.from_numpy(ref_pre.T[lo:]).cuda(), musd,
-               ref_pre, lo)
+               ref_pre, lo, (a, b))
         first = False
 
 
@@ -86,7 +86,7 @@ def test_config2_chain_and_states_vs_oracle_every_cell(dev, run50k):
     worst, flips, seen = 0.0, 0, 0
     mism_same_input, mism_end_to_end = 0, 0
     musd0 = None
-    for rows, ref_out, ref_pre, musd, ref_pre_host, lo in oracle_slices(r):
+    for rows, ref_out, ref_pre, musd, ref_pre_host, lo, _ in oracle_slices(r):
         musd0 = musd0 or musd
         assert musd == musd0, "the oracle's step-22 parameters must not depend on the slice"
         got_pre, got_out = r["pre"][rows], r["out"][rows]
@@ -129,9 +129,7 @@ def test_config4_i3_subclusters_vs_oracle_every_subcluster(dev, run50k):
     torch.cuda.synchronize()
     assert int(bad.item()) == 0
     mismatches, groups_seen = 0, 0
-    for rows, _, _, _, ref_pre_host, lo in oracle_slices(r):
-        a = int(rows[n_ref])                                           # first observation cell of the slice
-        b = int(rows[-1]) + 1
+    for _, _, _, _, ref_pre_host, lo, (a, b) in oracle_slices(r):
         o_mu, o_sigma = oc.mean_sd_of_cells(ref_pre_host, ref_idx)     # reference cells sit at 0..n_ref-1 of every slice
         assert abs(o_mu - mu) < 1e-12 and abs(o_sigma - sigma) < 1e-12
         o_delta = abs(-1.6448536269514722 * o_sigma)
