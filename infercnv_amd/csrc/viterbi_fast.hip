@@ -28,7 +28,7 @@
 // comparison  nu_k + b  vs  nu_i1 + a  (row i1 keeps itself: b - a is far outside the band):
 // 2 K + 5 (K - 1) operations instead of 4 K^2.  Back-pointers shrink to K bits + i1 (uint16).
 //
-// Mapping: persistent workgroups of 16 wavefronts -- four per SIMD -- (the table fills most of the CU's LDS),
+// Mapping: persistent workgroups of 12 wavefronts -- three per SIMD -- (the table fills most of the CU's LDS),
 // every wavefront pulls (chromosome, 64-column block) tasks, longest chromosomes first, one lane per
 // sequence as in the exact kernel.
 #include <algorithm>
@@ -46,20 +46,27 @@ namespace icnv {
 namespace {
 
 // Launch geometry and chunk sizes (measured choices; experiments with other values are built as replacement translation
-// units by scripts/viterbi_variants.py / scripts/build_variant.sh, never by -D switches on this file).
-// Round 3: 1024 threads = FOUR wavefronts per SIMD at <= 128 registers.  Rounds 1-2 ran 512 threads (2 per SIMD, 256
-// registers): with the scheduler free to request all coefficient gathers of several genes at once the gene loop
-// needs ~250 registers, and every larger workgroup spilled (768 threads: 3.0-3.3 ms against 2.32).  The register-lean gene
-// step below (bookkeeping first, scores gathered and consumed in two batches behind fake dependences, the launch
-// descriptor re-read from the kernel-argument segment instead of living in ~60 scalar registers that spill into VGPR lanes)
-// fits 128 registers without scratch in the gene loop: 512 threads 2.47 ms (the serialisation costs when only two
-// wavefronts hide it), 768 threads 2.22, 1024 threads 2.19 ms -- the vector pipe is then 81 % busy, the LDS pipe 71 %.
-// What is left is the instruction count: degree-4 polynomials on sd / 15 intervals (emission_table.cpp) instead of degree 5
-// on sd / 12 take five multiply-adds and two 16-byte gathers per gene off it (96 vector + 16 LDS instructions): -4 %.
-constexpr int FAST_NT = 1024;
+// units or with -DVF_NT / -DVF_CH by scripts/build_variant.sh, never shipped).
+// Round 4: 768 threads = THREE wavefronts per SIMD (<= 168 registers), 128-byte observation chunks.  What round 4's
+// ablations showed (docs/KERNEL_LOG.md): with the observations served from 256 L2-resident columns the 1024-thread kernel
+// of round 3 takes 1.73 instead of 2.1 ms, without the back-pointer stores it takes the same 2.1 -- the launch was paced
+// by the observation stream (1024 lanes per CU each fetching HALF a 128-byte line per request from a column of its own:
+// 4 MiB of lines in flight per XCD = the whole L2, every half line fetched twice, DRAM rows opened for 64 bytes), not by
+// the vector or LDS pipes: taking 10 % of the vector instructions out (block summaries for the traceback) or hiding both
+// LDS round trips of a gene behind the decision bookkeeping changed nothing at 1024 threads.  With the gene step software-
+// pipelined (below) three wavefronts per SIMD are enough to keep the pipes as busy, the 40 registers they free hold a
+// whole 128-byte line per lane and request, and the lines in flight fit the L2: 2.17-2.29 -> 2.00-2.07 ms on one box
+// (1024 threads / 64-byte chunks -> 768 / 128; 512 threads 2.08, 768 / 64-byte 2.13-2.16, 256-byte chunks spill).
+#ifndef VF_NT
+#define VF_NT 768
+#endif
+constexpr int FAST_NT = VF_NT;
 constexpr int FAST_TG = 8;    // traceback group of the non-uniform-alignment walk: 2 x 8 back-pointer lines in flight (registers)
 constexpr int FAST_TB = 16;   // genes per block of the uniform-alignment traceback (16: 2.54 ms, 32: 2.58, 64: 2.61)
-constexpr int FAST_CH = 8;    // genes per observation chunk: 64 bytes per lane and request
+#ifndef VF_CH
+#define VF_CH 16
+#endif
+constexpr int FAST_CH = VF_CH;    // genes per observation chunk: 128 bytes = one whole cache line per lane and request
 constexpr int NCF = EMIS_DEG + 1;
 // coefficient record of one interval: (K - 1) x NCF doubles (scores relative to state 1, whose row is not stored),
 // state after state, padded to an ODD number of 16-byte bank groups (the lanes' random intervals then spread over all LDS
@@ -259,11 +266,31 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         // exists.  Fake dependences (empty asm) keep batch B's gathers behind batch A's arithmetic and a gene behind its
         // predecessor: left to itself the scheduler requests all gathers of several genes at once (50-60 registers
         // per gene) -- the right thing with 256 registers, spills with 168 or 128.
-        auto gene = [&](double xv, int i) {
-            asm volatile("" : "+v"(xv) : "v"(nu[K - 1]));      // this gene starts when the previous one's last row is done
-            double tn;
-            int idx;
-            locate(xv, idx, tn);
+        // Software pipeline across genes: the record of gene i + 1 is located while gene i runs (idx_c / tn_c hold the current
+        // gene's), so a gene starts with its batch-A gathers already addressable; the instruction order below is pinned with
+        // scheduling barriers:  gathers A, locate(i + 1) | candidates and keep bits | rows of batch A, gathers B | near-top word,
+        // band test, back-pointer store | rows of batch B.  Both LDS round trips of the gene hide behind the ~50 vector
+        // instructions of decision bookkeeping that need no score (before: gathers A waited for, rows A, gathers B waited for).
+        int idx_c = 0;
+        double tn_c = 0.0;
+        auto gene = [&](double xv_next, int i) {
+            constexpr int KA = (K - 1) < 2 ? (K - 1) : 2;    // states of batch A
+            constexpr int KB0 = (K - 1 > KA) ? KA + 1 : 1;   // first state of batch B (if any)
+            constexpr int pA1 = (KA * NCF + 1) / 2;                                   // pairs [0, pA1) hold the states 1..KA
+            constexpr int pB0 = ((KB0 - 1) * NCF) / 2, pB1 = ((K - 1) * NCF + 1) / 2;  // pairs of the states KB0..K-1
+            const int idx_here = idx_c;
+            const double *cq = coef + idx_here;
+            const double tn = tn_c;
+            dbl2_t qa[pA1];
+#pragma unroll
+            for (int p = 0; p < pA1; ++p) qa[p] = *reinterpret_cast<const dbl2_t *>(cq + 2 * p);
+            // the successor's grid entry rides behind the gathers; it is consumed together with them after the first block
+            const double xs_n = max_raw_s(min_raw_s(xv_next, x_hi_s), x_lo_s);
+            seqflag |= __builtin_amdgcn_ballot_w64(!(xs_n == xv_next));
+            const double u_n = (xs_n - x_lo_s) * inv_w_s;
+            const int j_n = (int)u_n;
+            const double2 ge_n = *reinterpret_cast<const double2 *>(gridp + 2 * j_n);
+            __builtin_amdgcn_sched_barrier(0);
             double m1 = nu[0];
 #pragma unroll
             for (int k = 1; k < K; ++k) m1 = max_raw(m1, nu[k]);
@@ -278,6 +305,33 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
                 amin = (k == K - 1) ? __builtin_fabs(e[k]) : __builtin_fmin(amin, __builtin_fabs(e[k]));
             }
             const uint64_t band = __builtin_amdgcn_ballot_w64(!(amin > thr));
+            nu[0] = max_raw(nu[0], c);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const int r = (int)(uint32_t)__double_as_longlong(ge_n.y) + ((xs_n >= ge_n.x) ? 1 : 0);
+                tn_c = (u_n - (double)j_n) - 0.5;
+                idx_c = (int)__umul24((uint32_t)r, (uint32_t)REC);
+            }
+#pragma unroll
+            for (int k = 1; k <= KA; ++k) nu[k] = max_raw(nu[k], c) + horner(qa, 0, (k - 1) * NCF, tn);
+            dbl2_t qb[(K - 1 > KA) ? (pB1 - pB0) : 1];
+            if (K - 1 > KA) {
+                // batch B's gathers behind batch A's arithmetic (an empty asm makes their address depend on A's rows): with all
+                // thirteen quads requested at once the step does not fit 128 registers, and a single scratch reload costs a
+                // vmcnt(0) -- a drain of every outstanding store and observation load of the wavefront
+                int idxb = idx_here;
+                if (KA >= 2) asm volatile("" : "+v"(idxb) : "v"(nu[1]), "v"(nu[KA]));
+                else asm volatile("" : "+v"(idxb) : "v"(nu[KA]));
+                const double *cqb = coef + idxb;
+#pragma unroll
+                for (int p = pB0; p < pB1; ++p) {
+                    // (an odd number of coefficients: the last pair's upper half is padding -- read 8 bytes, or the dead half of
+                    // the destination is handed out again and its next writer waits for the LDS: an lgkmcnt(0) in mid-flight)
+                    if (p == pB1 - 1 && (((K - 1) * NCF) & 1)) qb[p - pB0].x = *(cqb + 2 * p);
+                    else qb[p - pB0] = *reinterpret_cast<const dbl2_t *>(cqb + 2 * p);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
             const uint32_t near = near_top_bits<K>(e, t2);
             const uint32_t i1 = (uint32_t)__builtin_ctz(near | 0x80u);
             const uint64_t two_near = __builtin_amdgcn_ballot_w64(__builtin_popcount(near) != 1);
@@ -293,27 +347,14 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             }
             bpc[i * 64] = (uint16_t)word;
             sacc |= word;
-            nu[0] = max_raw(nu[0], c);
-            constexpr int KA = (K - 1) < 2 ? (K - 1) : 2;    // states of batch A
-            auto score_rows = [&](auto k0c, auto k1c, int idxq) {
-                constexpr int k0 = decltype(k0c)::value, k1 = decltype(k1c)::value;
-                constexpr int p0 = ((k0 - 1) * NCF) / 2, p1 = (k1 * NCF + 1) / 2;   // pairs that hold the states k0..k1
-                const double *cq = coef + idxq;
-                dbl2_t q[p1 - p0];
-#pragma unroll
-                for (int p = p0; p < p1; ++p) q[p - p0] = *reinterpret_cast<const dbl2_t *>(cq + 2 * p);
-#pragma unroll
-                for (int k = k0; k <= k1; ++k) nu[k] = max_raw(nu[k], c) + horner(q, p0, (k - 1) * NCF, tn);
-            };
-            score_rows(std::integral_constant<int, 1>{}, std::integral_constant<int, KA>{}, idx);
+            __builtin_amdgcn_sched_barrier(0);
             if (K - 1 > KA) {
-                int idxb = idx;
-                asm volatile("" : "+v"(idxb) : "v"(nu[KA]));   // batch B's gathers behind batch A's arithmetic
-                score_rows(std::integral_constant<int, (K - 1 > KA ? KA + 1 : 1)>{}, std::integral_constant<int, K - 1>{}, idxb);
+#pragma unroll
+                for (int k = KB0; k <= K - 1; ++k) nu[k] = max_raw(nu[k], c) + horner(qb, pB0, (k - 1) * NCF, tn);
             }
         };
-        auto gene_s = [&](double xv, int i) {   // a gene outside the chunk loop: it may close a block
-            gene(xv, i);
+        auto gene_s = [&](int i) {   // a gene outside the chunk loop: its successor's observation comes by itself; it may close a block
+            gene(xc[(i + 1 < n) ? i + 1 : i], i);
             if (((a0u + i) & 15) == 15) {
                 bsum[((a0u + i) >> 4) * 64] = (uint16_t)sacc;
                 sacc = 0;
@@ -326,8 +367,9 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             poly(idx0, tn0, sc);
 #pragma unroll
             for (int k = 0; k < K; ++k) nu[k] = A.logDelta[k] + sc[k];
+            locate(xc[1], idx_c, tn_c);   // n >= 2
         }
-        // Observations are streamed CH genes (64 bytes, one aligned half cache line when G is a multiple of 8) per
+        // Observations are streamed CH genes (128 bytes, one aligned cache line when G is a multiple of 16) per
         // lane and request: every lane walks its own column, so the memory system sees 64 streams per wavefront;
         // 8-byte requests would fetch each line sixteen times through an L1 that cannot hold 1024 of them, and
         // small unaligned pieces of a DRAM burst arrive as separate requests long after the burst was evicted.
@@ -343,25 +385,29 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             }
         };
         int i = 1;
-        {   // wave-uniform peel up to lane 0's next 64-byte boundary
+        {   // wave-uniform peel up to lane 0's next chunk (cache line) boundary
             const uint64_t a0 = (uint64_t)(uintptr_t)(xc + 1);
             constexpr uint32_t AL = CH * 8;
             int peel = (int)(((AL - (uint32_t)(a0 & (AL - 1))) & (AL - 1)) >> 3);
             peel = __builtin_amdgcn_readfirstlane(peel);
-            for (; peel > 0 && i < n; --peel, ++i) gene_s(xc[i], i);
+            for (; peel > 0 && i < n; --peel, ++i) gene_s(i);
         }
-        // the chunks are whole halves of the 16-gene blocks when the observations' 64-byte alignment and the states' 16-byte
+        // the chunks are the 16-gene blocks of the summaries when the observations' line alignment and the states' 16-byte
         // alignment go together (always, for G a multiple of 16 and aligned matrices): a block then ends with a chunk
-        const bool use_sum = a0_uniform && ((a0u + i) & 7) == 0;
+        const bool use_sum = a0_uniform && ((a0u + i) & (CH - 1)) == 0;
         if (i + CH <= n) {
+            // the chunk behind the current one is requested before the current one's genes run: one chunk (16 gene steps) of lead.
+            // (Two buffers taking turns without the copy -- the loop body twice -- measured 5 % slower: 2.10 against 2.00 ms.)
             double xcur[CH], xnext[CH];
             load_chunk(xc + i, xcur);
             for (; i + CH <= n; i += CH) {
                 const bool more = i + 2 * CH <= n;
                 if (more) load_chunk(xc + i + CH, xnext);
+                // (the observation behind the chunk: the next chunk's first, or -- last chunk -- the tail's first gene, if any)
+                const double x_behind = more ? xnext[0] : xc[(i + CH < n) ? i + CH : i + CH - 1];
 #pragma unroll
-                for (int j = 0; j < CH; ++j) gene(xcur[j], i + j);
-                if (use_sum && ((a0u + i) & 8)) {
+                for (int j = 0; j < CH; ++j) gene((j + 1 < CH) ? xcur[j + 1] : x_behind, i + j);
+                if (use_sum && ((a0u + i + CH) & 15) == 0) {
                     bsum[((a0u + i) >> 4) * 64] = (uint16_t)sacc;
                     sacc = 0;
                 }
@@ -371,7 +417,7 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
                 }
             }
         }
-        for (; i < n; ++i) gene_s(xc[i], i);
+        for (; i < n; ++i) gene_s(i);
         ARGS_HERE();
         // last row: R's which.max
         double m1 = nu[0], m2 = -__builtin_inf();

@@ -4,9 +4,10 @@ instructions between the markers around the CH unrolled genes, divided by CH."""
 import collections, os, re, subprocess, sys, tempfile
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "infercnv_amd", "csrc")
 src = open(os.path.join(root, "viterbi_fast.hip")).read()
-anchor = "#pragma unroll\n                for (int j = 0; j < CH; ++j) gene(xcur[j], i + j);\n"
-assert anchor in src
-src = src.replace(anchor, 'asm volatile("; MARK begin");\n' + anchor + 'asm volatile("; MARK end");\n', 1)
+begin = "                const double x_behind = more ? xnext[0] : xc[(i + CH < n) ? i + CH : i + CH - 1];\n"
+end = "                if (use_sum && ((a0u + i + CH) & 15) == 0) {\n"
+assert begin in src and end in src
+src = src.replace(begin, begin + 'asm volatile("; MARK begin");\n', 1).replace(end, 'asm volatile("; MARK end");\n' + end, 1)
 tmp = tempfile.mkdtemp()
 open(os.path.join(tmp, "vf.hip"), "w").write(src)
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + root,
@@ -30,5 +31,7 @@ for K in (6, 3):
         elif op.startswith("scratch_"): c["scratch"] += 1
         elif op.startswith(("global_", "buffer_", "flat_")): c["vmem"] += 1
         else: c["other"] += 1
-    ch = 8
+    ch = 16
+    for a_ in sys.argv[1:]:
+        if a_.startswith('-DVF_CH='): ch = int(a_.split('=')[1])
     print("K=%d per gene:" % K, {k: round(v / ch, 1) for k, v in sorted(c.items())})
