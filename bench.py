@@ -432,7 +432,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = C_total * args.steps / elapsed
         kernels = {}
-        for k in ("chain_apply", "chain2_apply", "chain_apply_ref", "chain_stage_ref", "chain2_stage_ref", "chain_gene_sums", "chain_cell_stats", "viterbi", "viterbi_redo", "reduce_partials"):
+        for k in ("chain_apply", "chain_apply_ref", "chain_stage_ref", "chain_gene_sums", "chain_cell_stats", "viterbi", "viterbi_redo", "reduce_partials"):
             ms, n = device.timing_get(k)
             if n:
                 kernels[k] = {"avg_ms": ms / n, "launches_per_step": n / args.steps, "ms_per_step": ms / args.steps}

@@ -27,8 +27,6 @@ cd $R && python scripts/pmc_summary.py gpurun_out/pmc > $O/${TAG}_pmc_traffic.tx
 find $R/gpurun_out/pmc -name "*.db" -delete; du -sh $R/gpurun_out/pmc
 python scripts/bench_host_path.py 20000 1 > $O/host_path.json 2> $O/host_path.err
 # the opt-in two-cells-per-CU chain kernels: the kept negative result
-ICNV_CHAIN2=1 timeout 300 python $R/bench.py --no-cpu-baseline > $O/bench_chain2.json 2> $O/bench_chain2.err
-if [ -f $R/infercnv_amd/libicnv_hip_prof.so ]; then ICNV_CHAIN2=1 python $R/scripts/chain2_phase_profile.py > $O/chain2_phase_profile.txt 2>&1; fi
 tail -2 $O/bench_full.json | cut -c1-600
 # SQ / LDS counters of the fast Viterbi kernel, what the launch path costs (eager vs hipGraph replay), the other slices
 timeout 900 bash $R/scripts/pmc_viterbi_fast.sh > $O/pmc_viterbi_fast_log.txt 2>&1

@@ -1186,7 +1186,9 @@ def test_chain2_opt_in_kernels_vs_oracle(dev, monkeypatch, case):
     product kernel and therefore opt-in, ICNV_CHAIN2=1) against the oracle: full chain with and without denoise on the
     bench's layout with more cells than workgroups, a layout whose chromosomes start at odd genes (pairs straddling a
     boundary, halo pairs with one element), and the cells built to take the median select's rare paths."""
-    from infercnv_amd import synth
+    from infercnv_amd import synth, _lib
+    if not hasattr(_lib.load(), "icnv_debug_chain2_plan"):
+        pytest.skip("the chain2 kernels are a variant build (make -C infercnv_amd/csrc chain2-variant; ICNV_LIB=infercnv_amd/libicnv_hip_chain2.so)")
     monkeypatch.setenv("ICNV_CHAIN2", "1")
     rng = np.random.default_rng(3)
     if case == "bench_layout":
