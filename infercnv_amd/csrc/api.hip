@@ -1197,7 +1197,13 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
     int64_t batch = scratch_budget / ((int64_t)G * 4);
     batch = std::max<int64_t>(64, (batch / 64) * 64);
     batch = std::min(batch, ((ncols + 63) / 64) * 64);
-    if ((rc = d_bp.alloc(std::max((size_t)G * (size_t)batch * 4, fast ? viterbi_fast_scratch_bytes((int32_t)G, n_chr, batch) : (size_t)0)))) return rc;
+    // (a smaller GPU, or one whose memory is held by resident matrices: halve the column batch until the scratch fits)
+    for (;;) {
+        rc = d_bp.alloc(std::max((size_t)G * (size_t)batch * 4, fast ? viterbi_fast_scratch_bytes((int32_t)G, n_chr, batch) : (size_t)0));
+        if (!rc || batch <= 64) break;
+        batch = std::max<int64_t>(64, (batch / 2 / 64) * 64);
+    }
+    if (rc) return rc;
     if (fast) {
         if ((rc = d_list.alloc((size_t)2 * n_chr * batch * sizeof(int32_t)))) return rc;
         if ((rc = d_redo.alloc(viterbi_redo_scratch_bytes(max_len)))) return rc;
@@ -1347,10 +1353,22 @@ int icnv_group_means_dev(const double *expr, int64_t G, int64_t C, const int32_t
     DevBuf d_idx, d_off, d_part;
     if ((rc = upload(d_idx, grp_idx, (size_t)grp_off[n_grp], s))) return rc;
     if ((rc = upload(d_off, grp_off, (size_t)n_grp + 1, s))) return rc;
-    const int ns = group_means_nsplit((int32_t)G, n_grp);
-    if ((rc = d_part.alloc((size_t)n_grp * ns * 3 * G * sizeof(double)))) return rc;
-    return launch_group_means_ws(expr, (int32_t)G, d_idx.as<int32_t>(), d_off.as<int32_t>(), n_grp, ns,
-                                 d_part.as<double>(), out, s);
+    // The partial-sum workspace is sized per CHUNK of groups (<= 1 GiB), not for all groups at once: with
+    // cluster_by_groups = FALSE the reference makes every observation cell its own "sample" (R/inferCNV_HMM.R:528-533), i.e.
+    // n_grp ~ C, and a workspace of n_grp * nsplit * 3 * G doubles would be three times the matrix.
+    const size_t ws_budget = (size_t)1 << 30;
+    const int ns_all = group_means_nsplit((int32_t)G, n_grp);
+    int64_t chunk = (int64_t)(ws_budget / ((size_t)ns_all * 3 * (size_t)G * sizeof(double)));
+    chunk = std::max<int64_t>(1, std::min<int64_t>(chunk, n_grp));
+    const int ns = group_means_nsplit((int32_t)G, (int32_t)chunk);
+    if ((rc = d_part.alloc((size_t)chunk * ns * 3 * G * sizeof(double)))) return rc;
+    for (int64_t q0 = 0; q0 < n_grp; q0 += chunk) {
+        const int32_t nq = (int32_t)std::min<int64_t>(chunk, n_grp - q0);
+        if ((rc = launch_group_means_ws(expr, (int32_t)G, d_idx.as<int32_t>(), d_off.as<int32_t>() + q0, nq, ns, d_part.as<double>(),
+                                        out + q0 * G, s)))
+            return rc;
+    }
+    return ICNV_OK;
 }
 
 // parallelDist(t(expr[, cells])) (Euclidean) as the reference computes it before hclust

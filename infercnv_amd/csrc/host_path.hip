@@ -84,8 +84,12 @@ uint64_t fingerprint(const double *x, int64_t n) {
     mix(w[n - 1]);
     return h;
 }
-// ---- content hash: H = fmix64( n ^ sum_i fmix64(w_i + (i + 1) * PHI) ) over the 64-bit words of the matrix.  The sum is
-// commutative, so any partition of the words (host threads, device workgroups) yields the same value.
+// ---- content hash over the 64-bit words w_i of the matrix, in blocks of eight words (one 64-byte line):
+//        b_q = sum_j (w_{8q+j} + j PHI) K_j  (mod 2^64, K_j odd),   H = fmix64( n ^ sum_q fmix64(b_q + (q + 1) PHI) ).
+// An edit of one word moves its block's b_q by delta * K_j != 0 (K_j is odd: multiplication by it is a bijection), hence the
+// block's mix, hence H; the outer sum is commutative, so any partition of the BLOCKS (host threads, device threads) yields
+// the same value.  One multiply-add per word and one fmix64 per line: round 3's hash mixed every word (two multiplies and
+// three xor-shifts each) and cost the host more time than the PCIe upload it saves on a 16-core quota.
 inline __host__ __device__ uint64_t fmix64(uint64_t k) {
     k ^= k >> 33;
     k *= 0xff51afd7ed558ccdull;
@@ -95,33 +99,83 @@ inline __host__ __device__ uint64_t fmix64(uint64_t k) {
     return k;
 }
 constexpr uint64_t HASH_PHI = 0x9E3779B97F4A7C15ull;
+#define ICNV_HASH_K0 0x9E3779B97F4A7C15ull
+#define ICNV_HASH_K1 0xBF58476D1CE4E5B9ull
+#define ICNV_HASH_K2 0x94D049BB133111EBull
+#define ICNV_HASH_K3 0xD6E8FEB86659FD93ull
+#define ICNV_HASH_K4 0xFF51AFD7ED558CCDull
+#define ICNV_HASH_K5 0xC4CEB9FE1A85EC53ull
+#define ICNV_HASH_K6 0xD1B54A32D192ED03ull
+#define ICNV_HASH_K7 0x8CB92BA72F3D8DD7ull
+inline __host__ __device__ uint64_t hash_block8(const uint64_t *w, uint64_t q) {   // a whole block: words 8q .. 8q+7
+    uint64_t b = (w[0] + 0 * HASH_PHI) * ICNV_HASH_K0;
+    b += (w[1] + 1 * HASH_PHI) * ICNV_HASH_K1;
+    b += (w[2] + 2 * HASH_PHI) * ICNV_HASH_K2;
+    b += (w[3] + 3 * HASH_PHI) * ICNV_HASH_K3;
+    b += (w[4] + 4 * HASH_PHI) * ICNV_HASH_K4;
+    b += (w[5] + 5 * HASH_PHI) * ICNV_HASH_K5;
+    b += (w[6] + 6 * HASH_PHI) * ICNV_HASH_K6;
+    b += (w[7] + 7 * HASH_PHI) * ICNV_HASH_K7;
+    return fmix64(b + (q + 1) * HASH_PHI);
+}
+inline __host__ __device__ uint64_t hash_block_tail(const uint64_t *w, int m, uint64_t q) {   // the last block's m < 8 words
+    const uint64_t K[8] = {ICNV_HASH_K0, ICNV_HASH_K1, ICNV_HASH_K2, ICNV_HASH_K3, ICNV_HASH_K4, ICNV_HASH_K5, ICNV_HASH_K6, ICNV_HASH_K7};
+    uint64_t b = 0;
+    for (int j = 0; j < m; ++j) b += (w[j] + (uint64_t)j * HASH_PHI) * K[j];
+    return fmix64(b + (q + 1) * HASH_PHI);
+}
 __global__ void __launch_bounds__(256) content_hash_kernel(const uint64_t *__restrict__ w, int64_t n, unsigned long long *out) {
     uint64_t acc = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        acc += fmix64(w[i] + (uint64_t)(i + 1) * HASH_PHI);
+    const int64_t nb = n >> 3;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nb; q += (int64_t)gridDim.x * blockDim.x) {
+        uint64_t v[8];
+        const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(w + 8 * q);   // the matrix is 16-byte aligned (pool allocation)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const ulonglong2 t = p[j]; v[2 * j] = t.x; v[2 * j + 1] = t.y; }
+        acc += hash_block8(v, (uint64_t)q);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 7)) acc += hash_block_tail(w + 8 * nb, (int)(n & 7), (uint64_t)nb);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor((unsigned long long)acc, o, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(out, (unsigned long long)acc);
 }
+// threads the host may keep busy: the hardware's, capped by the container's CPU quota (cgroup v2 cpu.max, v1 cfs quota) --
+// more runnable threads than the quota allows are throttled, not run
+static int host_hash_threads() {
+    if (const char *e = std::getenv("ICNV_HASH_THREADS")) return std::max(1, std::atoi(e));
+    int nt = (int)std::max(1u, std::thread::hardware_concurrency());
+    double quota = 0.0;
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64];
+        double per = 0.0;
+        if (std::fscanf(f, "%63s %lf", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0.0) quota = std::atof(q) / per;
+        std::fclose(f);
+    } else {
+        double q = 0.0, per = 0.0;
+        if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(g, "%lf", &q) != 1) q = 0.0; std::fclose(g); }
+        if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(g, "%lf", &per) != 1) per = 0.0; std::fclose(g); }
+        if (q > 0.0 && per > 0.0) quota = q / per;
+    }
+    if (quota >= 1.0) nt = std::min(nt, (int)(quota + 0.5));
+    return std::min(nt, 32);
+}
 uint64_t content_hash_host(const double *x, int64_t n) {
     if (n <= 0) return fmix64(0);
     const uint64_t *w = reinterpret_cast<const uint64_t *>(x);
-    int nt = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), 32);
-    if (const char *e = std::getenv("ICNV_HASH_THREADS")) nt = std::max(1, std::atoi(e));
-    nt = (int)std::min<int64_t>(nt, (n + (1 << 20) - 1) >> 20);   // at least 8 MiB per thread
+    const int64_t nb = n >> 3;
+    static const int nt_max = host_hash_threads();
+    int nt = (int)std::max<int64_t>(1, std::min<int64_t>(nt_max, (nb + (1 << 17) - 1) >> 17));   // at least 8 MiB per thread
     std::vector<uint64_t> part((size_t)nt, 0);
     auto work = [&](int t) {
-        const int64_t b = n * t / nt, e = n * (t + 1) / nt;
-        uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        int64_t i = b;
-        for (; i + 4 <= e; i += 4) {
-            a0 += fmix64(w[i] + (uint64_t)(i + 1) * HASH_PHI);
-            a1 += fmix64(w[i + 1] + (uint64_t)(i + 2) * HASH_PHI);
-            a2 += fmix64(w[i + 2] + (uint64_t)(i + 3) * HASH_PHI);
-            a3 += fmix64(w[i + 3] + (uint64_t)(i + 4) * HASH_PHI);
+        const int64_t b = nb * t / nt, e = nb * (t + 1) / nt;
+        uint64_t a0 = 0, a1 = 0;
+        int64_t q = b;
+        for (; q + 2 <= e; q += 2) {
+            a0 += hash_block8(w + 8 * q, (uint64_t)q);
+            a1 += hash_block8(w + 8 * q + 8, (uint64_t)q + 1);
         }
-        for (; i < e; ++i) a0 += fmix64(w[i] + (uint64_t)(i + 1) * HASH_PHI);
-        part[(size_t)t] = (a0 + a1) + (a2 + a3);
+        for (; q < e; ++q) a0 += hash_block8(w + 8 * q, (uint64_t)q);
+        part[(size_t)t] = a0 + a1;
     };
     std::vector<std::thread> th;
     for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
@@ -129,6 +183,7 @@ uint64_t content_hash_host(const double *x, int64_t n) {
     for (auto &t : th) t.join();
     uint64_t sum = 0;
     for (uint64_t v : part) sum += v;
+    if (n & 7) sum += hash_block_tail(w + 8 * nb, (int)(n & 7), (uint64_t)nb);
     return fmix64(sum ^ (uint64_t)n);
 }
 // the same value from the device copy (synchronous; the entry's content is complete: every host-buffer call ends with a
@@ -139,7 +194,7 @@ int content_hash_device(const double *dev, int64_t n, uint64_t *out) {
     int rc = acc.alloc(sizeof(unsigned long long));
     if (rc) return rc;
     ICNV_HIP(hipMemsetAsync(acc.p, 0, sizeof(unsigned long long), nullptr));
-    const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)num_cus() * 8);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(((n >> 3) + 255) / 256, (int64_t)num_cus() * 8));
     hipLaunchKernelGGL(content_hash_kernel, dim3(grid), dim3(256), 0, nullptr, reinterpret_cast<const uint64_t *>(dev), n,
                        acc.as<unsigned long long>());
     ICNV_HIP(hipGetLastError());
@@ -174,30 +229,43 @@ int acquire_input(const double *host, int64_t n, hipStream_t s, MatrixLease &lea
         ResidentDomain &d = res_domain();
         uint64_t h = 0;
         bool have_h = false;
+        // Candidates (same length, same strided sample) are pinned under the lock; the hashes -- a pass over the host
+        // matrix, and for a resident matrix that has none yet a device kernel whose 8-byte accumulator comes from the pool --
+        // are computed WITHOUT the lock: pool_alloc may call residency_release_idle() under memory pressure, which takes it.
+        std::vector<ResidentEntry *> cands;
         {
             std::lock_guard<std::mutex> lk(d.mu);
-            bool candidate = false;
             for (auto &e : d.entries)
-                if (e.n == n && e.fp == fp) candidate = true;
-            if (candidate) {
-                // the sample agrees with a resident matrix: identity is decided by the hash of EVERY value
-                h = content_hash_host(host, n);
-                have_h = true;
-                for (auto &e : d.entries) {
-                    if (e.n != n || e.fp != fp) continue;
-                    if (!e.hash_valid) {
-                        if (int rc = content_hash_device(e.buf.as<double>(), e.n, &e.hash)) return rc;
-                        e.hash_valid = true;
-                    }
-                    if (e.hash != h) continue;
-                    ++e.busy;
-                    e.stamp = g_res_clock++;
-                    e.host = host;
-                    lease.entry = &e;
-                    lease.dev = e.buf.as<double>();
-                    ++g_res_hits;
-                    return ICNV_OK;
+                if (e.n == n && e.fp == fp) { ++e.busy; cands.push_back(&e); }
+        }
+        if (!cands.empty()) {
+            // the sample agrees with a resident matrix: identity is decided by the hash of EVERY value
+            h = content_hash_host(host, n);
+            have_h = true;
+            int rc_hash = ICNV_OK;
+            std::vector<uint64_t> dev_hash(cands.size(), 0);
+            std::vector<char> fresh(cands.size(), 0);
+            for (size_t i = 0; i < cands.size() && !rc_hash; ++i)
+                if (!cands[i]->hash_valid) {   // (a pinned entry's buffer cannot go away; hash_valid only ever turns true)
+                    rc_hash = content_hash_device(cands[i]->buf.as<double>(), cands[i]->n, &dev_hash[i]);
+                    fresh[i] = 1;
                 }
+            std::lock_guard<std::mutex> lk(d.mu);
+            ResidentEntry *hit = nullptr;
+            for (size_t i = 0; i < cands.size(); ++i) {
+                ResidentEntry &e = *cands[i];
+                if (fresh[i] && !rc_hash) { e.hash = dev_hash[i]; e.hash_valid = true; }
+                if (!hit && !rc_hash && e.hash_valid && e.hash == h) hit = &e;   // keeps its pin: the lease's
+                else --e.busy;
+            }
+            if (rc_hash) return rc_hash;
+            if (hit) {
+                hit->stamp = g_res_clock++;
+                hit->host = host;
+                lease.entry = hit;
+                lease.dev = hit->buf.as<double>();
+                ++g_res_hits;
+                return ICNV_OK;
             }
         }
         ++g_res_misses;

@@ -127,7 +127,9 @@ __global__ void __launch_bounds__(256) ingest_apply_dense_kernel(const int32_t *
     }
 }
 // CSC: the output was zero-filled (a zero count stays 0 through every step: 0 / cs * f = 0, log2(0 + 1) = 0); the stored
-// entries of the kept genes are scattered to their new rows
+// entries of the kept genes are scattered to their new rows.  A cell whose column sum over the kept genes is 0 is the
+// exception: R computes 0 / 0 * f = NaN for every gene of it (so do the dense path and icnv_normalize_log2) -- its column
+// is filled with that very expression instead.
 __global__ void __launch_bounds__(256) ingest_apply_csc_kernel(const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx,
                                                                 const int32_t *__restrict__ vals, int64_t C, const int32_t *__restrict__ new_row,
                                                                 int G_out, const double *__restrict__ col_sums, double factor, int do_norm,
@@ -136,6 +138,10 @@ __global__ void __launch_bounds__(256) ingest_apply_csc_kernel(const int64_t *__
     for (int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); c < C; c += (int64_t)gridDim.x * 4) {
         const double cs = do_norm ? col_sums[c] : 1.0;
         double *dst = out + c * (int64_t)G_out;
+        if (do_norm && cs == 0.0) {   // wave-uniform
+            const double z = ingest_value(0, cs, factor, do_norm, do_log);
+            for (int j = lane; j < G_out; j += 64) dst[j] = z;
+        }
         for (int64_t i = colptr[c] + lane; i < colptr[c + 1]; i += 64) {
             const int32_t j = new_row[rowidx[i]];
             if (j >= 0) dst[j] = ingest_value(vals[i], cs, factor, do_norm, do_log);
@@ -334,6 +340,8 @@ int icnv_ingest_counts(const icnv_counts *cnt, int64_t G, int64_t C, double min_
         up = (int64_t)bytes;
     } else {
         if (cnt->colptr[0] != 0 || cnt->colptr[C] != cnt->nnz) ICNV_FAIL(ICNV_ERR_ARG, "icnv_counts: colptr does not span nnz");
+        for (int64_t cc = 0; cc < C; ++cc)   // (the kernels walk [colptr[c], colptr[c+1]): every entry inside [0, nnz], non-decreasing)
+            if (cnt->colptr[cc] > cnt->colptr[cc + 1] || cnt->colptr[cc] < 0) ICNV_FAIL(ICNV_ERR_ARG, "icnv_counts: colptr is not non-decreasing");
         for (int64_t i = 0; i < cnt->nnz; ++i)
             if (cnt->rowidx[i] < 0 || cnt->rowidx[i] >= G) ICNV_FAIL(ICNV_ERR_ARG, "icnv_counts: gene index out of range");
         const size_t nz = (size_t)std::max<int64_t>(cnt->nnz, 1);

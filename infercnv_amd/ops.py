@@ -244,7 +244,13 @@ def remove_genes_at_ends_of_chromosomes(infercnv_obj: InfercnvObject, window_len
     for c in seen:
         drop.append(_remove_tails(np.nonzero(chrs == c)[0], contig_tail))
     drop = np.concatenate(drop) if drop else np.zeros(0, dtype=np.int64)
-    return remove_genes(infercnv_obj, drop) if drop.size else infercnv_obj
+    if not drop.size:                                    # the reference stops here (flog.error + stop(1234), :3029-3031)
+        raise ValueError("No genes removed at chr ends.... something wrong here")
+    out = remove_genes(infercnv_obj, drop)
+    if infercnv_obj.hspike is not None:                  # "-mirroring for hspike" (:3035-3038): its own gene order, its own tails
+        hs = remove_genes_at_ends_of_chromosomes(infercnv_obj.hspike, window_length)
+        out = _with_expr(out, out.expr_data, hs)
+    return out
 
 
 def remove_outliers_norm(infercnv_obj: InfercnvObject, out_method="average_bound", lower_bound=None, upper_bound=None) -> InfercnvObject:

@@ -212,7 +212,20 @@ def test_remove_genes_at_ends_of_chromosomes(dev):
     keep = list(range(5, 25)) + list(range(32, 35)) + [37, 38] + list(range(39 + 5, 39 + 7))
     np.testing.assert_array_equal(got.expr_data, x[keep])
     assert list(got.gene_order.chr) == list(chrs[keep])
-    assert ops.remove_genes_at_ends_of_chromosomes(obj, 5) is obj   # tail 2 < 3: nothing to remove
+    with pytest.raises(ValueError, match="No genes removed"):       # tail 2 < 3: nothing to remove -> the reference stops (stop(1234), R/inferCNV_ops.R:3029-3031)
+        ops.remove_genes_at_ends_of_chromosomes(obj, 5)
+    # mirrored on the hidden spike-in (its own gene order): R/inferCNV_ops.R:3035-3038
+    hchrs = np.concatenate([["chrA"] * 20, ["chrB"] * 9])
+    hx = np.arange(29 * 2, dtype=np.float64).reshape(2, 29).T.copy()
+    hs = InfercnvObject(expr_data=hx, gene_order=GeneOrder(chr=hchrs), reference_grouped_cell_indices={"a": np.array([0])},
+                        observation_grouped_cell_indices={"b": np.array([1])})
+    obj2 = InfercnvObject(expr_data=x, gene_order=GeneOrder(chr=chrs), reference_grouped_cell_indices={"a": np.array([0])},
+                          observation_grouped_cell_indices={"b": np.array([1, 2])}, hspike=hs)
+    got2 = ops.remove_genes_at_ends_of_chromosomes(obj2, 11)
+    np.testing.assert_array_equal(got2.expr_data, x[keep])
+    hkeep = list(range(5, 15)) + list(range(20 + 3, 20 + 6))        # chrA: 5 off either end; chrB (9 < 10): floor(9 / 3) = 3 off either end
+    np.testing.assert_array_equal(got2.hspike.expr_data, hx[hkeep])
+    assert list(got2.hspike.gene_order.chr) == list(hchrs[hkeep])
 
 
 def test_average_bounds_and_auto_threshold(dev):
@@ -697,6 +710,29 @@ def test_ingest_from_integer_counts_equals_the_step_functions(dev, run_inputs, g
         with pytest.raises(Exception, match="negative value in the count matrix"):
             ops.ingest_counts(InfercnvObject(expr_data=m, gene_order=obj.gene_order, reference_grouped_cell_indices=run_inputs["refs"],
                                              observation_grouped_cell_indices=run_inputs["obs"]), 1, 3)
+    # a cell without a single count over the kept genes: R gives 0 / 0 * factor = NaN for every gene of it -- dense and CSC alike
+    empty = x.copy()
+    empty[:, 5] = 0
+    mk = lambda m: InfercnvObject(expr_data=m, gene_order=obj.gene_order, reference_grouped_cell_indices=run_inputs["refs"],
+                                  observation_grouped_cell_indices=run_inputs["obs"])
+    e_dense, _ = ops.ingest_counts(mk(empty), 1, 3, sparse=False)
+    e_csc, _ = ops.ingest_counts(mk(sp.csc_matrix(empty)), 1, 3)
+    assert np.isnan(e_dense.expr_data[:, 5]).all() and np.isnan(e_csc.expr_data[:, 5]).all()
+    np.testing.assert_array_equal(e_dense.expr_data, e_csc.expr_data)
+    # a colptr that is not non-decreasing is refused on the host (the kernels would walk out of the arrays)
+    import ctypes as ct
+    from infercnv_amd import _lib
+    m = sp.csc_matrix(x)
+    colptr = np.ascontiguousarray(m.indptr, dtype=np.int64).copy()
+    colptr[3], colptr[4] = colptr[4] + 7, colptr[3]
+    rowidx, vals = np.ascontiguousarray(m.indices, dtype=np.int32), np.ascontiguousarray(m.data, dtype=np.int32)
+    cnt = _lib.Counts(None, colptr.ctypes.data, rowidx.ctypes.data, vals.ctypes.data, int(vals.size))
+    keep_buf = np.empty(x.shape[0], dtype=np.int32)
+    n_, used_, up_ = ct.c_int64(), ct.c_double(), ct.c_int64()
+    out_buf = np.empty(x.shape, dtype=np.float64, order="F")
+    rc = _lib.load().icnv_ingest_counts(ct.byref(cnt), x.shape[0], x.shape[1], 1.0, 3, float("nan"), keep_buf.ctypes.data_as(ct.POINTER(ct.c_int32)),
+                                        ct.byref(n_), out_buf.ctypes.data_as(ct.c_void_p), ct.byref(used_), ct.byref(up_))
+    assert rc != 0 and b"colptr" in _lib.load().icnv_last_error()
     # device-resident flavour, explicit factor, no filters
     t = torch.from_numpy(np.ascontiguousarray(x.T.astype(np.int32))).cuda()
     e, keep, used = dev.ingest_counts(dev.DeviceCounts(x.shape[0], x.shape[1], dense=t), normalize_factor=1e5)

@@ -531,3 +531,81 @@ def test_sharded_ingest_two_ranks_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
         assert f"rank {r} ok" in o
+
+
+# ------------------------------------------------------------------ R glue: .Call arity against the shim's registration table
+def _r_call_sites(text):
+    """Every `.Call("name", arg, ...)` of an R source: (name, number of arguments after the name, line).  Arguments are
+    split at top-level commas (parentheses / brackets / braces and string literals respected, `#` comments dropped)."""
+    clean = []
+    for line in text.split("\n"):
+        out, q = [], None
+        for ch in line:
+            if q:
+                out.append(ch)
+                if ch == q:
+                    q = None
+            elif ch in "\"'":
+                q = ch
+                out.append(ch)
+            elif ch == "#":
+                break
+            else:
+                out.append(ch)
+        clean.append("".join(out))
+    src = "\n".join(clean)
+    sites = []
+    for m in re.finditer(r"\.Call\(", src):
+        i, depth, q, parts, cur = m.end(), 1, None, [], []
+        while i < len(src) and depth:
+            ch = src[i]
+            if q:
+                cur.append(ch)
+                if ch == q:
+                    q = None
+            elif ch in "\"'":
+                q = ch
+                cur.append(ch)
+            elif ch in "([{":
+                depth += 1
+                cur.append(ch)
+            elif ch in ")]}":
+                depth -= 1
+                if depth:
+                    cur.append(ch)
+            elif ch == "," and depth == 1:
+                parts.append("".join(cur).strip())
+                cur = []
+            else:
+                cur.append(ch)
+            i += 1
+        parts.append("".join(cur).strip())
+        assert depth == 0, "unbalanced .Call"
+        name = parts[0].strip("\"'")
+        sites.append((name, len(parts) - 1, src.count("\n", 0, m.start()) + 1))
+    return sites
+
+
+def test_r_wrappers_call_the_shim_with_the_registered_arity():
+    """rglue/R/zzz_hip_backend.R cannot be parsed by R in this image (no R): what CAN be checked statically is that every
+    `.Call("icnv_R_x", ...)` names a routine the shim registers (rglue/src/icnv_shim.c, `call_methods[]`) and passes exactly
+    as many arguments as the registration declares -- R would stop with "Incorrect number of arguments" at the first call
+    otherwise -- and that every registered routine is reached from the wrappers."""
+    rsrc = open(os.path.join(ROOT, "rglue", "R", "zzz_hip_backend.R")).read()
+    csrc = open(os.path.join(ROOT, "rglue", "src", "icnv_shim.c")).read()
+    table = csrc[csrc.index("call_methods[]"):]
+    table = table[:table.index("};")]
+    registered = {m.group(1): int(m.group(2)) for m in re.finditer(r'\{"(icnv_R_\w+)",\s*\(DL_FUNC\)&\w+,\s*(\d+)\}', table)}
+    assert len(registered) >= 10
+    # the C definitions themselves: SEXP icnv_R_x(SEXP a, SEXP b, ...) has as many parameters as it registers
+    for name, n in registered.items():
+        m = re.search(r"SEXP\s+" + name + r"\s*\(([^)]*)\)", csrc)
+        assert m, name
+        params = [p for p in m.group(1).split(",") if p.strip() and p.strip() != "void"]
+        assert len(params) == n, (name, len(params), n)
+    sites = _r_call_sites(rsrc)
+    assert sites, "no .Call in the R wrappers?"
+    for name, nargs, line in sites:
+        assert name in registered, f"zzz_hip_backend.R:{line}: .Call to unregistered routine {name}"
+        assert nargs == registered[name], f"zzz_hip_backend.R:{line}: {name} called with {nargs} arguments, registered with {registered[name]}"
+    assert {s[0] for s in sites} == set(registered), sorted(set(registered) - {s[0] for s in sites})
