@@ -45,12 +45,42 @@ STREAM_1R2W_GBS, STREAM_1R2W_SOURCE = _stream_ceiling()
 FP64_VECTOR_PEAK_TF = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 
 
+def source_stamp():
+    """16 hex digits of the sha256 over the library's sources (infercnv_amd/csrc, include/): what a counter file under
+    profiles/ is tied to.  scripts/pmc_summary.py writes it (and the commit, when it is told one) into
+    profiles/pmc_traffic.json; a bench line only quotes counter traffic collected on THIS source."""
+    import hashlib
+    h = hashlib.sha256()
+    files = []
+    for d in (os.path.join(ROOT, "infercnv_amd", "csrc"), os.path.join(ROOT, "include")):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".inc", ".h", ".cpp")) or f == "Makefile":
+                files.append(os.path.join(d, f))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _pmc_traffic():
-    """profiles/pmc_traffic.json (scripts/pmc_traffic.sh + pmc_summary.py): HBM bytes from separate rocprofv3 --pmc passes."""
+    """profiles/pmc_traffic.json (scripts/pmc_traffic.sh + pmc_summary.py): HBM bytes from separate rocprofv3 --pmc passes.
+    Returns ({} if absent) the file's content plus "_current": whether its source stamp is this tree's."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except Exception:
         return {}
+    tr["_current"] = tr.get("source_sha16") == source_stamp()
+    return tr
+
+
+def _traffic_fields(tr):
+    """traffic_source / traffic_commit / traffic_source_sha16 of a roofline object."""
+    return {"traffic_source": "profiles/pmc_traffic.json: FETCH_SIZE (x2 as MI355X_MICROARCH.md prescribes; calibrated on the chain's "
+                              "16-byte coalesced stream, uncalibrated for the Viterbi's per-lane lines) + WRITE_SIZE of separate "
+                              "rocprofv3 --pmc passes over this workload (scripts/pmc_traffic.sh), per launch; not measured in this run"
+                              + ("" if tr.get("_current") else " -- STALE: collected on other sources than this tree's, traffic set to null"),
+            "traffic_commit": tr.get("commit"), "traffic_source_sha16": tr.get("source_sha16"),
+            "traffic_is_of_this_source": bool(tr.get("_current"))}
 
 
 def effective_cores():
@@ -307,9 +337,9 @@ def run_group_config(args, world, rank):
                           "parallelism": f"whole subclusters per GPU x{world} (contiguous blocks cut at subcluster boundaries)"},
                "roofline": {"bound": "hbm", "achieved": alg / (max(ksum, 1e-9) * 1e-3) / 1e9 if kernels else None, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": (alg / (ksum * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernels and ksum > 0 else None,
-                            "traffic": (_pmc_traffic().get("config%d_bytes_per_step" % args.config) if args.cells == 50000 and G == 10000 and world == 1 else None),
-                            "traffic_source": "profiles/pmc_traffic.json: FETCH_SIZE (x2) + WRITE_SIZE of the step's kernels, separate rocprofv3 --pmc passes "
-                                              "over this workload (scripts/pmc_traffic.sh), per step; not measured in this run",
+                            "traffic": (_pmc_traffic().get("config%d_bytes_per_step" % args.config)
+                                        if args.cells == 50000 and G == 10000 and world == 1 and _pmc_traffic().get("_current") else None),
+                            **_traffic_fields(_pmc_traffic()),
                             "algorithmic_bytes_per_step": alg, "kernel_ms_per_step": ksum,
                             "note": "all kernels of the step together (group means / Viterbi / broadcast, or the interior and edge median kernels)"},
                "kernels": kernels, "cpu_baseline": None,
@@ -490,22 +520,19 @@ def main():
                                                   "frac_of_peak": moved / t / 1e9 / HBM_PEAK_GBS,
                                                   "stream_1r2w": STREAM_1R2W_GBS, "stream_1r2w_source": STREAM_1R2W_SOURCE,
                                                   "frac_of_stream_1r2w": moved / t / 1e9 / STREAM_1R2W_GBS}
-        traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(traffic_file) and G == 10000 and C_local == 50000:   # counters were collected on this shape
-            try:
-                tr = json.load(open(traffic_file))
-                for k in roof:
-                    if k in tr:
-                        roof[k]["traffic"] = tr[k]
-                        if k == "chain_apply":
-                            ht, t = roof[k]["hbm_traffic"], kernels[k]["avg_ms"] * 1e-3
-                            ht.update({"bytes_per_launch": tr[k], "source": "FETCH_SIZE (x2) + WRITE_SIZE counters, see traffic_source",
-                                       "achieved": tr[k] / t / 1e9, "frac_of_peak": tr[k] / t / 1e9 / HBM_PEAK_GBS,
-                                       "frac_of_stream_1r2w": tr[k] / t / 1e9 / STREAM_1R2W_GBS})
-                        roof[k]["traffic_source"] = ("profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE of separate rocprofv3 --pmc "
-                                                     "passes over this workload (scripts/pmc_traffic.sh), not measured in this run")
-            except Exception:
-                pass
+        tr = _pmc_traffic()
+        if tr and G == 10000 and C_local == 50000:   # counters were collected on this shape
+            for k in roof:
+                if k in tr:
+                    roof[k].update(_traffic_fields(tr))
+                    if not tr.get("_current"):
+                        continue                         # counters of other sources: the line says so and quotes no traffic
+                    roof[k]["traffic"] = tr[k]
+                    if k == "chain_apply":
+                        ht, t = roof[k]["hbm_traffic"], kernels[k]["avg_ms"] * 1e-3
+                        ht.update({"bytes_per_launch": tr[k], "source": "FETCH_SIZE (x2) + WRITE_SIZE counters, see traffic_source",
+                                   "achieved": tr[k] / t / 1e9, "frac_of_peak": tr[k] / t / 1e9 / HBM_PEAK_GBS,
+                                   "frac_of_stream_1r2w": tr[k] / t / 1e9 / STREAM_1R2W_GBS})
         res = {
             "metric": "cells/sec through smooth+i6-HMM, 10k genes", "value": value, "unit": "cells/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

@@ -55,6 +55,13 @@ for t, names in STEP_KERNELS.items():
             lines.append(f"{t}:{k}  launches/step {len(fa[k]) / 3.0:.2f}  fetch_bytes/step(x2 corrected) {fb:.4g}  write_bytes/step {wb:.4g}  total/step {fb + wb:.4g}")
     out["config%s_bytes_per_step" % t[-1]] = sum(per.values())
     out["config%s_by_kernel" % t[-1]] = per
+# what the counters belong to: the library sources' stamp (bench.py quotes the traffic only for the same stamp) and the commit
+# (ICNV_COMMIT: the GPU box has no .git -- pass `ICNV_COMMIT=$(git rev-parse --short HEAD)` in the gpurun command)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as _bench
+out["source_sha16"] = _bench.source_stamp()
+out["commit"] = os.environ.get("ICNV_COMMIT") or None
+lines.append(f"source_sha16 {out['source_sha16']}  commit {out['commit']}")
 print("\n".join(lines))
 os.makedirs("profiles", exist_ok=True)
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)

@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd database (kernel-trace --stats) as text:
    python scripts/rocprof_summary.py gpurun_out/prof/r01_results.db > profiles/r01_kernel_stats.txt"""
-import sqlite3, sys
+import os, sqlite3, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as _bench
 c = sqlite3.connect(sys.argv[1])
+# what the statistics belong to (the GPU box has no .git: pass ICNV_COMMIT=$(git rev-parse --short HEAD) in the gpurun command)
+print(f"# library sources sha16 {_bench.source_stamp()}  commit {os.environ.get('ICNV_COMMIT') or 'unknown'}")
 rows = c.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
 print(f"# rocprofv3 --kernel-trace --stats summary of {sys.argv[1]} (durations in microseconds)")
 print(f"{'calls':>6} {'total_us':>12} {'avg_us':>12} {'pct':>7}  kernel")
