@@ -43,6 +43,8 @@ def _stream_ceiling():
 
 STREAM_1R2W_GBS, STREAM_1R2W_SOURCE = _stream_ceiling()
 FP64_VECTOR_PEAK_TF = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+VITERBI_VALU_PER_GENE = 92.0   # SQ_INSTS_VALU / (genes x cells / 64), profiles/r04_pmc_viterbi_fast.txt
+COLUMN_WALK_GBS = 3660.0       # ceiling of the Viterbi's per-lane column walk, profiles/r04_ubench_column_walk.txt
 
 
 def source_stamp():
@@ -483,34 +485,42 @@ def main():
                            "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": b,
                            "avg_launch_ms": kernels[k]["avg_ms"]}
         if "chain_apply" in roof:
+            cap = STREAM_1R2W_GBS / HBM_PEAK_GBS * 16.0 / 24.0
+            roof["chain_apply"]["structural_cap_of_frac"] = cap
+            roof["chain_apply"]["frac_of_structural_cap"] = roof["chain_apply"]["frac"] / cap
             roof["chain_apply"]["note"] = (
                 f"fused smooth pass (steps 8-14 + 22) over the {n_main} non-reference cells of this rank: reads each cell once, writes "
                 "the denoised matrix and -- not counted in the algorithmic bytes -- the pre-denoise HMM input (+8 B/gene*cell, the "
-                "Viterbi's observations): 24 B of HBM traffic per gene*cell.  `frac` prices the 16 algorithmic bytes against the 8 TB/s "
-                "spec; `hbm_traffic` prices what the pass really moves, also against what a plain 1-read : 2-write stream reaches on "
-                "this GPU -- the pass is paced by the memory system (DESIGN.md section 4: ablations, phase profile)")
+                "Viterbi's observations, which infercnv::run() needs as a matrix of its own): 24 B of HBM traffic per gene*cell for "
+                "16 algorithmic.  `frac` prices the 16 algorithmic bytes against the 8 TB/s spec.  STRUCTURAL CAP: a plain "
+                f"1-read : 2-write stream reaches {STREAM_1R2W_GBS:.0f} GB/s on this GPU ({STREAM_1R2W_SOURCE}), so with two output "
+                f"matrices `frac` cannot exceed {STREAM_1R2W_GBS:.0f} / 8000 x 16 / 24 = {cap:.2f}; the north star's 0.70 is out of reach for "
+                f"the pass as specified, and this launch sits at {roof['chain_apply']['frac'] / cap:.2f} of the cap (`hbm_traffic` prices the "
+                "bytes really moved).  Round 4 (profiles/r04_cu_mask_probe.txt): confined to half the CUs the pass takes 1.73 x as long for "
+                "twice the cells per CU -- it is paced by the memory system, like the Viterbi it shares the step with")
         if "viterbi" in roof:
             st = device.viterbi_last_stats()
             roof["viterbi"]["note"] = (f"certified fast path ({st['path']}; {st['flagged']} of {st['sequences']} sequences redone exactly): "
-                                       "table-driven emission scores (degree-4 polynomials on a uniform grid) + max-plus recurrence, 89 vector + 14 LDS-gather + "
-                                       "18 other instructions per gene and wavefront in the forward pass (101 vector instructions per gene with the "
-                                       "traceback), every lane streaming its own column, four wavefronts per SIMD; hardware counters "
-                                       "(profiles/r03_pmc_viterbi_fast.txt): vector pipes busy 72 % of the launch, LDS 71 % -- the 14 random 16-byte gathers per "
-                                       "lane and gene cost 99 LDS cycles (43 % of them bank conflicts) of the 139 cycles a gene step takes on a CU: "
-                                       "the LDS and fp64 issue pace it together, no MFMA-shaped work")
+                                       "table-driven emission scores (degree-4 polynomials on a uniform grid) + max-plus recurrence, one lane per "
+                                       "sequence, 768 threads (three wavefronts per SIMD), the gene step software-pipelined (gathers | decision "
+                                       "bookkeeping | rows), 88 vector + 14 LDS-gather + 18 scalar + 1 store instructions per gene and wavefront in "
+                                       "the forward pass, block summaries for the traceback.  What paces it (round 4, DESIGN.md K4b): the observation "
+                                       "stream -- every lane walks a column of its own, one 128-byte line per visit; that pattern alone reads the 4 GB "
+                                       "in 1.09 ms at its ceiling of 3.66 TB/s (profiles/r04_ubench_column_walk.txt), and with the observations served "
+                                       "from L2 the launch takes 1.73 ms (ablation).  No MFMA-shaped work")
         if "viterbi" in roof:
-            # second ceiling of the Viterbi (SURVEY.md 8d asks for HBM GB/s *and* the fp64 rate): its forward pass issues
-            # 101 vector instructions per gene and wavefront (SQ_INSTS_VALU of the launch / gene steps; 89 of them in the forward
-            # pass by static count, scripts/vf_asm_stats.py), every one of them 4 cycles of a 16-lane SIMD; 256 CUs x 4 SIMDs at
-            # the 2.4 GHz peak clock
-            instr = 101.0
+            # second ceiling of the Viterbi (SURVEY.md 8d asks for HBM GB/s *and* the fp64 rate): vector instructions per gene and
+            # wavefront (SQ_INSTS_VALU of the launch / gene steps, profiles/r04_pmc_viterbi_fast.txt; 88 of them in the forward pass
+            # by static count, scripts/vf_asm_stats.py), every one of them 4 cycles of a 16-lane SIMD; 256 CUs x 4 SIMDs at the 2.4 GHz peak clock
+            instr = VITERBI_VALU_PER_GENE
             ceil_ms = (G * C_local / 64.0) * instr * 4.0 / (256 * 4) / 2.4e9 * 1e3
             roof["viterbi"]["fp64_issue"] = {"vector_instr_per_gene_wavefront": instr, "ceiling_ms": ceil_ms,
                                              "frac": ceil_ms / kernels["viterbi"]["avg_ms"],
                                              "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TF,
                                              "note": "share of the launch the vector pipes would need at full issue rate and the 2.4 GHz peak "
-                                                     "clock; at the ~2.05 GHz the chip holds under this load the counters show the pipes "
-                                                     "busy 72 % of the launch, next to an LDS pipe that is 71 % busy (DESIGN.md K4b)"}
+                                                     "clock (the chip holds ~2.05-2.1 GHz under this load)"}
+            roof["viterbi"]["column_walk_ceiling"] = {"gbs": COLUMN_WALK_GBS, "source": "profiles/r04_ubench_column_walk.txt (768 threads, 128-byte visits)",
+                                                      "ms_for_the_observations_alone": 8.0 * G * C_local / COLUMN_WALK_GBS / 1e6}
         dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
         if "chain_apply" in roof:
             moved = 3 * 8 * G * n_main            # one matrix read, two written (refined below by the counters when present)

@@ -18,7 +18,11 @@ for f in glob.glob(out+"/g*/**/*counter_collection.csv", recursive=True):
         if "median" in r["Kernel_Name"]:
             k=r["Kernel_Name"].replace("(anonymous namespace)::","").split("(")[0].split("::")[-1]
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+import sys
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT","."))
+import bench as _bench
 with open(out+"/summary.txt","w") as fo:
+    fo.write(f"# library sources sha16 {_bench.source_stamp()}  commit {os.environ.get('ICNV_COMMIT') or 'unknown'}\n")
     for k,d in agg.items():
         for c,v in sorted(d.items()):
             line=f"{k}  {c}  mean={sum(v)/len(v):.6g}  n={len(v)}"
