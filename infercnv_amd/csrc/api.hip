@@ -1135,7 +1135,7 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
         key.insert(key.end(), order.begin(), order.end());
         if (key != vc.layout_key || !vc.d_layout) {
             if (key.size() > vc.layout_cap) {
-                ICNV_HIP(hipStreamSynchronize(s));
+                ICNV_HIP(hipDeviceSynchronize());
                 if (vc.d_layout) (void)hipFree(vc.d_layout);
                 vc.d_layout = nullptr;
                 vc.layout_cap = 0;
@@ -1143,8 +1143,9 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
                 ICNV_HIP(hipMalloc((void **)&vc.d_layout, key.size() * sizeof(int32_t)));
                 vc.layout_cap = key.size();
             }
-            // work queued on the stream may still read the previous layout: order the upload behind it
-            ICNV_HIP(hipStreamSynchronize(s));
+            // work queued on ANY stream of this device may still read the previous layout (an asynchronous _dev call on another
+            // stream of the same thread with another chromosome layout): the layout changes rarely, wait for the device
+            ICNV_HIP(hipDeviceSynchronize());
             vc.layout_key.clear();
             ICNV_HIP(hipMemcpy(vc.d_layout, key.data(), key.size() * sizeof(int32_t), hipMemcpyHostToDevice));
             vc.layout_key = std::move(key);
