@@ -609,3 +609,41 @@ def test_r_wrappers_call_the_shim_with_the_registered_arity():
         assert name in registered, f"zzz_hip_backend.R:{line}: .Call to unregistered routine {name}"
         assert nargs == registered[name], f"zzz_hip_backend.R:{line}: {name} called with {nargs} arguments, registered with {registered[name]}"
     assert {s[0] for s in sites} == set(registered), sorted(set(registered) - {s[0] for s in sites})
+
+
+def test_r_wrappers_are_lexically_well_formed():
+    """The least a file R has never parsed must satisfy: with string literals and comments removed, every ( [ { closes in
+    the right order, and every step function of SURVEY 8b.1 is (re)bound to a `function(...)`."""
+    rsrc = open(os.path.join(ROOT, "rglue", "R", "zzz_hip_backend.R")).read()
+    stack, q, line = [], None, 1
+    pairs = {")": "(", "]": "[", "}": "{"}
+    i = 0
+    while i < len(rsrc):
+        ch = rsrc[i]
+        if ch == "\n":
+            line += 1
+        if q:
+            if ch == "\\":
+                i += 1
+            elif ch == q:
+                q = None
+        elif ch in "\"'":
+            q = ch
+        elif ch == "#":
+            while i < len(rsrc) and rsrc[i] != "\n":
+                i += 1
+            continue
+        elif ch in "([{":
+            stack.append((ch, line))
+        elif ch in ")]}":
+            assert stack and stack[-1][0] == pairs[ch], f"zzz_hip_backend.R:{line}: unmatched {ch}"
+            stack.pop()
+        i += 1
+    assert not stack and q is None, stack[-3:]
+    for fn in ("subtract_ref_expr_from_obs", "apply_max_threshold_bounds", "smooth_by_chromosome", "center_cell_expr_across_chromosome",
+               "invert_log2", "clear_noise_via_ref_mean_sd", "clear_noise", "predict_CNV_via_HMM_on_indiv_cells",
+               "predict_CNV_via_HMM_on_tumor_subclusters", "predict_CNV_via_HMM_on_tumor_subclusters_per_chr",
+               "predict_CNV_via_HMM_on_whole_tumor_samples", "i3HMM_predict_CNV_via_HMM_on_indiv_cells",
+               "i3HMM_predict_CNV_via_HMM_on_tumor_subclusters", "i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples",
+               "assign_HMM_states_to_proxy_expr_vals", "i3HMM_assign_HMM_states_to_proxy_expr_vals", "apply_median_filtering"):
+        assert re.search(r"\b" + re.escape(fn) + r"\b", rsrc), fn
