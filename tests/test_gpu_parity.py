@@ -1274,3 +1274,64 @@ def test_chain_missing_values_policy_against_the_reference_semantics(dev):
     assert np.isfinite(to_host(pre)).all() and np.isfinite(to_host(out)).all()
     want_pre = oc.smooth_chain(x, cs, refs, want_pre_denoise=True)[1]
     assert np.abs(to_host(pre)[:, clean] - want_pre[:, clean]).max() < 1e-11
+
+
+# ------------------------------------------------------------------ ragged and degenerate layouts (round 4)
+@pytest.mark.parametrize("sizes,C", [
+    ((1, 2, 15, 16, 17, 31, 33, 1, 129, 255, 3), 200),      # single-gene chromosomes (state 3, R/inferCNV_HMM.R:1104-1107), lengths around the 16-gene block
+    ((16,) * 9 + (1,), 65),                                  # every chromosome exactly one block; one column more than a wavefront
+    ((1072, 7, 708), 64),                                    # a whole wavefront of columns, chromosome starts at odd offsets
+    ((640, 641), 127),                                       # G odd: state columns differ in their alignment from lane to lane (no block summaries)
+])
+def test_viterbi_ragged_layouts_bit_exact(dev, sizes, C):
+    """The certified fast path on layouts that exercise its alignment logic -- 128-byte observation chunks, the per-gene
+    head / tail of a sequence, 16-gene block summaries of the traceback (used only when the states' 16-byte alignment is
+    wave-uniform and goes together with the observations' line alignment), partial column blocks -- against the exact
+    kernel and the oracle, i6 and i3."""
+    from infercnv_amd import synth
+    G = int(sum(sizes))
+    cs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    rng = np.random.default_rng(G + C)
+    means, sd, logPi, logDelta = synth.hmm_params_i6()
+    level = rng.choice(means, size=(len(sizes), C))                       # one CNV level per (chromosome, cell) ...
+    x = np.repeat(level, sizes, axis=0) + rng.normal(0.0, 0.08, size=(G, C))
+    x[rng.integers(0, G, 40), rng.integers(0, C, 40)] += rng.choice([-0.4, 0.4], 40)   # ... and a few excursions
+    xd = to_dev(x)
+    st, bad = dev.viterbi_cells(xd, cs, means, sd, logPi, logDelta)
+    assert dev.viterbi_last_stats()["path"] == ("fast" if C >= 64 else "exact")
+    want, _ = oc.viterbi_cells(x, cs, means, sd, logPi, logDelta)
+    np.testing.assert_array_equal(to_host(st), want)
+    for k, n in enumerate(sizes):
+        if n == 1:
+            assert (want[cs[k]] == 3).all()
+    dev.viterbi_set_mode(1)
+    st_exact, _ = dev.viterbi_cells(xd, cs, means, sd, logPi, logDelta)
+    dev.viterbi_set_mode(0)
+    assert torch.equal(st, st_exact)
+    # i3 on the same layout
+    Pi, dl = onp.get_HMM_i3(1e-6)
+    m3 = np.array([0.8, 1.0, 1.2])
+    st3, _ = dev.viterbi_cells(xd, cs, m3, 0.1, np.log(Pi), np.log(dl))
+    want3, _ = oc.viterbi_cells(x, cs, m3, 0.1, np.log(Pi), np.log(dl))
+    np.testing.assert_array_equal(to_host(st3), want3)
+
+
+@pytest.mark.parametrize("G", [3000, 4096])     # 3000: the columns' alignment alternates from lane to lane; 4096: wave-uniform
+def test_viterbi_unaligned_matrix_views_bit_exact(dev, G):
+    """The fast path on matrices that do not start on a cache line (a view into a larger allocation: observations 8 or 24
+    bytes off a line, states 1 or 3 bytes off a 16-byte word): the chunk loop's alignment assumptions are wave-uniform
+    decisions, not preconditions."""
+    from infercnv_amd import synth
+    pre, cs = _hmm_input(G, 130, seed=5)
+    means, sd, logPi, logDelta = synth.hmm_params_i6()
+    want, _ = oc.viterbi_cells(pre, cs, means, sd, logPi, logDelta)
+    C = pre.shape[1]
+    for off_x, off_s in ((1, 1), (3, 3), (0, 5), (2, 0)):
+        bufx = torch.zeros(C * G + 8, dtype=torch.float64, device="cuda")
+        xv = bufx[off_x:off_x + C * G].view(C, G)
+        xv.copy_(to_dev(pre))
+        bufs = torch.zeros(C * G + 16, dtype=torch.uint8, device="cuda")
+        sv = bufs[off_s:off_s + C * G].view(C, G)
+        st, bad = dev.viterbi_cells(xv, cs, means, sd, logPi, logDelta, states=sv)
+        np.testing.assert_array_equal(to_host(st), want)
+        assert int(bufs[:off_s].sum()) == 0 and int(bufs[off_s + C * G:].sum()) == 0     # nothing written outside the view
