@@ -1185,8 +1185,9 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
                                    d_all.as<int32_t>() + 2 * (size_t)count, d_all.as<int32_t>(), 0x7fffffff, d_scr.as<uint32_t>(),
                                    n_underflow_dev, max_len, "viterbi", s);
     }
-    // the scratch holds the exact kernel's 4-byte back-pointer words; the fast kernel's 2-byte words use its first half
-    // (the exact kernel only runs after the fast kernel of the same batch has finished with them)
+    // the scratch holds the exact kernel's 4-byte back-pointer words; the fast kernel's 2-byte words and its 16-gene block
+    // summaries (viterbi_fast_scratch_bytes: G + G / 16 + 3 n_chr + 1 rows of 2 bytes per column) use its first half -- the
+    // larger of the two sizes is allocated (the exact kernel only runs after the fast kernel of the same batch has finished)
     // back-pointer scratch per column batch: 16 GiB = 429 000 cells at 10 000 genes in ONE launch (a second, small launch
     // balances its (chromosome, 64 columns) tasks badly over the 4 096 wavefronts: 125 000 cells as 107 000 + 18 000 took
     // 5.9 ms where one launch takes 5.3); HBM is 288 GB
