@@ -527,7 +527,12 @@ int icnv_chain_round_partial_dev(icnv_chain_t *ch, int round, const double *expr
             a.mask &= ~ch->cache_mask;
         }
         if (nref > 0) {
-            if ((rc = launch_chain(a, MODE_CELL_STATS, s))) return rc;
+            // from the cache only the elementwise steps 12 / 14 are left: one streaming pass instead of the chain geometry
+            const bool elementwise = a.in_by_pos && cache_cell_stats_covers((int32_t)G) &&
+                                     (a.mask & ~(uint32_t)(ICNV_ST_SUBTRACT_REF_2 | ICNV_ST_INVERT_LOG2 | ICNV_ST_CENTER_MEAN)) == 0;
+            if (elementwise) rc = launch_cache_cell_stats(a.in, (int32_t)G, nref, a.mask, a.b2, a.cell_stats, s);
+            else rc = launch_chain(a, MODE_CELL_STATS, s);
+            if (rc) return rc;
         }
         if ((rc = launch_reduce_cell_stats(ch->d_cellstats.as<double>(), nref, (int32_t)G, ch->d_stats.as<double>(), s)))
             return rc;

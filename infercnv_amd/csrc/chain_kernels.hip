@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "icnv_internal.h"
+#include "icnv_exp2_coef.h"
 #include <algorithm>
 #include <cmath>
 #include <map>
@@ -175,6 +176,114 @@ __global__ void reduce_cell_stats_kernel(const double *cs, int n_cells, int G, d
         out4[1] = td;
         out4[2] = (double)n_cells;
         out4[3] = (double)n_cells * (double)G;
+    }
+}
+
+// Round C of the reference rounds when the reference cells continue from their cache (steps 8-11 done): steps 12 and 14
+// are elementwise, so the per-cell (sum, sd) of R/inferCNV_ops.R:2302-2318 come from one streaming pass over the cache
+// instead of a launch of the chain geometry (LDS-resident cell, one 1 024-thread workgroup per CU, the pipeline's barriers):
+// 0.143 -> 0.121 ms for 5 000 cells.  A 512-thread workgroup per cell, two resident per CU (125 registers, no scratch): a
+// cell's values stay in registers between the two passes of R's sd(), the bound vectors come from L2 two slots at a time.
+// Getting here took three attempts (docs/KERNEL_LOG.md, round 4): 256 threads with everything of a cell in flight at once
+// needed 452 registers -- one wavefront per SIMD, 0.505 ms; 1 024 threads per cell, one workgroup per CU, exposed every
+// load latency -- 0.174 ms; the chain geometry it replaces is a software pipeline and was faster than both.  Arithmetic per
+// value as in the chain kernel (x - clamp(x, lo, hi); 2^x by the same degree-11 polynomial inside its range); sums in a fixed
+// order (thread-strided partials, wavefront butterflies, the wavefront sums in wavefront order).
+__device__ inline double exp2_lean_cs(double x) {   // chain_kernel.inc: exp2_lean
+    const double n = __builtin_rint(x);
+    const double f = x - n;
+    double p = ICNV_EXP2_C11;
+    p = __builtin_fma(p, f, ICNV_EXP2_C10);
+    p = __builtin_fma(p, f, ICNV_EXP2_C9);
+    p = __builtin_fma(p, f, ICNV_EXP2_C8);
+    p = __builtin_fma(p, f, ICNV_EXP2_C7);
+    p = __builtin_fma(p, f, ICNV_EXP2_C6);
+    p = __builtin_fma(p, f, ICNV_EXP2_C5);
+    p = __builtin_fma(p, f, ICNV_EXP2_C4);
+    p = __builtin_fma(p, f, ICNV_EXP2_C3);
+    p = __builtin_fma(p, f, ICNV_EXP2_C2);
+    p = __builtin_fma(p, f, ICNV_EXP2_C1);
+    p = __builtin_fma(p, f, 1.0);
+    return __builtin_ldexp(p, (int)n);
+}
+constexpr int CS_NT = 512, CS_NS = 10, CS_GRP = 2;   // 256 threads x 20 gene pairs = up to 10 240 (even) genes per cell
+__global__ void __launch_bounds__(CS_NT) __attribute__((amdgpu_waves_per_eu(4, 8))) cache_cell_stats_kernel(const double *__restrict__ cache, int G, int n_cells, uint32_t mask,
+                                                                  const double *__restrict__ b2, double *__restrict__ cell_stats) {
+    __shared__ double red[CS_NT / 64];
+    const int t = threadIdx.x;
+    auto block_sum = [&](double v) -> double {
+        v = wave_sum(v);
+        if ((t & 63) == 0) red[t >> 6] = v;
+        __syncthreads();
+        double r = red[0];
+#pragma unroll
+        for (int w = 1; w < CS_NT / 64; ++w) r += red[w];
+        __syncthreads();
+        return r;
+    };
+    const bool sub = (mask & ICNV_ST_SUBTRACT_REF_2) != 0, inv = (mask & ICNV_ST_INVERT_LOG2) != 0;
+    const int np = G >> 1;
+    const double2 *lo2 = reinterpret_cast<const double2 *>(b2), *hi2 = reinterpret_cast<const double2 *>(b2 + G);
+    for (int c = blockIdx.x; c < n_cells; c += gridDim.x) {
+        const double2 *col = reinterpret_cast<const double2 *>(cache + (int64_t)c * G);
+        double2 v[CS_NS];
+#pragma unroll
+        for (int k = 0; k < CS_NS; ++k) {
+            const int q = t + k * CS_NT;
+            v[k] = (q < np) ? col[q] : make_double2(0.0, 0.0);
+        }
+        double s = 0.0;
+#pragma unroll
+        for (int g0 = 0; g0 < CS_NS; g0 += CS_GRP) {   // the bound vectors (L2) a group of slots at a time: registers
+            double2 lo[CS_GRP], hi[CS_GRP];
+#pragma unroll
+            for (int k = 0; k < CS_GRP; ++k) {
+                const int q = t + (g0 + k) * CS_NT;
+                lo[k] = make_double2(0.0, 0.0);
+                hi[k] = lo[k];
+                if (sub && q < np) { lo[k] = lo2[q]; hi[k] = hi2[q]; }
+            }
+#pragma unroll
+            for (int k = 0; k < CS_GRP; ++k) {
+                const int q = t + (g0 + k) * CS_NT;
+                double x0 = v[g0 + k].x, x1 = v[g0 + k].y;
+                if (sub) {   // .subtract_expr, R/inferCNV_ops.R:1764-1768 (lo <= hi)
+                    x0 = x0 - fmin(fmax(x0, lo[k].x), hi[k].x);
+                    x1 = x1 - fmin(fmax(x1, lo[k].y), hi[k].y);
+                }
+                if (inv) {   // R/inferCNV_ops.R:2818
+                    const bool wide = !(__builtin_fabs(x0) < 1022.0) || !(__builtin_fabs(x1) < 1022.0);
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(wide) != 0, 0)) {
+                        asm volatile("; exp2 outside the lean range" ::: "memory");
+                        x0 = exp2(x0);
+                        x1 = exp2(x1);
+                    } else {
+                        x0 = exp2_lean_cs(x0);
+                        x1 = exp2_lean_cs(x1);
+                    }
+                }
+                if (q < np) { s += x0; s += x1; }
+                v[g0 + k] = make_double2(x0, x1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const double tot = block_sum(s);
+        const double mean = tot / (double)G;
+        double ss = 0.0;
+#pragma unroll
+        for (int k = 0; k < CS_NS; ++k) {
+            const int q = t + k * CS_NT;
+            if (q < np) {
+                const double d0 = v[k].x - mean, d1 = v[k].y - mean;
+                ss += d0 * d0;
+                ss += d1 * d1;
+            }
+        }
+        const double sst = block_sum(ss);
+        if (t == 0) {
+            cell_stats[2 * (int64_t)c] = tot;
+            cell_stats[2 * (int64_t)c + 1] = sqrt(sst / (double)(G - 1));   // sample sd, two passes like R's sd()
+        }
     }
 }
 
@@ -424,6 +533,17 @@ int launch_reduce_cell_stats(const double *cell_stats, int32_t n_cells, int32_t 
                              hipStream_t stream) {
     KernelTimer kt("reduce_cell_stats", stream);
     hipLaunchKernelGGL(reduce_cell_stats_kernel, dim3(1), dim3(256), 0, stream, cell_stats, n_cells, G, out4);
+    ICNV_HIP(hipGetLastError());
+    return ICNV_OK;
+}
+
+bool cache_cell_stats_covers(int32_t G) { return (G & 1) == 0 && G <= CS_NT * CS_NS * 2; }
+int launch_cache_cell_stats(const double *cache, int32_t G, int32_t n_cells, uint32_t mask, const double *b2, double *cell_stats,
+                            hipStream_t stream) {
+    if (n_cells <= 0) return ICNV_OK;
+    KernelTimer kt("chain_cell_stats", stream);
+    hipLaunchKernelGGL(cache_cell_stats_kernel, dim3((unsigned)std::min(n_cells, num_cus() * 16)), dim3(CS_NT), 0, stream, cache, (int)G,
+                       (int)n_cells, mask, b2, cell_stats);
     ICNV_HIP(hipGetLastError());
     return ICNV_OK;
 }

@@ -156,6 +156,9 @@ int launch_group_gene_sums(const double *x, int32_t G, const int32_t *cells_dev,
                            double *partial, int32_t partial_rows, double *sums_counts, hipStream_t stream);
 int launch_bounds_from_sums(const double *sums_counts, int32_t G, int32_t n_grp, int32_t use_bounds, int32_t inv_log,
                             double *bounds, hipStream_t stream);
+bool cache_cell_stats_covers(int32_t G);   // even G <= 10 240: the cell fits the streaming kernel's registers
+int launch_cache_cell_stats(const double *cache, int32_t G, int32_t n_cells, uint32_t mask /* steps 12 / 14 still to run */, const double *b2,
+                            double *cell_stats, hipStream_t stream);
 int launch_reduce_cell_stats(const double *cell_stats, int32_t n_cells, int32_t G, double *out4,
                              hipStream_t stream);
 int launch_denoise_from_stats(const double *stats4, double sd_amplifier, double noise_filter,
