@@ -430,15 +430,37 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # Inside the timed region only the two hot launches carry HIP events (level 2): an event pair costs a few microseconds of
+    # stream time, and with all ~14 launches of a step bracketed the step is 2.5 % slower (5.27 against 5.13 ms, measured).
+    # The other kernel families are timed in a short DETAIL pass right behind the timed region (level 1, same state).
     if not args.no_kernel_timing:
         device.timing_reset()
-        device.timing_enable(True)
+        device.timing_enable(2)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
     device.timing_enable(False)
+    hot = {}
+    if not args.no_kernel_timing:
+        for k in ("chain_apply", "viterbi"):
+            ms, n = device.timing_get(k)
+            if n:
+                hot[k] = {"avg_ms": ms / n, "launches_per_step": n / args.steps, "ms_per_step": ms / args.steps,
+                          "measured": "HIP events on the launch stream inside the timed region"}
+    detail_steps, detail_ms = 0, None
+    if not args.no_kernel_timing:
+        detail_steps = max(1, min(5, args.steps))
+        device.timing_reset()
+        device.timing_enable(1)
+        fence()
+        td = time.perf_counter()
+        for _ in range(detail_steps):
+            step()
+        fence()
+        detail_ms = (time.perf_counter() - td) / detail_steps * 1e3
+        device.timing_enable(False)
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if dist_on:
@@ -465,9 +487,12 @@ def main():
         value = C_total * args.steps / elapsed
         kernels = {}
         for k in ("chain_apply", "chain_apply_ref", "chain_stage_ref", "chain_gene_sums", "chain_cell_stats", "viterbi", "viterbi_redo", "reduce_partials"):
-            ms, n = device.timing_get(k)
+            ms, n = device.timing_get(k)      # the detail pass (every family bracketed by events)
             if n:
-                kernels[k] = {"avg_ms": ms / n, "launches_per_step": n / args.steps, "ms_per_step": ms / args.steps}
+                kernels[k] = {"avg_ms": ms / n, "launches_per_step": n / detail_steps, "ms_per_step": ms / detail_steps,
+                              "measured": f"HIP events, detail pass of {detail_steps} steps right behind the timed region"}
+        detail = {k: dict(v) for k, v in kernels.items()}
+        kernels.update(hot)                   # the two hot launches: from the timed region itself
         # algorithmic bytes per launch: chain apply reads 8 B and writes 8 B per gene*cell
         # (+8 B for the HMM-input copy it also emits here); Viterbi reads 8 B and writes 1 B per gene*cell.
         # With the reference-cell cache the dominant chain_apply launch covers the non-reference cells only;
@@ -561,8 +586,12 @@ def main():
             "roofline_step": {"bound": "hbm", "algorithmic_bytes_per_step": (16 + 9) * G * C_local,
                               "achieved": (16 + 9) * G * C_local / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": (16 + 9) * G * C_local / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "ms_outside_kernels": ms_per_step - sum(v["ms_per_step"] for v in kernels.values()) if kernels else None},
+                              "ms_outside_kernels": (detail_ms - sum(v["ms_per_step"] for v in detail.values())) if detail else None,
+                              "ms_outside_kernels_note": "of the detail pass: its own step time minus its own kernel times"},
             "kernels": kernels,
+            "kernel_timing": {"timed_region": "events on chain_apply and viterbi only (icnv_timing_enable(2))",
+                              "detail_pass": {"steps": detail_steps, "ms_per_step": detail_ms,
+                                              "hot_kernels_there": {k: detail[k]["avg_ms"] for k in ("chain_apply", "viterbi") if k in detail}}},
         }
         if checksums is not None:
             res["checksums"] = {"per_part": checksums, "meaning": "[sum(denoised), sum(hmm_input), sum(states)] of the cells of rank r"}

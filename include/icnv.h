@@ -392,7 +392,9 @@ int icnv_median_filter_dev(const double *expr_in, double *expr_out, int64_t G, i
  * launch stream; icnv_timing_get() synchronises those events and returns the
  * accumulated milliseconds and launch count of one kernel family:
  * "chain_apply", "chain_gene_sums", "chain_cell_stats", "viterbi",
- * "group_means", "broadcast_states", "median_filter", ... */
+ * "group_means", "broadcast_states", "median_filter", ...
+ * on = 1: every kernel family; on = 2: only "chain_apply" and "viterbi" (an event pair costs a few microseconds of
+ * stream time: fourteen pairs per bench step are 2.5 % of it, two pairs are not); on = 0: off. */
 void icnv_timing_enable(int on);
 void icnv_timing_reset(void);
 int icnv_timing_get(const char *kernel, double *total_ms, int64_t *launches);

@@ -140,17 +140,26 @@ void pool_free(void *p) {
 
 // ------------------------------------------------------------------ kernel timing
 namespace {
-bool g_timing = false;
+int g_timing = 0;   // 0 off, 1 every kernel family, 2 only the two hot launches of the bench step (chain_apply, viterbi)
 struct TimedRec { std::string name; hipEvent_t e0, e1; };
 std::vector<TimedRec> g_pending;
+std::vector<hipEvent_t> g_event_pool;   // recycled events: creating two per launch costs host time inside a timed region
 std::map<std::string, std::pair<double, int64_t>> g_times;
 std::mutex g_time_mu;
+bool hot_kernel(const char *n) { return std::strcmp(n, "chain_apply") == 0 || std::strcmp(n, "viterbi") == 0; }
+bool pooled_event(hipEvent_t *e) {
+    {
+        std::lock_guard<std::mutex> lk(g_time_mu);
+        if (!g_event_pool.empty()) { *e = g_event_pool.back(); g_event_pool.pop_back(); return true; }
+    }
+    return hipEventCreate(e) == hipSuccess;
+}
 }  // namespace
 
 KernelTimer::KernelTimer(const char *n, hipStream_t s) : name(n), stream(s) {
-    on = g_timing;
+    on = g_timing == 1 || (g_timing == 2 && hot_kernel(n));
     if (on) {
-        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { on = false; return; }
+        if (!pooled_event(&e0) || !pooled_event(&e1)) { on = false; return; }
         (void)hipEventRecord(e0, stream);
     }
 }
@@ -172,8 +181,8 @@ static void drain_timers() {
             acc.first += ms;
             acc.second += 1;
         }
-        (void)hipEventDestroy(r.e0);
-        (void)hipEventDestroy(r.e1);
+        g_event_pool.push_back(r.e0);
+        g_event_pool.push_back(r.e1);
     }
     g_pending.clear();
 }
@@ -272,7 +281,7 @@ void icnv_shutdown(void) {
     g_free.clear();
 }
 
-void icnv_timing_enable(int on) { g_timing = on != 0; }
+void icnv_timing_enable(int on) { g_timing = on == 2 ? 2 : (on != 0 ? 1 : 0); }
 void icnv_timing_reset(void) {
     drain_timers();
     std::lock_guard<std::mutex> lk(g_time_mu);

@@ -390,7 +390,8 @@ def median_filter(x, chr_start, tiles, window_size=7, out=None):
 
 # ------------------------------------------------------------------ timing hooks
 def timing_enable(on=True):
-    _lib.load().icnv_timing_enable(int(bool(on)))
+    """on: False / 0 off, True / 1 every kernel family, 2 only the hot launches "chain_apply" and "viterbi"."""
+    _lib.load().icnv_timing_enable(2 if on == 2 and on is not True else int(bool(on)))
 
 
 def timing_reset():
