@@ -528,14 +528,14 @@ def main():
             roof["viterbi"]["note"] = (f"certified fast path ({st['path']}; {st['flagged']} of {st['sequences']} sequences redone exactly): "
                                        "table-driven emission scores (degree-4 polynomials on a uniform grid) + max-plus recurrence, one lane per "
                                        "sequence, 768 threads (three wavefronts per SIMD), the gene step software-pipelined (gathers | decision "
-                                       "bookkeeping | rows), 88 vector + 14 LDS-gather + 18 scalar + 1 store instructions per gene and wavefront in "
+                                       "bookkeeping | rows), 86 vector + 14 LDS-gather + 18 scalar + 1 store instructions per gene and wavefront in "
                                        "the forward pass, block summaries for the traceback.  What paces it (round 4, DESIGN.md K4b): the observation "
                                        "stream -- every lane walks a column of its own, one 128-byte line per visit; that pattern alone reads the 4 GB "
                                        "in 1.09 ms at its ceiling of 3.66 TB/s (profiles/r04_ubench_column_walk.txt), and with the observations served "
                                        "from L2 the launch takes 1.73 ms (ablation).  No MFMA-shaped work")
         if "viterbi" in roof:
             # second ceiling of the Viterbi (SURVEY.md 8d asks for HBM GB/s *and* the fp64 rate): vector instructions per gene and
-            # wavefront (SQ_INSTS_VALU of the launch / gene steps, profiles/r04_pmc_viterbi_fast.txt; 88 of them in the forward pass
+            # wavefront (SQ_INSTS_VALU of the launch / gene steps, profiles/r04_pmc_viterbi_fast.txt; 86 of them in the forward pass
             # by static count, scripts/vf_asm_stats.py), every one of them 4 cycles of a 16-lane SIMD; 256 CUs x 4 SIMDs at the 2.4 GHz peak clock
             instr = VITERBI_VALU_PER_GENE
             ceil_ms = (G * C_local / 64.0) * instr * 4.0 / (256 * 4) / 2.4e9 * 1e3

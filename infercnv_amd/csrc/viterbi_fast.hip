@@ -32,6 +32,7 @@
 // every wavefront pulls (chromosome, 64-column block) tasks, longest chromosomes first, one lane per
 // sequence as in the exact kernel.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 #include "icnv_internal.h"
@@ -218,7 +219,6 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         // Scores of one observation from the table, in two stages so that the LDS round trips of several genes
         // overlap: locate() finds the interval (lookup cell -> segment record -> interval index) and the position
         // inside it; poly() evaluates the K polynomials.
-        constexpr int REC = rec_doubles(K);
         auto locate = [&](double xv, int &idx, double &tn) {
             // clamp into the table's domain; an observation the clamp changes (NaN included) flags its sequence
             const double xs = max_raw_s(min_raw_s(xv, x_hi_s), x_lo_s);
@@ -227,10 +227,10 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             // interval with a mean has two records, below the mean and from the mean on (x_hi is chosen so that j needs no clamp)
             const double u = (xs - x_lo_s) * inv_w_s;
             const int j = (int)u;
-            const double2 ge = *reinterpret_cast<const double2 *>(gridp + 2 * j);   // boundary, {rec, pad}
-            const int r = (int)(uint32_t)__double_as_longlong(ge.y) + ((xs >= ge.x) ? 1 : 0);
-            tn = (u - (double)j) - 0.5;
-            idx = (int)__umul24((uint32_t)r, (uint32_t)REC);   // record numbers are far below 2^24
+            const double2 ge = *reinterpret_cast<const double2 *>(gridp + 2 * j);   // boundary, {index of the record below it, of the record from it on}
+            const unsigned long long rr = (unsigned long long)__double_as_longlong(ge.y);
+            idx = (xs >= ge.x) ? (int)(uint32_t)(rr >> 32) : (int)(uint32_t)rr;
+            tn = __builtin_amdgcn_fract(u) - 0.5;   // u >= 0: u - floor(u) = u - (double)(int)u, exactly
         };
         // Coefficients [f0, f1) of the record at cq (flat index f = (state - 1) * NCF + j, c0 first) as 16-byte pairs: for
         // NCF = 6 a state is three pairs of its own; an odd NCF makes pairs straddle two states (all indices are static)
@@ -308,9 +308,9 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             nu[0] = max_raw(nu[0], c);
             __builtin_amdgcn_sched_barrier(0);
             {
-                const int r = (int)(uint32_t)__double_as_longlong(ge_n.y) + ((xs_n >= ge_n.x) ? 1 : 0);
-                tn_c = (u_n - (double)j_n) - 0.5;
-                idx_c = (int)__umul24((uint32_t)r, (uint32_t)REC);
+                const unsigned long long rr = (unsigned long long)__double_as_longlong(ge_n.y);
+                idx_c = (xs_n >= ge_n.x) ? (int)(uint32_t)(rr >> 32) : (int)(uint32_t)rr;
+                tn_c = __builtin_amdgcn_fract(u_n) - 0.5;   // u >= 0: u - floor(u) = u - (double)(int)u, exactly
             }
 #pragma unroll
             for (int k = 1; k <= KA; ++k) nu[k] = max_raw(nu[k], c) + horner(qa, 0, (k - 1) * NCF, tn);
@@ -345,6 +345,7 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
                     word |= unsure ? (512u << k) : 0u;
                 }
             }
+            // (one address per chunk + immediate offsets for its sixteen rows measured SLOWER: 2.03 against 1.96 ms)
             bpc[i * 64] = (uint16_t)word;
             sacc |= word;
             __builtin_amdgcn_sched_barrier(0);
@@ -481,8 +482,13 @@ void viterbi_fast_table_image(const EmisTable &t, std::vector<double> &img) {
                 img[(size_t)i * rec + (k - 1) * NCF + j] = t.coef[((size_t)i * t.K + k) * NCF + j];
     const size_t g0 = (size_t)t.n_int * rec;
     for (int j = 0; j < t.n_grid; ++j) {
+        // {boundary, index (in doubles) of the record below the boundary, index of the record from the boundary on}: the kernel
+        // selects one of the two words -- no add and multiply per gene.  Without a mean in the interval (boundary = +inf)
+        // both are the interval's one record.
         img[g0 + 2 * (size_t)j] = t.grid[(size_t)j].boundary;
-        int32_t rp[2] = {t.grid[(size_t)j].rec, 0};
+        const int32_t lo = t.grid[(size_t)j].rec;
+        const int32_t hi = std::isinf(t.grid[(size_t)j].boundary) ? lo : lo + 1;
+        int32_t rp[2] = {lo * rec, hi * rec};
         std::memcpy(&img[g0 + 2 * (size_t)j + 1], rp, sizeof(rp));
     }
     if (img.size() & 1) img.push_back(0.0);   // the kernel copies 16 bytes at a time
