@@ -43,7 +43,7 @@ def _stream_ceiling():
 
 STREAM_1R2W_GBS, STREAM_1R2W_SOURCE = _stream_ceiling()
 FP64_VECTOR_PEAK_TF = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
-VITERBI_VALU_PER_GENE = 95.7   # SQ_INSTS_VALU / (genes x cells / 64), profiles/r04_pmc_viterbi_fast.txt
+VITERBI_VALU_PER_GENE = 93.7   # SQ_INSTS_VALU / (genes x cells / 64), profiles/r04_pmc_viterbi_fast.txt
 COLUMN_WALK_GBS = 3660.0       # ceiling of the Viterbi's per-lane column walk, profiles/r04_ubench_column_walk.txt
 
 
