@@ -463,3 +463,23 @@ def test_ks_test_and_honeybadger_delta_restatements():
         want = onp.honeybadger_set_gexp_dev(0.24, 0.05, k, seed, n_iter=n_iter)
         assert abs(got - want) < 1e-13, (k, got, want)
     assert hmm.get_HoneyBADGER_setGexpDev(0.24, 0.05, k_cells=1, n_iter=5, seed=3) == hmm.get_HoneyBADGER_setGexpDev(0.24, 0.05, k_cells=2, n_iter=5, seed=3)
+
+
+def test_median_filter_against_scipy_on_interior_outputs():
+    """An implementation from outside this repository as a third opinion: for outputs at least window_size // 2 + 1
+    genes and cells from every tile / chromosome edge the reference's window (R/noise_reduction.R:101-106: half_window + 1
+    either side, i.e. (window_size + 2)^2 values) is complete, and scipy.ndimage.median_filter with that footprint must
+    return the same order statistic as both oracles.  (The clamped windows of the border outputs have no scipy counterpart:
+    its boundary modes pad, the reference truncates.)"""
+    ndi = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(77)
+    for w, (nx, ny) in ((7, (61, 40)), (3, (23, 19)), (5, (30, 31))):
+        h = (w - 1) // 2 + 1
+        tile = rng.normal(1.0, 0.2, size=(nx, ny))
+        tile[rng.integers(0, nx, 30), rng.integers(0, ny, 30)] = 1.0          # ties
+        want = ndi.median_filter(tile, size=(2 * h + 1, 2 * h + 1), mode="constant", cval=0.0)
+        got_np = onp.median_filter(tile, w)
+        got_c = oc.median_filter(tile, np.array([0, nx], dtype=np.int32), [np.arange(ny, dtype=np.int32)], w)
+        inner = (slice(h + 1, nx - h - 1), slice(h + 1, ny - h - 1))
+        np.testing.assert_array_equal(got_np[inner], want[inner])
+        np.testing.assert_array_equal(got_c[inner], want[inner])
