@@ -483,3 +483,46 @@ def test_median_filter_against_scipy_on_interior_outputs():
         inner = (slice(h + 1, nx - h - 1), slice(h + 1, ny - h - 1))
         np.testing.assert_array_equal(got_np[inner], want[inner])
         np.testing.assert_array_equal(got_c[inner], want[inner])
+
+
+def test_viterbi_oracles_against_exhaustive_path_search():
+    """An algorithm-independent opinion on the DP: for short sequences EVERY state path is scored directly --
+    log delta[y_1] + sum_i log Pi[y_{i-1}, y_i] + sum_i s_{i, y_i} with the emission scores of
+    `Viterbi.dthmm.adj` (R/inferCNV_HMM.R:1129-1133, 1156-1160) -- and the best path must be the one both oracles trace
+    back (i3 and i6 transition structures, the reference's non-normalised i3 rows included).  Sequences with a runner-up
+    within 1e-9 of the winner are left out: there the DP's rounding order, not the model, decides."""
+    import itertools
+    rng = np.random.default_rng(314)
+    checked = 0
+    for K, n in ((3, 7), (3, 2), (6, 5), (6, 3)):
+        if K == 6:
+            Pi = np.full((6, 6), 1e-6); np.fill_diagonal(Pi, 1 - 5e-6)
+            delta = np.array([1e-6, 1e-6, 1 - 5e-6, 1e-6, 1e-6, 1e-6])
+            means, sd = np.asarray(I6_MEANS), 0.17756
+        else:
+            Pi, delta = onp.get_HMM_i3(1e-2)          # a transition probability at which paths really compete
+            means, sd = np.array([0.8, 1.0, 1.2]), 0.1
+        with np.errstate(divide="ignore"):
+            lPi, ld = np.log(Pi), np.log(delta)
+        S = 40
+        x = rng.choice(means, size=(n, S)) + rng.normal(0.0, 1.5 * sd, size=(n, S))
+        got_np, _ = onp.viterbi_core(x, means, sd, lPi, ld)
+        got_c, _ = oc.viterbi_cells(x, np.array([0, n], dtype=np.int32), means, sd, lPi, ld)
+        for s in range(S):
+            sc = np.stack([onp.emission_scores(x[i, s:s + 1], means, sd)[0] for i in range(n)])      # (n, K)
+            best, second, arg = -np.inf, -np.inf, None
+            for path in itertools.product(range(K), repeat=n):
+                v = ld[path[0]] + sc[0, path[0]]
+                for i in range(1, n):
+                    v += lPi[path[i - 1], path[i]] + sc[i, path[i]]
+                if v > best:
+                    best, second, arg = v, best, path
+                elif v > second:
+                    second = v
+            if best - second < 1e-9:
+                continue
+            want = np.asarray(arg) + 1
+            np.testing.assert_array_equal(np.asarray(got_np[:, s]), want)
+            np.testing.assert_array_equal(got_c[:, s], want)
+            checked += 1
+    assert checked > 120
