@@ -2,7 +2,8 @@
 // product kernel's 2.3 ms (docs/KERNEL_LOG.md, profiles/r03_chain2_*) -- and are not part of libicnv_hip.so.  The product
 // library links these two stubs; `make -C infercnv_amd/csrc chain2-variant` builds ../libicnv_hip_chain2.so with the real
 // translation unit in their place (load it with ICNV_LIB=..., switch the kernels on with ICNV_CHAIN2=1: the chain2 tests
-// do, and skip when the loaded library is the product).
+// do: `build()` builds the variant, the CPU plan tests load it directly, the GPU tests run themselves in a process that
+// loads it).
 #include "icnv_internal.h"
 
 namespace icnv {
