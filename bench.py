@@ -26,10 +26,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy ceiling
-def _stream_ceiling():
-    """What a plain grid-stride kernel gets for the fused pass's traffic mix (one matrix read, two written): the best
-    "1r2w" line of profiles/ubench_stream_1r2w.txt, the tracked output of scripts/ubench/stream_1r2w.hip on MI355X
-    (scripts/refresh_profiles.sh refreshes it); 5300 GB/s -- the value measured in rounds 2 and 3 -- if the file is absent."""
+def _stream_ceiling_from_file():
+    """Fallback only (the ubench binaries are missing): the best "1r2w" line of profiles/ubench_stream_1r2w.txt, the tracked
+    output of scripts/ubench/stream_1r2w.hip on SOME MI355X on some other day; 5300 GB/s if the file is absent too."""
     best = None
     try:
         for line in open(os.path.join(ROOT, "profiles", "ubench_stream_1r2w.txt")):
@@ -38,13 +37,54 @@ def _stream_ceiling():
                 best = v if best is None else max(best, v)
     except Exception:
         pass
-    return (best, "profiles/ubench_stream_1r2w.txt") if best else (5300.0, "constant (profiles/ubench_stream_1r2w.txt absent)")
+    return (best, "profiles/ubench_stream_1r2w.txt (NOT measured in this run)") if best else (5300.0, "constant (no ubench binary, no profile)")
 
 
-STREAM_1R2W_GBS, STREAM_1R2W_SOURCE = _stream_ceiling()
+def measure_ceilings():
+    """The two memory-system ceilings the roofline objects are priced against, measured ON THIS BOX IN THIS RUN, before any
+    bench tensor exists (boxes differ by +-10 %): scripts/ubench/stream_1r2w (a plain grid-stride 1-read : 2-write stream --
+    the traffic mix of the fused smooth pass) and scripts/ubench/column_walk (every lane walks a column of its own, 128-byte
+    visits, 768 lanes per CU -- the Viterbi's observation stream without arithmetic), both in their `quick` mode (< 1 s).
+    Built by __graft_entry__.build() (hipcc, in-tree, git-ignored).  Returns a dict; falls back to the tracked files."""
+    import subprocess
+    res = {}
+    def run(name):
+        exe = os.path.join(ROOT, "scripts", "ubench", name)
+        out = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=120, cwd="/tmp")
+        if out.returncode != 0:
+            raise RuntimeError(out.stderr[-200:])
+        return out.stdout
+    try:
+        best = None
+        for line in run("stream_1r2w").splitlines():
+            if line.startswith("1r2w") and "TB/s" in line:
+                v = float(line.split()[-2]) * 1000.0
+                best = v if best is None else max(best, v)
+        if not best:
+            raise RuntimeError("no 1r2w line")
+        res["stream_1r2w_gbs"], res["stream_1r2w_source"] = best, "scripts/ubench/stream_1r2w quick, measured in this run on this GPU"
+    except Exception as e:
+        v, src = _stream_ceiling_from_file()
+        res["stream_1r2w_gbs"], res["stream_1r2w_source"] = v, f"{src}; in-run measurement failed: {str(e)[:80]}"
+    try:
+        best = None
+        for line in run("column_walk").splitlines():
+            if line.startswith("visit") and "TB/s" in line:
+                v = float(line.split()[-2]) * 1000.0
+                best = v if best is None else max(best, v)
+        if not best:
+            raise RuntimeError("no visit line")
+        res["column_walk_gbs"], res["column_walk_source"] = best, "scripts/ubench/column_walk quick (768 lanes per CU, 128-byte visits), measured in this run on this GPU"
+    except Exception as e:
+        res["column_walk_gbs"] = 3660.0
+        res["column_walk_source"] = f"profiles/r04_ubench_column_walk.txt (NOT measured in this run: {str(e)[:80]})"
+    return res
+
+
+STREAM_1R2W_GBS, STREAM_1R2W_SOURCE = _stream_ceiling_from_file()     # replaced by measure_ceilings() in main()
 FP64_VECTOR_PEAK_TF = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 VITERBI_VALU_PER_GENE = 93.7   # SQ_INSTS_VALU / (genes x cells / 64), profiles/r04_pmc_viterbi_fast.txt
-COLUMN_WALK_GBS = 3660.0       # ceiling of the Viterbi's per-lane column walk, profiles/r04_ubench_column_walk.txt
+COLUMN_WALK_GBS, COLUMN_WALK_SOURCE = 3660.0, "profiles/r04_ubench_column_walk.txt"   # replaced by measure_ceilings() in main()
 
 
 def source_stamp():
@@ -209,6 +249,94 @@ def cpu_baseline(G, target_seconds=12.0, on_gpu=True):
     return res, parity
 
 
+def cpu_baseline_on_matrix(x, out, pre, states, chr_start, refs, hmm, n_sample=2000, seed=11):
+    """Config 3 (one GPU holds the whole job): the oracle over `[all reference cells | n_sample observation cells]` of the
+    bench matrix itself -- the first and the last 100 columns, both sides of every multiple of 2^31 elements, random ones.
+    Cells are independent given the reference cells' statistics (R/inferCNV_ops.R:1678-1786, 2302-2346), so the slice sees
+    what the whole matrix sees.  Timed, it is the cpu_baseline sample; compared with the last step's outputs (denoised
+    matrix, HMM input, states), it is the parity block.  Returns (cpu_baseline, parity)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import torch
+    import oracle_c as oc
+    from infercnv_amd import device
+    oc.build()
+    eff, affinity, quota = effective_cores()
+    cores = max(1, int(round(eff)))
+    oc.set_num_threads(cores)
+    means, sd, logPi, logDelta = hmm
+    C, G = x.shape
+    ref_all = np.concatenate(refs)
+    is_ref = np.zeros(C, dtype=bool)
+    is_ref[ref_all] = True
+    obs = np.flatnonzero(~is_ref)
+    pick = set(obs[:100].tolist()) | set(obs[-100:].tolist())
+    for k in range(1, (G * C) // (1 << 31) + 1):
+        c = (k << 31) // G
+        pick.update(int(v) for v in range(max(0, c - 2), min(C, c + 3)) if not is_ref[v])
+    rng = np.random.default_rng(seed)
+    pick.update(int(v) for v in rng.choice(obs, size=min(n_sample, obs.size), replace=False))
+    cols = np.array(sorted(pick), dtype=np.int64)
+    rows = torch.as_tensor(np.concatenate([ref_all.astype(np.int64), cols]), device="cuda")
+    # the slice's reference groups: positions 0 .. n_ref-1 in the order of the concatenated groups
+    off = np.concatenate([[0], np.cumsum([len(r) for r in refs])])
+    refs_slice = [np.arange(off[i], off[i + 1], dtype=np.int32) for i in range(len(refs))]
+    n = int(rows.numel())
+    CH = 8192                                            # rows per transfer / comparison: the GPU holds 270 GB of bench tensors
+    x_rows = np.empty((n, G), dtype=np.float64)          # (cells, genes) row-major == genes x cells column-major
+    for a in range(0, n, CH):
+        x_rows[a:a + CH] = x[rows[a:a + CH]].cpu().numpy()
+    xh = x_rows.T
+    t0 = time.perf_counter()
+    ref_out, ref_pre, (mu, s) = oc.smooth_chain(xh, chr_start, refs_slice, want_pre_denoise=True)
+    ref_st, _ = oc.viterbi_cells(ref_pre, chr_start, means, sd, logPi, logDelta)
+    t = time.perf_counter() - t0
+    del x_rows, xh
+    base = {"value": n / t, "unit": "cells/s", "cores": oc.num_threads(), "cores_note": (
+                f"{oc.num_threads()} OpenMP threads = the CPU quota of this container ({quota:.1f} cores) of {os.cpu_count()} logical CPUs on the node"
+                if quota else f"{oc.num_threads()} OpenMP threads = affinity mask ({affinity}) of {os.cpu_count()} logical CPUs, no CPU quota"),
+            "kind": "port",
+            "sample": f"{G} genes x {n} cells of the bench matrix itself ({ref_all.size} reference + {cols.size} sampled observation cells of "
+                      f"{C}), smooth chain + i6 Viterbi, oracle/icnv_oracle.c with OpenMP over cells, {t:.1f} s"}
+    device.release_pool()                                # the Viterbi's 16 GiB of scratch: the comparison needs a little room
+    scale = max(1.0, float(np.abs(ref_pre).max()))
+    tol = 1e-11 * scale
+    chain_max_abs, flips, legal, mism, same_input = 0.0, 0, True, 0, 0
+    ref_pre_t, ref_out_t, ref_st_t = ref_pre.T, ref_out.T, ref_st.T      # (cells, genes) views
+    for a in range(0, n, CH):
+        rr = rows[a:a + CH]
+        g_pre, g_out, g_st = pre[rr], out[rr], states[rr]
+        r_pre = torch.from_numpy(np.ascontiguousarray(ref_pre_t[a:a + CH])).cuda()
+        r_out = torch.from_numpy(np.ascontiguousarray(ref_out_t[a:a + CH])).cuda()
+        chain_max_abs = max(chain_max_abs, float((g_pre - r_pre).abs().max()))
+        diff = (g_out - r_out).abs() > tol
+        nf = int(diff.sum())
+        flips += nf
+        if nf:
+            pv, gv = r_pre[diff], g_out[diff]
+            on_bound = torch.minimum((pv - (mu - s)).abs(), (pv - (mu + s)).abs()) <= 2.0 * tol
+            legal = legal and bool((on_bound & (((gv - mu).abs() <= tol) | ((gv - pv).abs() <= tol))).all())
+        r_st = torch.from_numpy(np.ascontiguousarray(ref_st_t[a:a + CH])).cuda()
+        bad_rows = (g_st != r_st).any(dim=1)
+        nm = int((g_st != r_st).sum())
+        mism += nm
+        if nm:                                           # the contract is bit-exactness on IDENTICAL inputs: redo those cells
+            bad_cells = torch.nonzero(bad_rows).flatten()
+            want, _ = oc.viterbi_cells(g_pre[bad_cells].cpu().numpy().T, chr_start, means, sd, logPi, logDelta)
+            same_input += int((g_st[bad_cells].cpu().numpy().T != want).sum())
+        del g_pre, g_out, g_st, r_pre, r_out, r_st, diff
+    parity = {"cells": int(n), "of_cells": int(C), "genes": int(G), "elements_of_the_matrix": int(G) * int(C),
+              "multiples_of_2_31_elements_crossed": int((G * C) >> 31),
+              "chain_max_abs": chain_max_abs, "chain_tolerance_abs": 1e-11,
+              "chain_max_rel": chain_max_abs / scale, "north_star_rel_tolerance": 1e-5,
+              "denoise_flips": flips, "denoise_flips_all_on_a_bound_and_legal": legal,
+              "state_calls": int(n) * int(G), "state_mismatches": mism, "state_mismatches_on_identical_inputs": same_input,
+              "ok": bool(chain_max_abs <= 1e-11 and legal and same_input == 0),
+              "what": "the timed step's own outputs (C ABI, device-resident) vs the oracle over [all reference cells | sampled observation "
+                      "cells incl. both ends and both sides of every 2^31-element multiple] of the same matrix; outside the timed region"}
+    return base, parity
+
+
 def host_path_rate(x_dev, chr_start, refs, hmm, cells=20000):
     """PCIe-inclusive rate of the HOST-BUFFER entry points -- what an R process gets through the .Call shim: the fused
     icnv_smooth_chain (matrix up; denoised matrix + HMM input down) and icnv_viterbi_cells on host matrices (pageable
@@ -358,9 +486,12 @@ def main():
     ap.add_argument("--cells", type=int, default=50000, help="cells per GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5),
-                    help="BASELINE.json config: 2 (default) fused smooth chain + per-cell i6 HMM -- the headline metric; "
-                         "4 i3 HMM at subcluster level; 5 apply_median_filtering (whole subclusters / tiles per GPU, SURVEY.md 8e)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5),
+                    help="BASELINE.json config: 2 (default) fused smooth chain + per-cell i6 HMM, 50 000 cells per GPU (weak scaling) -- the "
+                         "headline metric; 3 the same step on BASELINE configs[2]: --total-cells (1 000 000) cells IN TOTAL dealt over the "
+                         "N GPUs (strong scaling; N = 1 holds all of them: 270 GB of HBM); 4 i3 HMM at subcluster level; "
+                         "5 apply_median_filtering (whole subclusters / tiles per GPU, SURVEY.md 8e)")
+    ap.add_argument("--total-cells", type=int, default=1000000, help="config 3: cells of the whole job")
     ap.add_argument("--checksum", type=int, default=0, metavar="PARTS",
                     help="also print checksums of the outputs: per rank (N > 1), or -- on one rank -- per residue class of the cell "
                          "index modulo PARTS, i.e. the cells rank r of a PARTS-rank run holds (tests/test_gpu_entrypoints.py)")
@@ -396,8 +527,21 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    G, C_local = args.genes, args.cells
-    C_total = C_local * world
+    global STREAM_1R2W_GBS, STREAM_1R2W_SOURCE, COLUMN_WALK_GBS, COLUMN_WALK_SOURCE
+    if rank == 0 and args.config in (2, 3) and not os.environ.get("ICNV_BENCH_NO_UBENCH"):
+        ceil = measure_ceilings()                    # on this box, in this run, before any bench tensor exists
+        STREAM_1R2W_GBS, STREAM_1R2W_SOURCE = ceil["stream_1r2w_gbs"], ceil["stream_1r2w_source"]
+        COLUMN_WALK_GBS, COLUMN_WALK_SOURCE = ceil["column_walk_gbs"], ceil["column_walk_source"]
+    if dist_on:
+        dist.barrier()
+
+    G = args.genes
+    if args.config == 3:                             # strong scaling: the job's cells dealt round-robin over the ranks
+        C_total = args.total_cells
+        C_local = len(range(rank, C_total, world))
+    else:
+        C_local = args.cells
+        C_total = C_local * world
     if args.config in (4, 5):
         run_group_config(args, world, rank)
         if dist_on:
@@ -412,12 +556,13 @@ def main():
     means, sd, logPi, logDelta = synth.hmm_params_i6()
 
     out = torch.empty_like(x)
+    pre_buf = torch.empty_like(x)                    # the HMM input (the matrix before step 22), written by the apply pass
     states = torch.empty((C_local, G), dtype=torch.uint8, device="cuda")
     plan = device.ChainPlan(G, C_local, chr_start, refs_local)
     chain = sharded.ShardedChain(plan, always_reduce=dist_on)
 
     def step():
-        _, pre = chain.run(x, out=out, want_pre_denoise=True)
+        _, pre = chain.run(x, out=out, pre=pre_buf)
         device.viterbi_cells(pre, chr_start, means, sd, logPi, logDelta, states=states)
         return pre
 
@@ -463,8 +608,13 @@ def main():
         device.timing_enable(False)
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    cells_per_rank = [C_local]
     if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        mine = torch.tensor([float(C_local)], dtype=torch.float64, device="cuda")
+        allc = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(allc, mine)
+        cells_per_rank = [int(v.item()) for v in allc]
     elapsed = float(tmax.item())
 
     checksums = None
@@ -505,10 +655,13 @@ def main():
         roof = {}
         for k, b in alg.items():
             if k in kernels:
-                gbs = b / (kernels[k]["avg_ms"] * 1e-3) / 1e9
+                # (a family with several launches per step -- the Viterbi's column batches past 429 000 cells -- is priced per
+                # launch: its bytes per step / launches per step over its average launch duration = bytes per step / ms per step)
+                gbs = b / (kernels[k]["ms_per_step"] * 1e-3) / 1e9
                 roof[k] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": b,
-                           "avg_launch_ms": kernels[k]["avg_ms"]}
+                           "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_launch": b / max(kernels[k]["launches_per_step"], 1e-9),
+                           "launches_per_step": kernels[k]["launches_per_step"], "avg_launch_ms": kernels[k]["avg_ms"]}
         if "chain_apply" in roof:
             cap = STREAM_1R2W_GBS / HBM_PEAK_GBS * 16.0 / 24.0
             roof["chain_apply"]["structural_cap_of_frac"] = cap
@@ -530,9 +683,9 @@ def main():
                                        "sequence, 768 threads (three wavefronts per SIMD), the gene step software-pipelined (gathers | decision "
                                        "bookkeeping | rows), 86 vector + 14 LDS-gather + 18 scalar + 1 store instructions per gene and wavefront in "
                                        "the forward pass, block summaries for the traceback.  What paces it (round 4, DESIGN.md K4b): the observation "
-                                       "stream -- every lane walks a column of its own, one 128-byte line per visit; that pattern alone reads the 4 GB "
-                                       "in 1.09 ms at its ceiling of 3.66 TB/s (profiles/r04_ubench_column_walk.txt), and with the observations served "
-                                       "from L2 the launch takes 1.73 ms (ablation).  No MFMA-shaped work")
+                                       "stream -- every lane walks a column of its own, one 128-byte line per visit; `column_walk_ceiling` is that "
+                                       "pattern without arithmetic, measured in this run; with the observations served from L2 the 50 000-cell launch "
+                                       "takes 1.73 ms (ablation).  No MFMA-shaped work")
         if "viterbi" in roof:
             # second ceiling of the Viterbi (SURVEY.md 8d asks for HBM GB/s *and* the fp64 rate): vector instructions per gene and
             # wavefront (SQ_INSTS_VALU of the launch / gene steps, profiles/r04_pmc_viterbi_fast.txt; 86 of them in the forward pass
@@ -540,16 +693,17 @@ def main():
             instr = VITERBI_VALU_PER_GENE
             ceil_ms = (G * C_local / 64.0) * instr * 4.0 / (256 * 4) / 2.4e9 * 1e3
             roof["viterbi"]["fp64_issue"] = {"vector_instr_per_gene_wavefront": instr, "ceiling_ms": ceil_ms,
-                                             "frac": ceil_ms / kernels["viterbi"]["avg_ms"],
+                                             "frac": ceil_ms / kernels["viterbi"]["ms_per_step"],
                                              "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TF,
                                              "note": "share of the launch the vector pipes would need at full issue rate and the 2.4 GHz peak "
                                                      "clock (the chip holds ~2.05-2.1 GHz under this load)"}
-            roof["viterbi"]["column_walk_ceiling"] = {"gbs": COLUMN_WALK_GBS, "source": "profiles/r04_ubench_column_walk.txt (768 threads, 128-byte visits)",
+            roof["viterbi"]["column_walk_ceiling"] = {"gbs": COLUMN_WALK_GBS, "source": COLUMN_WALK_SOURCE,
+                                                      "frac_of_column_walk": 8.0 * G * C_local / COLUMN_WALK_GBS / 1e6 / kernels["viterbi"]["ms_per_step"],
                                                       "ms_for_the_observations_alone": 8.0 * G * C_local / COLUMN_WALK_GBS / 1e6}
         dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
         if "chain_apply" in roof:
             moved = 3 * 8 * G * n_main            # one matrix read, two written (refined below by the counters when present)
-            t = kernels["chain_apply"]["avg_ms"] * 1e-3
+            t = kernels["chain_apply"]["ms_per_step"] * 1e-3
             roof["chain_apply"]["hbm_traffic"] = {"bytes_per_launch": moved, "source": "3 x 8 B per gene*cell",
                                                   "achieved": moved / t / 1e9, "unit": "GB/s",
                                                   "frac_of_peak": moved / t / 1e9 / HBM_PEAK_GBS,
@@ -568,14 +722,28 @@ def main():
                         ht.update({"bytes_per_launch": tr[k], "source": "FETCH_SIZE (x2) + WRITE_SIZE counters, see traffic_source",
                                    "achieved": tr[k] / t / 1e9, "frac_of_peak": tr[k] / t / 1e9 / HBM_PEAK_GBS,
                                    "frac_of_stream_1r2w": tr[k] / t / 1e9 / STREAM_1R2W_GBS})
+        if args.config == 3:
+            workload = (f"BASELINE configs[2]: synthetic {G} genes x {C_total} cells IN TOTAL, dealt round-robin over {world} GPU(s) "
+                        f"({C_local} on rank 0), fused smooth chain (steps 8,9,10,11,12,14,22) + per-cell i6 HMM Viterbi, inputs resident in HBM")
+        else:
+            workload = (f"BASELINE configs[1] per GPU: synthetic {G} genes x {C_local} cells per GPU ({C_total} total), fused smooth chain "
+                        "(steps 8,9,10,11,12,14,22) + per-cell i6 HMM Viterbi, inputs resident in HBM")
         res = {
             "metric": "cells/sec through smooth+i6-HMM, 10k genes", "value": value, "unit": "cells/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"synthetic {G} genes x {C_local} cells per GPU ({C_total} total), fused smooth chain "
-                                   "(steps 8,9,10,11,12,14,22) + per-cell i6 HMM Viterbi, inputs resident in HBM",
+            "higher_is_better": True, "scaling": "strong" if args.config == 3 else "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": workload, "baseline_config": args.config,
                        "genes": G, "cells_per_gpu": C_local, "cells_total": C_total, "window_length": 101,
                        "hmm": "i6, t=1e-6", "parallelism": f"cell-shard x{world} (round-robin deal), 3 small all-reduces"},
+            # what the driver's SCALE record can be checked against: the launcher's world size, the communicator's own, the
+            # backend, and the cells every rank really held (all-gathered)
+            "world": {"env_world_size": world, "n_gpus_arg": args.gpus,
+                      "communicator_world_size": dist.get_world_size() if dist_on else 1,
+                      "backend": (dist.get_backend() if dist_on else None),
+                      "cells_per_rank": cells_per_rank, "cells_sum": int(sum(cells_per_rank))},
+            "ceilings_measured_in_this_run": {"stream_1r2w_gbs": STREAM_1R2W_GBS, "stream_1r2w_source": STREAM_1R2W_SOURCE,
+                                              "column_walk_gbs": COLUMN_WALK_GBS, "column_walk_source": COLUMN_WALK_SOURCE},
             "roofline": roof.get(dominant) or (next(iter(roof.values())) if roof else None),
             "roofline_kernel": dominant,
             # the north star states its roofline target on the fused smooth pass: always there, whichever kernel is the
@@ -595,12 +763,17 @@ def main():
         }
         if checksums is not None:
             res["checksums"] = {"per_part": checksums, "meaning": "[sum(denoised), sum(hmm_input), sum(states)] of the cells of rank r"}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.config == 3:
+            # the oracle runs over [all reference cells | sampled observation cells] of THIS matrix: timed, it is the
+            # cpu_baseline sample; compared with the step's outputs, it is the parity block
+            res["cpu_baseline"], res["parity"] = cpu_baseline_on_matrix(x, out, pre_buf, states, chr_start, refs_local,
+                                                                        (means, sd, logPi, logDelta))
+        elif not args.no_cpu_baseline and world == 1:
             try:
                 res["host_path"] = host_path_rate(x, chr_start, refs_local, (means, sd, logPi, logDelta))
             except Exception as e:          # a reported side figure must not take the bench line down
                 res["host_path"] = {"error": str(e)[:200]}
-            del x, out, states, chain, plan        # the bench tensors: the parity leg below holds its own sample in HBM
+            del x, out, pre_buf, states, chain, plan        # the bench tensors: the parity leg below holds its own sample in HBM
             res["cpu_baseline"], res["parity"] = cpu_baseline(G)
         elif not args.no_cpu_baseline:
             res["cpu_baseline"] = None

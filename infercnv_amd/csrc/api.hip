@@ -141,33 +141,54 @@ void pool_free(void *p) {
 // ------------------------------------------------------------------ kernel timing
 namespace {
 int g_timing = 0;   // 0 off, 1 every kernel family, 2 only the two hot launches of the bench step (chain_apply, viterbi)
-struct TimedRec { std::string name; hipEvent_t e0, e1; };
+struct TimedRec { std::string name; hipEvent_t e0, e1; int dev; };
 std::vector<TimedRec> g_pending;
-std::vector<hipEvent_t> g_event_pool;   // recycled events: creating two per launch costs host time inside a timed region
+// recycled events, PER DEVICE (an event belongs to the device it was created on: with one worker thread per GPU -- icnv_set_devices --
+// a timer on device A must never pop an event of device B); creating two per launch costs host time inside a timed region
+std::map<int, std::vector<hipEvent_t>> g_event_pool;
 std::map<std::string, std::pair<double, int64_t>> g_times;
 std::mutex g_time_mu;
 bool hot_kernel(const char *n) { return std::strcmp(n, "chain_apply") == 0 || std::strcmp(n, "viterbi") == 0; }
-bool pooled_event(hipEvent_t *e) {
+bool pooled_event(int dev, hipEvent_t *e) {
     {
         std::lock_guard<std::mutex> lk(g_time_mu);
-        if (!g_event_pool.empty()) { *e = g_event_pool.back(); g_event_pool.pop_back(); return true; }
+        auto &pool = g_event_pool[dev];
+        if (!pool.empty()) { *e = pool.back(); pool.pop_back(); return true; }
     }
-    return hipEventCreate(e) == hipSuccess;
+    if (hipEventCreate(e) == hipSuccess) return true;
+    (void)hipGetLastError();
+    return false;
+}
+void unpool_events(int dev, hipEvent_t a, hipEvent_t b) {
+    std::lock_guard<std::mutex> lk(g_time_mu);
+    if (a) g_event_pool[dev].push_back(a);
+    if (b) g_event_pool[dev].push_back(b);
 }
 }  // namespace
 
 KernelTimer::KernelTimer(const char *n, hipStream_t s) : name(n), stream(s) {
     on = g_timing == 1 || (g_timing == 2 && hot_kernel(n));
     if (on) {
-        if (!pooled_event(&e0) || !pooled_event(&e1)) { on = false; return; }
-        (void)hipEventRecord(e0, stream);
+        dev = current_device();
+        if (!pooled_event(dev, &e0)) { e0 = nullptr; on = false; return; }
+        if (!pooled_event(dev, &e1)) { unpool_events(dev, e0, nullptr); e0 = e1 = nullptr; on = false; return; }
+        if (hipEventRecord(e0, stream) != hipSuccess) {   // a failed record must not surface as the launch's error
+            (void)hipGetLastError();
+            unpool_events(dev, e0, e1);
+            e0 = e1 = nullptr;
+            on = false;
+        }
     }
 }
 KernelTimer::~KernelTimer() {
     if (on) {
-        (void)hipEventRecord(e1, stream);
+        if (hipEventRecord(e1, stream) != hipSuccess) {
+            (void)hipGetLastError();
+            unpool_events(dev, e0, e1);
+            return;
+        }
         std::lock_guard<std::mutex> lk(g_time_mu);
-        g_pending.push_back({name, e0, e1});
+        g_pending.push_back({name, e0, e1, dev});
     }
 }
 
@@ -181,10 +202,16 @@ static void drain_timers() {
             acc.first += ms;
             acc.second += 1;
         }
-        g_event_pool.push_back(r.e0);
-        g_event_pool.push_back(r.e1);
+        g_event_pool[r.dev].push_back(r.e0);
+        g_event_pool[r.dev].push_back(r.e1);
     }
     g_pending.clear();
+}
+static void destroy_event_pool() {   // icnv_shutdown: hipEventDestroy takes the handle whatever the current device is
+    std::lock_guard<std::mutex> lk(g_time_mu);
+    for (auto &kv : g_event_pool)
+        for (hipEvent_t e : kv.second) (void)hipEventDestroy(e);
+    g_event_pool.clear();
 }
 
 // ------------------------------------------------------------------ helpers
@@ -227,9 +254,6 @@ struct icnv_chain {
     int T = 0;
     uint32_t mask = 0;
     DevBuf d_chr, d_ref, d_b1, d_b2, d_den, d_partial, d_sums, d_cellstats, d_stats, d_inv, d_inv_codes, d_inv_dict;
-    DevBuf d_plan2, d_dict2;            // sub-block plan of the chain2 kernels (empty: layout not covered)
-    std::vector<uint32_t> plan2;
-    std::vector<double> dict2;
     std::vector<double> inv_tab, inv_dict;
     std::vector<uint32_t> inv_codes;
     bool inv_coded = false;   // host copy of the smoothing normalisation table (kept alive for the async upload)
@@ -274,6 +298,7 @@ int icnv_init(int device) {
 
 void icnv_shutdown(void) {
     drain_timers();
+    destroy_event_pool();
     icnv_residency_drop();
     viterbi_release_contexts();
     std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -406,10 +431,6 @@ static int chain_upload(icnv_chain *ch, hipStream_t s) {
         if ((rc = upload(ch->d_inv, ch->inv_tab.data(), ch->inv_tab.size(), s))) return rc;
         if ((rc = upload(ch->d_inv_codes, ch->inv_codes.data(), ch->inv_codes.size(), s))) return rc;
         if ((rc = upload(ch->d_inv_dict, ch->inv_dict.data(), ch->inv_dict.size(), s))) return rc;
-        if (chain2_build_plan(ch->chr_start.data(), ch->cfg.n_chr, (int32_t)G, ch->T, ch->plan2, ch->dict2)) {
-            if ((rc = upload(ch->d_plan2, ch->plan2.data(), ch->plan2.size(), s))) return rc;
-            if ((rc = upload(ch->d_dict2, ch->dict2.data(), ch->dict2.size(), s))) return rc;
-        }
     }
     ch->uploaded = true;
     return ICNV_OK;
@@ -435,8 +456,6 @@ static ChainArgs chain_args(icnv_chain *ch, const double *in) {
     a.inv_coded = ch->inv_coded ? 1 : 0;
     a.partial = ch->d_partial.as<double>();
     a.cell_stats = ch->d_cellstats.as<double>();
-    a.plan2 = ch->plan2.empty() ? nullptr : ch->d_plan2.as<uint32_t>();
-    a.dict2 = ch->plan2.empty() ? nullptr : ch->d_dict2.as<double>();
     return a;
 }
 
@@ -1038,9 +1057,8 @@ struct ViterbiCtx {
     int64_t flag_limit = 0;            // of the last column batch: more flagged sequences than this -> exact kernel
     // chromosome layout of the last call on the device ([n_chr + 1] starts, then [n_chr] chromosomes longest first): a
     // pipeline calls with one layout over and over, and two pageable uploads per call are two stalls of the stream
-    std::vector<int32_t> layout_key;
-    int32_t *d_layout = nullptr;
-    size_t layout_cap = 0;
+    std::map<std::vector<int32_t>, int32_t *> layouts;
+    int32_t *d_layout = nullptr;   // the current call's
 };
 std::mutex g_vctx_mu;
 std::map<int, ViterbiCtx *> g_vctx;
@@ -1082,8 +1100,9 @@ void viterbi_release_contexts() {
         if (c.counters) (void)hipFree(c.counters);
         if (c.host_flag) (void)hipHostFree(c.host_flag);
         if (c.flag_ev) (void)hipEventDestroy(c.flag_ev);
-        if (c.d_layout) (void)hipFree(c.d_layout);
-        c.d_layout = nullptr; c.layout_cap = 0; c.layout_key.clear();
+        for (auto &kv2 : c.layouts) (void)hipFree(kv2.second);
+        c.layouts.clear();
+        c.d_layout = nullptr;
         c.dev = nullptr; c.dev_bytes = 0; c.counters = nullptr; c.host_flag = nullptr; c.flag_ev = nullptr;
         c.valid = false;
     }
@@ -1145,25 +1164,28 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
     ViterbiCtx &vc = *viterbi_ctx_ptr();
     std::lock_guard<std::mutex> vlk(vc.mu);
     {
+        // One device buffer per chromosome layout seen (a few hundred bytes each), never overwritten: work queued on any
+        // stream may still read an older layout, and a *_dev call must not stall the device (nor break a stream capture)
+        // because the layout changed.  A new layout costs one small allocation and one synchronous copy into memory nobody
+        // reads yet; a pipeline calls with one layout over and over and finds it here.
         std::vector<int32_t> key(chr_start, chr_start + n_chr + 1);
         key.insert(key.end(), order.begin(), order.end());
-        if (key != vc.layout_key || !vc.d_layout) {
-            if (key.size() > vc.layout_cap) {
+        auto it = vc.layouts.find(key);
+        if (it == vc.layouts.end()) {
+            if (vc.layouts.size() >= 256) {   // a caller that never repeats a layout: start over (the only place that waits)
                 ICNV_HIP(hipDeviceSynchronize());
-                if (vc.d_layout) (void)hipFree(vc.d_layout);
-                vc.d_layout = nullptr;
-                vc.layout_cap = 0;
-                vc.layout_key.clear();
-                ICNV_HIP(hipMalloc((void **)&vc.d_layout, key.size() * sizeof(int32_t)));
-                vc.layout_cap = key.size();
+                for (auto &kv : vc.layouts) (void)hipFree(kv.second);
+                vc.layouts.clear();
             }
-            // work queued on ANY stream of this device may still read the previous layout (an asynchronous _dev call on another
-            // stream of the same thread with another chromosome layout): the layout changes rarely, wait for the device
-            ICNV_HIP(hipDeviceSynchronize());
-            vc.layout_key.clear();
-            ICNV_HIP(hipMemcpy(vc.d_layout, key.data(), key.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-            vc.layout_key = std::move(key);
+            int32_t *d = nullptr;
+            ICNV_HIP(hipMalloc((void **)&d, key.size() * sizeof(int32_t)));
+            if (hipMemcpy(d, key.data(), key.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+                (void)hipFree(d);
+                ICNV_FAIL(ICNV_ERR_HIP, "upload of the chromosome layout failed");
+            }
+            it = vc.layouts.emplace(std::move(key), d).first;
         }
+        vc.d_layout = it->second;
     }
     const int32_t *const dev_chr = vc.d_layout, *const dev_ord = vc.d_layout + n_chr + 1;
     // the certified fast path needs a shared sd, the .get_HMM transition structure and a table that met its accuracy target

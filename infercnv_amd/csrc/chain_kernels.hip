@@ -463,10 +463,6 @@ int launch_chain(const ChainArgs &a0, int mode, hipStream_t stream) {
         ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "smoothing window too long for the fused chain kernel (half window / chunk length > 64)");
     if (smooth && !(a.inv_pos && a.inv_codes && a.inv_dict)) ICNV_FAIL(ICNV_ERR_ARG, "smoothing launch without its normalisation table");
     a.pad = g.pad;
-    if (a.plan2 && smooth) {   // two resident cells per CU, wave-private smoothing (chain2.hip) for the passes it is built for
-        const int rc = launch_chain2(a, mode, stream);
-        if (rc != -1000) return rc;
-    }
     if (g.lmax == 7) return launch_chain_m7(a, mode, stream);
     if (g.nt == 1024) {
         if (smooth && a.T == 50) {

@@ -69,6 +69,7 @@ struct KernelTimer {
     const char *name;
     hipStream_t stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    int dev = 0;          // device the events belong to (the event pool is per device)
     bool on = false;
 };
 
@@ -107,17 +108,10 @@ struct ChainArgs {
     double *cache_out;      // MODE_GENE_SUMS, nullable: the stages' output of list position i goes to cache_out[i * G ..]
     int32_t in_by_pos;      // 1: `in` holds one column per list position (a cache written through cache_out)
     double *cell_stats;     // MODE_CELL_STATS: [n_cells * 2] {sum, sd}
-    int32_t out_by_pos;     // 1 (chain2 kernels): `out` receives one column per list position (the reference-cell cache)
-    const uint32_t *plan2;  // nullable: sub-block plan of the two-cells-per-CU kernels (chain2.hip) for this layout
-    const double *dict2;    // [256] its dictionary of 1/denominator values
+    int32_t out_by_pos;     // 1: `out` receives one column per list position (the reference-cell cache written by round B)
 };
 
 int launch_chain(const ChainArgs &a, int mode, hipStream_t stream);
-// chain2.hip: plan of the sub-blocks for a chromosome layout (false: the layout is not covered), and the launch
-// (-1000 when the request is not one of its compile-time passes)
-bool chain2_build_plan(const int32_t *chr_start, int32_t n_chr, int32_t G, int32_t T, std::vector<uint32_t> &plan,
-                       std::vector<double> &dict);
-int launch_chain2(const ChainArgs &a, int mode, hipStream_t stream);
 int chain_max_genes();
 bool chain_fused_fits(int64_t G, int32_t n_chr, int32_t T);   // does the LDS-resident fused kernel take this geometry?
 

@@ -45,6 +45,14 @@ def init(device=None):
         check(L.icnv_viterbi_set_mode(int(os.environ["ICNV_VITERBI_MODE"])))
 
 
+def release_pool():
+    """Hand the library's cached device blocks (workspace pool, resident matrices, Viterbi tables) back to the driver
+    (icnv_shutdown; the library stays usable, the next call allocates again).  For callers that need the whole HBM for
+    one large matrix after smaller runs -- the 1 M-cell case holds 270 of the 288 GB."""
+    torch.cuda.synchronize()
+    _lib.load().icnv_shutdown()
+
+
 # ------------------------------------------------------------------ smoothing chain
 def smooth_chain(x, chr_start, ref_groups, window_length=101, max_thresh=3.0, use_bounds=True,
                  sd_amplifier=1.5, noise_filter=None, stage_mask=_lib.ST_ALL, out=None, want_pre_denoise=False,
@@ -89,10 +97,12 @@ class ChainPlan:
     def round_finish(self, r):
         check(self.L.icnv_chain_round_finish_dev(self.h, r, _stream()))
 
-    def apply(self, x, out=None, want_pre_denoise=False):
+    def apply(self, x, out=None, want_pre_denoise=False, pre=None):
+        """`pre`: a preallocated tensor for the matrix before step 22 (implies want_pre_denoise)."""
         if out is None:
             out = torch.empty_like(x)
-        pre = torch.empty_like(x) if want_pre_denoise else None
+        if pre is None and want_pre_denoise:
+            pre = torch.empty_like(x)
         check(self.L.icnv_chain_apply_dev(self.h, _ptr(x), _ptr(out), _ptr(pre), _stream()))
         return out, pre
 

@@ -84,11 +84,13 @@ class ShardedChain:
         if dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.pg) > 1 or self.always_reduce):
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
 
-    def run(self, x_local, out=None, want_pre_denoise=False):
+    def run(self, x_local, out=None, want_pre_denoise=False, pre=None):
         for r in range(self.engine.num_rounds):
             buf = self.engine.round_partial(r, x_local)
             self._all_reduce(buf)
             self.engine.round_finish(r)
+        if pre is not None:                      # a preallocated HMM-input matrix (engines without the keyword allocate their own)
+            return self.engine.apply(x_local, out=out, want_pre_denoise=True, pre=pre)
         return self.engine.apply(x_local, out=out, want_pre_denoise=want_pre_denoise)
 
 

@@ -29,11 +29,12 @@ __global__ void walk(const double *x, long long G, long long ncols, int *counter
     if (acc == 12345.678) sink[0] = acc;
     (void)s_task;
 }
-int main() {
+int main(int argc, char **argv) {
+    const bool quick = argc > 1;   // `column_walk quick`: the product's geometry only (768 lanes per CU, 128-byte visits)
     const long long G = 10000, C = 50000;
     double *x, *sink;
     int *counter;
-    hipMalloc(&x, G * C * 8); hipMalloc(&sink, 8); hipMalloc(&counter, 4);
+    if (hipMalloc(&x, G * C * 8) != hipSuccess || hipMalloc(&sink, 8) != hipSuccess || hipMalloc(&counter, 4) != hipSuccess) { fprintf(stderr, "hipMalloc failed\n"); return 1; }
     hipMemset(x, 0, G * C * 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto run = [&](const char *name, auto kern, int nt, int cus) {
@@ -48,6 +49,7 @@ int main() {
         }
         printf("%-22s %4d threads x %3d workgroups  %.3f ms  %.2f TB/s\n", name, nt, cus, best, (C / 64) * 64 * G * 8.0 / best / 1e9);
     };
+    if (quick) { run("visit 128 B", walk<128>, 768, 256); return 0; }
     for (int nt : {512, 768, 1024})
         for (int cus : {128, 256}) {
             run("visit  64 B", walk<64>, nt, cus);

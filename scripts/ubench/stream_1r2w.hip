@@ -14,10 +14,11 @@ __global__ void k(const dbl2 *in, dbl2 *o1, dbl2 *o2, size_t n) {
         else { o1[i] = v; if (NW > 1) o2[i] = v; }
     }
 }
-int main() {
+int main(int argc, char **argv) {
+    const bool quick = argc > 1;   // `stream_1r2w quick`: the two best geometries only (bench.py measures its ceiling with it in every run)
     const size_t bytes = 3600000000ull, n = bytes / 16;
     dbl2 *in, *o1, *o2;
-    hipMalloc(&in, bytes); hipMalloc(&o1, bytes); hipMalloc(&o2, bytes);
+    if (hipMalloc(&in, bytes) != hipSuccess || hipMalloc(&o1, bytes) != hipSuccess || hipMalloc(&o2, bytes) != hipSuccess) { fprintf(stderr, "hipMalloc failed\n"); return 1; }
     hipMemset(in, 0, bytes);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto run = [&](const char *name, auto kern, int nw, int grid, int block) {
@@ -29,6 +30,7 @@ int main() {
         printf("%-28s grid %5d x %4d  %.3f ms  %.2f TB/s\n", name, grid, block, ms, bytes * (1.0 + nw) / ms / 1e9);
     };
     for (int grid : {256, 1024, 4096, 16384}) {
+        if (quick && grid < 4096) continue;
         run("1r1w plain", k<0, 1>, 1, grid, 1024);
         run("1r1w nt", k<1, 1>, 1, grid, 1024);
         run("1r2w plain", k<0, 2>, 2, grid, 1024);

@@ -1179,69 +1179,6 @@ def test_parallelDist_mirror_matches_scipy(dev):
     assert d.shape == want.shape and np.abs(d - want).max() <= 1e-12 * want.max()
 
 
-# ------------------------------------------------------------------ chain2: the opt-in two-cells-per-CU kernels
-@pytest.mark.parametrize("case", ["bench_layout", "odd_starts", "median_paths"])
-def test_chain2_opt_in_kernels_vs_oracle(dev, monkeypatch, case):
-    """csrc/chain2.hip (two resident cells per CU, wave-private smoothing through LDS windows; measured slower than the
-    product kernel and therefore opt-in, ICNV_CHAIN2=1) against the oracle: full chain with and without denoise on the
-    bench's layout with more cells than workgroups, a layout whose chromosomes start at odd genes (pairs straddling a
-    boundary, halo pairs with one element), and the cells built to take the median select's rare paths."""
-    from infercnv_amd import synth, _lib
-    if not hasattr(_lib.load(), "icnv_debug_chain2_plan"):
-        # the product library carries stubs: run this very test in a process that loads the variant build instead
-        import subprocess, sys
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        variant = os.path.join(root, "infercnv_amd", "libicnv_hip_chain2.so")
-        if not os.path.exists(variant) or os.environ.get("ICNV_CHAIN2_SUBPROCESS"):
-            pytest.skip("the chain2 kernels are a variant build (make -C infercnv_amd/csrc chain2-variant)")
-        res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
-                              f"test_chain2_opt_in_kernels_vs_oracle and {case}"], capture_output=True, text=True, cwd=root,
-                             env=dict(os.environ, ICNV_LIB=variant, ICNV_CHAIN2_SUBPROCESS="1"))
-        assert res.returncode == 0 and "1 passed" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
-        return
-    monkeypatch.setenv("ICNV_CHAIN2", "1")
-    rng = np.random.default_rng(3)
-    if case == "bench_layout":
-        G, C = 10000, 1300
-        x, cs = synth.make_matrix_np(G, C)
-        refs, _ = synth.groups(C)
-    elif case == "odd_starts":
-        G, C = 9000, 600
-        cs = np.array([0, 1071, 1778, 2385, 2736, 3215, 3749, 4262, 4617, 5026, 5455, 6065, 6622, 6809, 7161, 7478, 7929, 8557,
-                       8705, G], dtype=np.int32)
-        x = rng.normal(0.0, 0.4, size=(G, C)) + rng.normal(0.0, 0.3, size=(G, 1)) + 1.0
-        refs = [np.arange(0, 30, dtype=np.int32), np.arange(30, 75, dtype=np.int32)]
-    else:
-        G, C = 6000, 64
-        cs = synth.chr_layout(G)
-        x = rng.normal(0.0, 0.3, size=(G, C))
-        x[:, :4] = 0.0
-        x[:, 4] = 0.0
-        x[:, 5] = np.concatenate([-np.ones(2000), np.zeros(2500), np.ones(1500)])
-        x[:, 6] = np.concatenate([-np.ones(1000), np.zeros(2000), rng.normal(2.0, 0.1, size=3000)])
-        x[:, 7] = np.where(rng.random(G) < 0.6, 0.0, rng.normal(size=G))
-        x[:, 8] = np.repeat(rng.normal(size=G // 200), 200)
-        x[:, 9] = -5.0                                           # every value at the lower clamp: the lowest bin holds the median
-        refs = [np.arange(4, dtype=np.int32)]
-    xd = to_dev(x)
-    for mask in (0x7F, 0x3F):
-        out, pre = dev.smooth_chain(xd, cs, refs, stage_mask=mask, want_pre_denoise=True)
-        want_out, want_pre, musd = oc.smooth_chain(x, cs, refs, want_pre_denoise=True, stage_mask=mask)
-        if mask == 0x3F:
-            want_pre = want_out
-        assert np.abs(to_host(pre) - want_pre).max() < 1e-11, (case, hex(mask))
-        if mask == 0x7F:
-            check_denoise_flips(to_host(out), want_out, want_pre, *musd, tol=1e-11, label=f"chain2 {case}")
-    # the opt-in kernels really ran: their launch is timed under its own name only when the plan exists
-    dev.timing_enable(True)
-    dev.timing_reset()
-    dev.smooth_chain(xd, cs, refs)
-    torch.cuda.synchronize()
-    ms, n = dev.timing_get("chain2_apply")
-    dev.timing_enable(False)
-    assert n >= 1, "the chain2 kernels did not run"
-
-
 def test_chain_missing_values_policy_against_the_reference_semantics(dev):
     """What happens to NA / NaN in the chain, stated against the reference.  R: `.smooth_helper` strips a cell's NAs,
     smooths the shortened sequence and re-inserts them (R/inferCNV_ops.R:2487-2489, 2529); `median(x, na.rm = TRUE)`

@@ -231,176 +231,6 @@ def test_r_shim_compiles_and_registers():
     assert res.returncode == 0 and "SHIM_CPU_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
 
 
-# ------------------------------------------------------------------ chain2: the sub-block plan, emulated on the CPU
-def _chain2_plan(chr_start, G, T=50):
-    import ctypes as ct
-    from infercnv_amd import _lib
-    L = _lib.load()
-    if not hasattr(L, "icnv_debug_chain2_plan"):
-        # the product library carries stubs; the plan builder lives in the variant build (host code: loadable without a GPU)
-        variant = os.path.join(ROOT, "infercnv_amd", "libicnv_hip_chain2.so")
-        if not os.path.exists(variant):
-            pytest.skip("the chain2 kernels are a variant build (make -C infercnv_amd/csrc chain2-variant)")
-        L = ct.CDLL(variant)
-    f = L.icnv_debug_chain2_plan
-    f.restype = ct.c_int
-    cs = np.ascontiguousarray(chr_start, dtype=np.int32)
-    n = f(cs.ctypes.data_as(ct.c_void_p), len(cs) - 1, int(G), int(T), None, 0, None)
-    if n <= 0:
-        return None, None
-    plan = np.zeros(n, dtype=np.uint32)
-    d = np.zeros(256)
-    assert f(cs.ctypes.data_as(ct.c_void_p), len(cs) - 1, int(G), int(T), plan.ctypes.data_as(ct.c_void_p), n,
-             d.ctypes.data_as(ct.c_void_p)) == n
-    return plan, d
-
-
-def _chain2_emulate_smoothing(plan, dct, x, T=50):
-    """What chain2_kernel does to one cell between step 9 and step 11, driven by the plan image alone: zero runs, slot
-    writes (core + halo) into a wave-private window, chunk sums / first moments, window state at the chunk start, the
-    sliding pyramid, 1 / denominator through the dictionary, read-back of the core slots.  Everything the plan does not
-    initialise is NaN here: a NaN in the result means a core output depends on a position the plan forgot."""
-    NW, NSB, Lc, WIN, NCS, HDR = 8, 2, 13, 832, 6, 28
-    PAD = (T + 3) & ~1
-    V0, STRAD, V1 = 0x400, 0x800, 0x1000
-    G = x.size
-    hdr = plan[:16 * HDR].view(np.int32).reshape(16, HDR)
-    lanew = plan[16 * HDR:16 * HDR + 16 * 64 * 8].reshape(16, 64, 8)
-    vm = plan[16 * HDR + 16 * 64 * 8:].reshape(8, 64)
-    out = np.full(G, np.nan)
-    lanes = np.arange(64)
-    O = 64                                                   # guard either side of the emulated window
-    for w in range(NW):
-        win = np.full(WIN + 2 * O, np.nan)
-        for sb in range(NSB):
-            k = NSB * w + sb
-            cg, cgn, nz = (int(v) for v in hdr[k, :3])
-            for z in range(nz):
-                zs, zl = int(hdr[k, 4 + 2 * z]), int(hdr[k, 5 + 2 * z])
-                assert 0 < zl <= 64 and zs >= 0 and zs + zl <= WIN
-                win[O + zs:O + zs + zl] = 0.0
-            for s in range(NCS + 1):
-                for lane in range(64):
-                    if s < NCS:
-                        g = min(cg + 2 * (64 * s + lane), G - 2)
-                        code = (int(lanew[k, lane, s >> 1]) >> (16 * (s & 1))) & 0xFFFF
-                    else:
-                        hp = cg // 2 - 32 + lane if lane < 32 else cgn // 2 + lane - 32
-                        g = 2 * min(max(hp, 0), G // 2 - 1)
-                        code = int(lanew[k, lane, 3])
-                    wi0 = code & 0x3FF
-                    if code & V0:
-                        win[O + wi0] = x[g]
-                    if code & V1:
-                        win[O + wi0 + 1 + (PAD if code & STRAD else 0)] = x[g + 1]
-                    assert s == NCS or bool(code & V0) == bool(code & V1)        # core pairs: both elements or none
-            p0 = O + Lc * lanes
-            xs = np.stack([win[p0 + q] for q in range(Lc)], axis=1)              # (64, 13)
-            S = np.zeros(64)
-            M = np.zeros(64)
-            for q in range(Lc):
-                S = S + xs[:, q]
-                M = q * xs[:, q] + M
-            csS = np.full(64 + 8, np.nan)
-            csM = np.full(64 + 8, np.nan)
-            csS[4:68], csM[4:68] = S, M
-            A = (T + 1) * S - M
-            Lb = xs[:, 0].copy()
-            Rb = S - xs[:, 0]
-            NL, NR = (T + Lc - 1) // Lc, (T + 1) // Lc
-            for i in range(1, NL + 1):
-                A = A + ((T + 1 - i * Lc) * csS[4 + lanes - i] + csM[4 + lanes - i])
-                Lb = Lb + csS[4 + lanes - i]
-                for q in range(Lc):
-                    d = i * Lc - q
-                    if d > T:
-                        xv = win[p0 - i * Lc + q]
-                        Lb = Lb - xv
-                        if d > T + 1:
-                            A = (d - T - 1) * xv + A
-            for i in range(1, NR + 1):
-                A = A + ((T + 1 - i * Lc) * csS[4 + lanes + i] - csM[4 + lanes + i])
-                Rb = Rb + csS[4 + lanes + i]
-                for q in range(Lc):
-                    d = i * Lc + q
-                    if d > T + 1:
-                        xv = win[p0 + i * Lc + q]
-                        Rb = Rb - xv
-                        A = (d - T - 1) * xv + A
-            for d in range((NR + 1) * Lc, T + 2):
-                xv = win[p0 + d]
-                Rb = Rb + xv
-                A = (T + 1 - d) * xv + A
-            r = np.zeros((64, Lc))
-            with np.errstate(invalid="ignore"):
-                for q in range(Lc):
-                    p = p0 + q
-                    codes = (lanew[k, :, 4 + (q >> 2)] >> (8 * (q & 3))) & 255
-                    r[:, q] = A * dct[codes]
-                    x1, xr, xl = win[p + 1], win[p + T + 2], win[p - T]
-                    A = A + (Rb - Lb)
-                    Rb = Rb + (xr - x1)
-                    Lb = Lb + (x1 - xl)
-            for q in range(Lc):
-                win[p0 + q] = r[:, q]
-            for s in range(NCS):
-                for lane in range(64):
-                    if not (int(vm[w, lane]) >> (sb * NCS + s)) & 1:
-                        continue
-                    g = cg + 2 * (64 * s + lane)
-                    code = (int(lanew[k, lane, s >> 1]) >> (16 * (s & 1))) & 0xFFFF
-                    wi0 = code & 0x3FF
-                    assert g + 1 < cgn and np.isnan(out[g]) and (code & V0)
-                    out[g] = win[O + wi0]
-                    out[g + 1] = win[O + wi0 + 1 + (PAD if code & STRAD else 0)]
-    return out
-
-
-@pytest.mark.parametrize("layout", ["bench", "odd_starts", "short_chromosomes", "one_chromosome", "tail"])
-def test_chain2_plan_emulated_smoothing_equals_oracle(layout, monkeypatch):
-    """The host side of the two-cells-per-CU chain kernels (csrc/chain2.hip): the sub-block plan -- core gene ranges,
-    window positions of every loaded pair, halo pairs, zero runs, dictionary codes -- drives a NumPy emulation of the
-    kernel's data movement and arithmetic; the result must be the oracle's pyramid smoothing for every gene
-    (R/inferCNV_ops.R:2406-2532), on layouts with odd chromosome starts (pairs straddling a boundary), chromosomes shorter
-    than the window, a single chromosome, and layouts the plan must refuse."""
-    import oracle_np as onp
-    from infercnv_amd import synth
-    monkeypatch.setenv("ICNV_CHAIN2", "1")                  # the kernels are opt-in (slower than the product kernel); so is their plan
-    rng = np.random.default_rng(len(layout))
-    if layout == "bench":
-        G = 10000
-        cs = synth.chr_layout(G)
-    elif layout == "odd_starts":
-        G = 9000
-        cs = np.array([0, 1071, 1778, 2385, 2736, 3215, 3749, 4262, 4617, 5026, 5455, 6065, 6622, 6809, 7161, 7478, 7929, 8557, 8705, G])
-    elif layout == "short_chromosomes":
-        G = 6000
-        cuts = np.sort(rng.choice(np.arange(1, G), size=40, replace=False))
-        cs = np.concatenate([[0], cuts, [G]])
-        cs[3] = cs[2] + 1                                   # a single-gene chromosome
-        cs[7] = cs[6] + 37                                  # shorter than the half window
-        cs = np.unique(cs)
-    elif layout == "one_chromosome":
-        G = 4096
-        cs = np.array([0, G])
-    else:
-        G = 2 * 5301                                        # 16 x 728 core positions do not hold 10 602 genes + padding
-        cs = synth.chr_layout(G)
-    plan, dct = _chain2_plan(cs, G)
-    if layout == "tail":
-        assert plan is None
-        assert _chain2_plan(synth.chr_layout(9999), 9999)[0] is None      # odd G
-        assert _chain2_plan(synth.chr_layout(10000), 10000, T=30)[0] is None
-        return
-    assert plan is not None
-    x = rng.normal(size=G) * np.exp(rng.normal(size=G))
-    got = _chain2_emulate_smoothing(plan, dct, x)
-    chr_codes = np.repeat(np.arange(len(cs) - 1), np.diff(cs))
-    want = onp.smooth_by_chromosome(x[:, None], chr_codes, 101)[:, 0]
-    assert not np.isnan(got).any(), np.nonzero(np.isnan(got))[0][:10]
-    assert np.abs(got - want).max() < 1e-12 * max(1.0, np.abs(want).max())
-
-
 WORKER_GROUPS = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
