@@ -411,11 +411,12 @@ def run_group_config(args, world, rank):
         what = "i3 HMM at subcluster level (R/inferCNV_i3HMM.R:249-308): i3 mu / sigma over the reference values (2 all-reduces of 2 doubles), group means, Viterbi per subcluster, broadcast"
         alg = 9 * G * C_local          # read every value once (group means), write one state byte per gene*cell
     else:
-        del pre
         mf = sharded.ShardedMedianFilter()
         result = [None]
         def step():
             result[0] = mf.run(out, chr_start, local, 7)
+        def step_no_ties():      # the same filter on the matrix BEFORE step 22: no value repeats, no window has a majority value
+            result[0] = mf.run(pre, chr_start, local, 7)
         names = ("median_filter",)
         what = "apply_median_filtering, window_size 7 (9 x 9 windows clamped at tile x chromosome edges; R/noise_reduction.R:43-113), tiles = subclusters x chromosomes, no collective"
         alg = 2 * 8 * G * C_local
@@ -437,6 +438,17 @@ def run_group_config(args, world, rank):
     fence()
     elapsed = time.perf_counter() - t0
     device.timing_enable(False)
+    no_ties_ms = None
+    if args.config == 5:
+        step_no_ties()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step_no_ties()
+        fence()
+        no_ties_ms = (time.perf_counter() - t1) / 3 * 1e3
+        step()                                  # (the checksum below is of the step's own output)
+        fence()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     cells = torch.tensor([float(C_local)], dtype=torch.float64, device="cuda")
     csum = torch.tensor([float(result[0].sum(dtype=torch.float64))], dtype=torch.float64, device="cuda")
@@ -473,6 +485,11 @@ def run_group_config(args, world, rank):
                             "algorithmic_bytes_per_step": alg, "kernel_ms_per_step": ksum,
                             "note": "all kernels of the step together (group means / Viterbi / broadcast, or the interior and edge median kernels)"},
                "kernels": kernels, "cpu_baseline": None,
+               **({"no_ties_input": {"ms_per_step": no_ties_ms, "frac": alg / (no_ties_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "what": "the same filter over the matrix BEFORE step 22 (no repeated values: no window has a majority value, "
+                                             "every output runs its selection network) -- the data-independent floor of the kernels; the timed step "
+                                             "runs on the denoised matrix, as BASELINE config 5 and apply_median_filtering's use specify, where "
+                                             "the majority shortcut decides most windows"}} if no_ties_ms else {}),
                "checksums": {"per_rank": checks, "meaning": "sum of the step's output (states, or the filtered matrix) over the rank's cells"}}
         print(json.dumps(res))
 

@@ -116,10 +116,21 @@ __global__ void __launch_bounds__(MF_TG *MF_TC) median_filter_kernel(
 }
 
 
+// Majority shortcut (exact, data-dependent).  A window in which one value occupies more than half of the positions has that
+// value as its median, whatever the rest is.  That is the common case on the matrix this filter is made for:
+// apply_median_filtering runs on the DENOISED matrix, where clear_noise_via_ref_mean_sd (R/inferCNV_ops.R:2302-2346) has set
+// every entry inside the noise band -- typically 80-90 % of them -- to one and the same value mu.  The kernels count, per
+// output, the window positions equal to a candidate value (row masks of the patch through ballots / LDS atomics, one
+// popcount per window row); an output whose count exceeds half its window takes the candidate, a wavefront whose outputs all
+// do skips its networks, a patch whose outputs all do skips the column sorts as well.  Any candidate is correct (the test is
+// exact); a good one is the last value that won, re-seeded from the patch itself when it fails.
+//
 // One patch of the 9 x 9 interior kernel: stage A (column sorts into LDS), then the outputs of thread (tx, ty).  The
 // patch holds interior outputs only: genes [g0, gend) with gend <= xdim - 4, cells [c0, cend) with c0 >= 4, cend <= ydim - 4.
+// `majA` / `majB`: this thread's outputs are decided by the majority value `vmaj`; `wave_skip`: so are all outputs of its wavefront.
 __device__ inline void median9_patch(int cs, int g0, int gend, int c0, int cend, const int32_t *rows /* LDS: cell of patch row r */,
-                                     int tx, int ty, const double *patch, double *sortedc, double *__restrict__ out, int G) {
+                                     int tx, int ty, const double *patch, double *sortedc, double *__restrict__ out, int G,
+                                     bool majA, bool majB, bool wave_skip, double vmaj) {
     constexpr int h = 4;
     constexpr int PW = MF_TG + 2 * h;
     constexpr int PH = MF9_TC + 2 * h;
@@ -135,9 +146,14 @@ __device__ inline void median9_patch(int cs, int g0, int gend, int c0, int cend,
     }
     __syncthreads();
     const int gx = g0 + tx;
-    if (gx >= gend) return;
     const int r0 = 2 * ty;                       // patch row of the first column of output A's window
     const int cyA = c0 + r0, cyB = cyA + 1;
+    if (wave_skip) {                             // (wave-uniform) every output of this wavefront is its window's majority value
+        if (gx < gend && cyA < cend) out[(int64_t)rows[r0 + 4] * G + cs + gx] = vmaj;
+        if (gx < gend && cyB < cend) out[(int64_t)rows[r0 + 5] * G + cs + gx] = vmaj;
+        return;
+    }
+    if (gx >= gend) return;
     if (cyA >= cend) return;
     if (cyB < cend) {
         double w[10];
@@ -152,10 +168,12 @@ __device__ inline void median9_patch(int cs, int g0, int gend, int c0, int cend,
         double p[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) p[k] = sortedc[(r0 * MF_TG + tx) * 9 + k];
-        out[(int64_t)rows[r0 + 4] * G + cs + gx] = median_window_finish(w, p);
+        const double mA = median_window_finish(w, p);
+        out[(int64_t)rows[r0 + 4] * G + cs + gx] = majA ? vmaj : mA;
 #pragma unroll
         for (int k = 0; k < 9; ++k) p[k] = sortedc[((r0 + 9) * MF_TG + tx) * 9 + k];
-        out[(int64_t)rows[r0 + 5] * G + cs + gx] = median_window_finish(w, p);
+        const double mB = median_window_finish(w, p);
+        out[(int64_t)rows[r0 + 5] * G + cs + gx] = majB ? vmaj : mB;
         return;
     }
     // the last interior cell of a tile with an odd number of them: the single-output network over its nine columns
@@ -166,6 +184,9 @@ __device__ inline void median9_patch(int cs, int g0, int gend, int c0, int cend,
         for (int k = 0; k < 9; ++k) a[9 * c + k] = sortedc[((r0 + c) * MF_TG + tx) * 9 + k];
     out[(int64_t)rows[r0 + 4] * G + cs + gx] = median81_sorted_columns(a);
 }
+
+// The value held by at least two of three probes (else the first): a cheap guess at a patch's most common value.
+__device__ inline double majority_of_three(double a, double b, double c) { return (b == c) ? b : a; }
 
 // Border outputs of the 9 x 9 filter (clamped windows, m < 81 values; R/noise_reduction.R:101-106), one per thread,
 // no interior outputs in the workgroup: the missing positions are padded with n_lo x -inf and +inf so that the wanted
@@ -222,6 +243,27 @@ __global__ void __launch_bounds__(256, 2) median_filter9_edge_kernel(const doubl
     } else {
         sx = 1; sy = 40;
         base = ((cy < 4 || ydim < 9) ? 0 : (16 - ydim) * 40) - (b0 - 4);
+    }
+    {   // majority shortcut (see above): a value on more than half of the window's m positions is its median (for an even m both
+        // middle values are that value); a wavefront whose outputs are all decided this way skips its networks
+        const double vc = mode == 0 ? majority_of_three(ep[8 * 17 + 2], ep[20 * 17 + 10], ep[30 * 17 + 5])
+                                    : majority_of_three(ep[2 * 40 + 10], ep[5 * 40 + 20], ep[12 * 40 + 30]);
+        int cnt = 0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            const int yy = cy - 4 + c;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int xx = g - 4 + k;
+                const bool in_win = yy >= ya && yy <= yb && xx >= xa && xx <= xb;
+                cnt += (in_win && ep[in_win ? base + yy * sy + xx * sx : 0] == vc) ? 1 : 0;
+            }
+        }
+        const bool maj = 2 * cnt > m;
+        if (__ballot(!maj) == 0ull) {
+            out[(int64_t)idx[cy] * G + cs + g] = vc;
+            return;
+        }
     }
     int npad = 0;
     double a[81];
@@ -290,6 +332,10 @@ __global__ void __launch_bounds__(MF_TG *MF_TC, 2) median_filter9_kernel(
     // parks its values and writes the row table of the patch after it while the slowest wavefront still reads the
     // current ones, so a patch costs two barriers (patch parked | columns sorted) instead of three.
     int32_t *rowbuf = reinterpret_cast<int32_t *>(sortedc + PH * MF_TG * 9);   // [3][PH]
+    // majority shortcut: per patch buffer, one 64-bit mask per patch row (bit g: the value at gene g of the row equals the
+    // candidate) and a word of flags (bit 0: some output needs its network, bit 1: some output took the candidate)
+    unsigned long long *rowmask = reinterpret_cast<unsigned long long *>(rowbuf + 3 * PH + (PH & 1));   // [2][PH], 8-byte aligned
+    unsigned int *mflag = reinterpret_cast<unsigned int *>(rowmask + 2 * PH);                            // [2]
     auto load_rows = [&](const Where &w) -> int32_t {
         const int cy = w.c0 - h + (int)threadIdx.x;
         return ((int)threadIdx.x < PH && cy >= 0 && cy < w.ydim) ? w.idx[cy] : 0;
@@ -318,8 +364,13 @@ __global__ void __launch_bounds__(MF_TG *MF_TC, 2) median_filter9_kernel(
     desc(pid, gd, cd);
     Where cur = where(gd, cd);
     if ((int)threadIdx.x < PH) rowbuf[threadIdx.x] = load_rows(cur);
+    if ((int)threadIdx.x < 2 * PH) rowmask[threadIdx.x] = 0ull;
+    if ((int)threadIdx.x < 2) mflag[threadIdx.x] = 0u;
     __syncthreads();
     gather(cur, rowbuf);
+    // first candidate: an element from the middle of the first patch (wave-uniform address); re-seeded below when it fails
+    double vguess = in[(int64_t)rowbuf[PH / 2] * G + cur.cs + cur.g0];
+    const int lane = threadIdx.x & 63;
     Where nxt = cur;                 // patch pid + step
     int32_t nxt_row = 0;             // its row table entry of this thread
     int4 gd2 = gd, cd2 = cd;         // descriptors of patch pid + 2 step
@@ -334,13 +385,28 @@ __global__ void __launch_bounds__(MF_TG *MF_TC, 2) median_filter9_kernel(
         const bool more = pid + step < n_patches;
         double *patch = patch2 + (it & 1) * (PW * PH);
         const int rb = it % 3, rb_next = (it + 1) % 3;
+        unsigned long long *rmask = rowmask + (it & 1) * PH;
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
             const int e = (int)threadIdx.x + q * NT;
             if (e < PW * PH) patch[e] = stage[q];
+            // which of the wavefront's 64 consecutive patch elements equal the candidate: one ballot, then at most three
+            // lanes add the bits of the (up to three) patch rows those elements lie in to the rows' masks
+            const unsigned long long m = __ballot(stage[q] == vguess);
+            const int e0 = ((int)threadIdx.x & ~63) + q * NT;
+            const int r = e0 / PW + lane;
+            if (lane < 3 && r < PH) {
+                const int lo = r * PW - e0;                  // element (relative to e0) that sits at gene 0 of row r
+                unsigned long long bits = lo >= 64 ? 0ull : (lo >= 0 ? (m >> lo) : (m << (-lo)));
+                bits &= (1ull << PW) - 1ull;
+                if (bits) atomicOr(&rmask[r], bits);
+            }
         }
         if (more && (int)threadIdx.x < PH) rowbuf[rb_next * PH + threadIdx.x] = nxt_row;
         __syncthreads();   // also: every wavefront is done with the previous patch's sorted columns
+        // the other buffer's masks and flags (the previous patch's: everybody is past them) are cleared for the patch after next
+        if ((int)threadIdx.x < PH) rowmask[((it + 1) & 1) * PH + threadIdx.x] = 0ull;
+        if (threadIdx.x == 0) mflag[(it + 1) & 1] = 0u;
         const Where w = cur;
         if (more) {
             cur = nxt;
@@ -351,7 +417,36 @@ __global__ void __launch_bounds__(MF_TG *MF_TC, 2) median_filter9_kernel(
                 if (pid + 3 * step < n_patches) desc(pid + 3 * step, gd2, cd2);
             }
         }
-        median9_patch(w.cs, w.g0, w.gend, w.c0, w.cend, rowbuf + rb * PH, tx, ty, patch, sortedc, out, G);
+        // majority shortcut: positions equal to the candidate in the windows of this thread's two outputs
+        bool majA, majB;
+        {
+            const int r0 = 2 * ty;
+            int hsum = 0, h0 = 0, h9 = 0;
+#pragma unroll
+            for (int c = 0; c < 10; ++c) {
+                const unsigned int hc = __builtin_popcount((unsigned int)(rmask[r0 + c] >> tx) & 0x1FFu);
+                if (c == 0) h0 = (int)hc;
+                if (c == 9) h9 = (int)hc; else hsum += (int)hc;
+            }
+            majA = hsum >= 41;
+            majB = hsum - h0 + h9 >= 41;
+        }
+        const bool actA = w.g0 + tx < w.gend && w.c0 + 2 * ty < w.cend, actB = actA && w.c0 + 2 * ty + 1 < w.cend;
+        const bool wave_net = __ballot((actA && !majA) || (actB && !majB)) != 0ull;       // some output of this wavefront needs its network
+        const bool wave_maj = __ballot((actA && majA) || (actB && majB)) != 0ull;
+        if (lane == 0 && (wave_net || wave_maj)) atomicOr(&mflag[it & 1], (wave_net ? 1u : 0u) | (wave_maj ? 2u : 0u));
+        __syncthreads();
+        const unsigned int fl = mflag[it & 1];
+        if (fl & 1u) {
+            median9_patch(w.cs, w.g0, w.gend, w.c0, w.cend, rowbuf + rb * PH, tx, ty, patch, sortedc, out, G, majA, majB, !wave_net, vguess);
+            // a candidate that decided nothing in a whole patch is replaced by the value two of three probes of this patch agree on
+            if (!(fl & 2u)) vguess = majority_of_three(patch[6 * PW + 10], patch[12 * PW + 20], patch[18 * PW + 30]);
+        } else {
+            // every output of the patch is its window's majority value: no column sorts, no networks
+            const int32_t *rows = rowbuf + rb * PH;
+            if (actA) out[(int64_t)rows[2 * ty + 4] * G + w.cs + w.g0 + tx] = vguess;
+            if (actB) out[(int64_t)rows[2 * ty + 5] * G + w.cs + w.g0 + tx] = vguess;
+        }
     }
 }
 
@@ -371,7 +466,8 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
         const int64_t n_patches = (int64_t)plan9.n_gene_blocks * plan9.n_cell_patches;
         if (n_patches > 0) {
             const size_t lds = ((size_t)2 * (MF_TG + 8) * (MF9_TC + 8) + (size_t)(MF9_TC + 8) * MF_TG * 9) * sizeof(double) +
-                               3 * (MF9_TC + 8) * sizeof(int32_t);
+                               (3 * (MF9_TC + 8) + ((MF9_TC + 8) & 1)) * sizeof(int32_t) +
+                               2 * (MF9_TC + 8) * sizeof(unsigned long long) + 2 * sizeof(unsigned int);   // + row masks and flags of the majority shortcut
             static DeviceOnce once;
             if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(median_filter9_kernel), 80 * 1024, once)) return rc;
             int64_t grid = (int64_t)num_cus() * 2;   // two resident workgroups per CU (70 KB of LDS, 256 registers)

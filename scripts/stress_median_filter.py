@@ -21,6 +21,8 @@ for seed in range(first, first + n):
     x = rng.normal(size=(G, C))
     if seed % 3 == 0: x = np.round(x, 1)                      # many ties
     if seed % 5 == 0: x[rng.random((G, C)) < 0.5] = 0.0       # half zeros
+    if seed % 4 == 1: x[rng.random((G, C)) < rng.uniform(0.3, 0.98)] = 1.012490474117089   # one dominant value (the majority shortcut)
+    if seed % 8 == 3: x[:, : C // 2][rng.random((G, C // 2)) < 0.85] = -2.5                  # ... a second one in half of the cells
     perm = rng.permutation(C)
     off = np.concatenate([[0], np.cumsum(tsz)])
     tiles = [perm[off[i]:off[i + 1]].astype(np.int32) for i in range(len(tsz))]

@@ -17,6 +17,14 @@ __global__ void k(double *out, int iters, double seed) {
             if (OP == 3) asm volatile("v_add_f64 %0, %0, %1" : "+v"(a[i]) : "v"(b));
             if (OP == 4) asm volatile("v_cmp_lt_f64 vcc, %0, %1" : "+v"(a[i]) : "v"(b) : "vcc");
             if (OP == 5) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 6) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(*reinterpret_cast<unsigned *>(&a[i])) : "v"(*reinterpret_cast<unsigned *>(&b)));
+            if (OP == 7) asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(*reinterpret_cast<unsigned *>(&a[i])) : "v"(*reinterpret_cast<unsigned *>(&b)));
+            if (OP == 8) asm volatile("v_min_u32 %0, %0, %1" : "+v"(*reinterpret_cast<unsigned *>(&a[i])) : "v"(*reinterpret_cast<unsigned *>(&b)));
+            if (OP == 9) asm volatile("v_max_u32 %0, %0, %1" : "+v"(*reinterpret_cast<unsigned *>(&a[i])) : "v"(*reinterpret_cast<unsigned *>(&b)));
+            if (OP == 10) asm volatile("v_cmp_lt_u64 vcc, %0, %1" : "+v"(a[i]) : "v"(b) : "vcc");
+            if (OP == 11) asm volatile("v_pk_min_i16 %0, %0, %1" : "+v"(*reinterpret_cast<unsigned *>(&a[i])) : "v"(*reinterpret_cast<unsigned *>(&b)));
+            if (OP == 12) asm volatile("v_min3_u32 %0, %0, %1, %1" : "+v"(*reinterpret_cast<unsigned *>(&a[i])) : "v"(*reinterpret_cast<unsigned *>(&b)));
+            if (OP == 13) asm volatile("v_med3_u32 %0, %0, %1, %1" : "+v"(*reinterpret_cast<unsigned *>(&a[i])) : "v"(*reinterpret_cast<unsigned *>(&b)));
         }
     }
     double s = 0;
@@ -49,5 +57,13 @@ int main() {
     run<3>("v_add_f64", d, 1);
     run<5>("v_mul_f64", d, 1);
     run<4>("v_cmp_lt_f64", d, 1);
+    run<6>("v_pk_min_u16", d, 1);
+    run<7>("v_pk_max_u16", d, 1);
+    run<11>("v_pk_min_i16", d, 1);
+    run<8>("v_min_u32", d, 1);
+    run<9>("v_max_u32", d, 1);
+    run<12>("v_min3_u32", d, 1);
+    run<13>("v_med3_u32", d, 1);
+    run<10>("v_cmp_lt_u64", d, 1);
     return 0;
 }

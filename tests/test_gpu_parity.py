@@ -730,6 +730,56 @@ def test_median_filter_block_boundaries(dev):
     np.testing.assert_array_equal(to_host(out2), oc.median_filter(x, cs, tiles_all, 7))
 
 
+@pytest.mark.parametrize("case", ["share_0.3", "share_0.55", "share_0.9", "two_values", "runs_along_genes", "negative_zero", "nan_candidate"])
+def test_median_filter_majority_shortcut_is_exact(dev, case):
+    """The majority shortcut of the 9 x 9 kernels (a value on more than half of a window's positions is its median: the
+    denoised matrix holds one value mu at most of its entries, R/inferCNV_ops.R:2335) must change nothing: matrices with a
+    dominant value at shares below, around and far above one half, two dominant values in two halves of the cells (the
+    candidate has to be re-seeded), dominant runs along the genes (whole patches decided, whole patches not), borders and
+    even window counts included -- exact against the oracle, many workgroups deep (persistent workgroups carry the candidate
+    from patch to patch)."""
+    rng = np.random.default_rng(len(case))
+    sizes = [150, 9, 61, 330, 8, 40, 75]
+    G = sum(sizes)
+    cs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    tile_sizes = [96, 41, 9, 8, 130, 57]
+    C = sum(tile_sizes)
+    x = rng.normal(1.0, 0.2, size=(G, C))
+    mu = 1.0124904741170890
+    if case.startswith("share_"):
+        x[rng.random((G, C)) < float(case.split("_")[1])] = mu
+    elif case == "two_values":
+        m = rng.random((G, C)) < 0.8
+        x[:, : C // 2][m[:, : C // 2]] = mu
+        x[:, C // 2:][m[:, C // 2:]] = -0.25
+    elif case == "runs_along_genes":
+        for c in range(C):                                  # per cell: long stretches of mu, interrupted by continuous stretches
+            g = 0
+            while g < G:
+                n = int(rng.integers(20, 200))
+                if rng.random() < 0.7:
+                    x[g:g + n, c] = mu
+                g += n
+    elif case == "negative_zero":
+        x[rng.random((G, C)) < 0.45] = 0.0
+        x[rng.random((G, C)) < 0.45] = -0.0                 # +0.0 and -0.0 are ONE value for the comparison and for the median
+    else:
+        x[rng.random((G, C)) < 0.8] = mu
+        x[75, :] = np.nan                                   # a probe position may hold a NaN: it never equals anything
+    perm = rng.permutation(C)
+    off = np.concatenate([[0], np.cumsum(tile_sizes)])
+    tiles = [perm[off[i]:off[i + 1]] for i in range(len(tile_sizes))]
+    if case == "two_values":                                # tiles that stay inside one half, so that whole workgroups see one value
+        left, right = np.arange(C // 2), np.arange(C // 2, C)
+        tiles = [left[:100], left[100:], right[:77], right[77:]]
+    if case == "nan_candidate":
+        x[75, :] = 7.0                                      # (the oracle has no NaN policy for the filter: keep the data finite ...)
+        x[75, ::2] = mu
+    out = dev.median_filter(to_dev(x), cs, tiles, 7)
+    want = oc.median_filter(x, cs, tiles, 7)
+    np.testing.assert_array_equal(to_host(out), want)
+
+
 # ------------------------------------------------------------------ host mirror == device path == oracle
 def test_host_mirror_runs_reference_workflow(dev, example):
     from infercnv_amd import GeneOrder, InfercnvObject, hmm, noise_reduction, ops
