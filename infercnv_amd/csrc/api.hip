@@ -1649,53 +1649,56 @@ int icnv_median_filter_dev(const double *expr_in, double *expr_out, int64_t G, i
     std::vector<int32_t> blk_off((size_t)n_tiles + 1, 0);
     for (int t = 0; t < n_tiles; ++t)
         blk_off[t + 1] = blk_off[t] + (tile_off[t + 1] - tile_off[t] + MEDIAN_CELLS_PER_PATCH - 1) / MEDIAN_CELLS_PER_PATCH;
-    // 9 x 9 windows: interior outputs (gene and cell at least four from either end of their chromosome / tile) in
-    // patches of 32 genes x 16 cells, border outputs as items of 256 for the edge kernel (mode 0: the border genes of
-    // a chromosome x 32 cells of a tile; mode 1: the border cells of a tile x 32 interior genes)
-    std::vector<int32_t> gdesc, cdesc, edesc;
+    // 9 x 9 windows (median_kernels.hip: a classification pass, a dense pass over the tiles that need one, single outputs).
+    // Kernel 1 cuts every (cell tile, chromosome) block into tiles of 56 genes x 32 cells from its first gene / cell, borders
+    // included; the dense pass has its own grid of 32 genes x 16 cells over the same blocks (a tile of kernel 1 covers two of
+    // its cell blocks exactly and two or three of its gene blocks).
+    std::vector<int32_t> gdesc, cdesc, g1desc, c1desc;
     if (median_is_9x9(window_size)) {
         for (int k = 0; k < n_chr; ++k) {
             const int32_t cs = chr_start[k], xdim = chr_start[k + 1] - chr_start[k];
-            for (int g0 = 4; g0 < xdim - 4; g0 += MEDIAN_GENES_PER_PATCH) {
-                const int32_t r[4] = {cs, xdim, g0, xdim - 4};
+            const int32_t kb2 = (int32_t)(gdesc.size() / 4);   // the chromosome's first dense-pass gene block
+            for (int g0 = 0; g0 < xdim; g0 += MEDIAN_GENES_PER_PATCH) {   // dense pass: {cs, xdim, first gene, end of its interior outputs}
+                const int32_t r[4] = {cs, xdim, g0, std::min(g0 + MEDIAN_GENES_PER_PATCH, xdim - 4)};
                 gdesc.insert(gdesc.end(), r, r + 4);
+            }
+            for (int g0 = 0; g0 < xdim; g0 += MEDIAN9_K1_GENES) {
+                const int32_t r1[4] = {cs, xdim, g0, kb2};
+                g1desc.insert(g1desc.end(), r1, r1 + 4);
             }
         }
         for (int t = 0; t < n_tiles; ++t) {
             const int32_t ydim = tile_off[t + 1] - tile_off[t];
-            for (int c0 = 4; c0 < ydim - 4; c0 += MEDIAN9_CELLS_PER_PATCH) {
-                const int32_t r[4] = {tile_off[t], ydim, c0, ydim - 4};
-                cdesc.insert(cdesc.end(), r, r + 4);
-            }
-            for (int k = 0; k < n_chr; ++k) {
-                const int32_t cs = chr_start[k], xdim = chr_start[k + 1] - chr_start[k];
-                if (xdim < 1 || ydim < 1) continue;
-                for (int b0 = 0; b0 < ydim; b0 += 32) {
-                    const int32_t r[8] = {0, cs, xdim, tile_off[t], ydim, b0, 0, 0};
-                    edesc.insert(edesc.end(), r, r + 8);
-                }
-                for (int b0 = 4; b0 < xdim - 4; b0 += 32) {
-                    const int32_t r[8] = {1, cs, xdim, tile_off[t], ydim, b0, 0, 0};
-                    edesc.insert(edesc.end(), r, r + 8);
+            for (int c0 = 0; c0 < ydim; c0 += MEDIAN9_K1_CELLS) {
+                const int32_t r1[4] = {tile_off[t], ydim, c0, (int32_t)(cdesc.size() / 4)};
+                c1desc.insert(c1desc.end(), r1, r1 + 4);
+                for (int half = 0; half < 2; ++half) {
+                    const int32_t r[4] = {tile_off[t], ydim, c0 + half * MEDIAN9_CELLS_PER_PATCH, 0};
+                    cdesc.insert(cdesc.end(), r, r + 4);
                 }
             }
         }
     }
-    DevBuf d_chr, d_idx, d_off, d_blk, d_gd, d_cd, d_ed;
+    DevBuf d_chr, d_idx, d_off, d_blk, d_gd, d_cd, d_g1, d_c1;
     if (!gdesc.empty() && (rc = upload(d_gd, gdesc.data(), gdesc.size(), s))) return rc;
     if (!cdesc.empty() && (rc = upload(d_cd, cdesc.data(), cdesc.size(), s))) return rc;
-    if (!edesc.empty() && (rc = upload(d_ed, edesc.data(), edesc.size(), s))) return rc;
+    if (!g1desc.empty() && (rc = upload(d_g1, g1desc.data(), g1desc.size(), s))) return rc;
+    if (!c1desc.empty() && (rc = upload(d_c1, c1desc.data(), c1desc.size(), s))) return rc;
     if ((rc = upload(d_chr, chr_start, (size_t)n_chr + 1, s))) return rc;
     if ((rc = upload(d_idx, tile_idx, (size_t)tile_off[n_tiles], s))) return rc;
     if ((rc = upload(d_off, tile_off, (size_t)n_tiles + 1, s))) return rc;
     if ((rc = upload(d_blk, blk_off.data(), blk_off.size(), s))) return rc;
     Median9Plan plan9;
+    DevBuf d_queue;
+    plan9.queue = &d_queue;
     plan9.gene_block_desc = d_gd.as<int32_t>();
     plan9.cell_patch_desc = d_cd.as<int32_t>();
-    plan9.edge_desc = d_ed.as<int32_t>();
     plan9.n_gene_blocks = (int32_t)(gdesc.size() / 4);
     plan9.n_cell_patches = (int32_t)(cdesc.size() / 4);
-    plan9.n_edge_items = (int32_t)(edesc.size() / 8);
+    plan9.gene1_desc = d_g1.as<int32_t>();
+    plan9.cell1_desc = d_c1.as<int32_t>();
+    plan9.n_gene_blocks1 = (int32_t)(g1desc.size() / 4);
+    plan9.n_cell_patches1 = (int32_t)(c1desc.size() / 4);
     return launch_median_filter(expr_in, expr_out, (int32_t)G, C, d_chr.as<int32_t>(), n_chr, d_idx.as<int32_t>(),
                                 d_off.as<int32_t>(), n_tiles, d_blk.as<int32_t>(), chr_start, blk_off[n_tiles],
                                 window_size, plan9, s);

@@ -240,13 +240,15 @@ int launch_cell_distances(const double *x, int32_t G, const int32_t *idx_dev, in
                           double *diag_dev, double *out, hipStream_t stream);
 
 // ---- median filter --------------------------------------------------------
-// The default window (9 x 9) runs on patch descriptors built by the host (api.hip): interior gene blocks / cell
-// patches for median_filter9_kernel, border items for median_filter9_edge_kernel; other windows use blk_off.
+// The default window (9 x 9) runs on tile descriptors built by the host (api.hip): kernel 1's tiles (56 genes x 32 cells of a
+// (cell tile, chromosome) block, borders included) and the 2 x 2 dense-pass tiles each of them covers; other windows use blk_off.
 struct Median9Plan {
-    const int32_t *gene_block_desc = nullptr;   // 4 ints per block: {chromosome's first gene, its length, block's first gene, xdim - 4}
-    const int32_t *cell_patch_desc = nullptr;   // 4 ints per patch: {offset of the tile's cells, tile length, patch's first cell, ydim - 4}
-    const int32_t *edge_desc = nullptr;         // 8 ints per item: {mode, cs, xdim, tile offset | ydim, b0, 0, 0}
-    int32_t n_gene_blocks = 0, n_cell_patches = 0, n_edge_items = 0;
+    const int32_t *gene_block_desc = nullptr;   // dense pass, 4 ints per gene block: {chromosome's first gene, its length, block's first gene, end of its interior outputs}
+    const int32_t *cell_patch_desc = nullptr;   // dense pass, 4 ints per cell block: {offset of the tile's cells, tile length, block's first cell, 0}
+    const int32_t *gene1_desc = nullptr;        // kernel 1, 4 ints: {chromosome's first gene, its length, tile's first gene, index of its first dense-pass gene block}
+    const int32_t *cell1_desc = nullptr;        // kernel 1, 4 ints: {offset of the tile's cells, tile length, tile's first cell, index of its first dense-pass cell block}
+    int32_t n_gene_blocks = 0, n_cell_patches = 0, n_gene_blocks1 = 0, n_cell_patches1 = 0;
+    DevBuf *queue = nullptr;                    // workspace of the three-kernel scheme's lists (allocated by the launch, owned by the caller)
 };
 int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, const int32_t *chr_start_dev,
                          int32_t n_chr, const int32_t *tile_idx_dev, const int32_t *tile_off_dev, int32_t n_tiles,
@@ -254,6 +256,7 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
                          int32_t window_size, const Median9Plan &plan9, hipStream_t stream);
 constexpr int MEDIAN_GENES_PER_PATCH = 32;
 constexpr int MEDIAN9_CELLS_PER_PATCH = 16;
+constexpr int MEDIAN9_K1_GENES = 56, MEDIAN9_K1_CELLS = 32;   // kernel 1's tile: with the halo one tile row is the 64 lanes of a wavefront
 inline bool median_is_9x9(int32_t window_size) { return (window_size - 1) / 2 + 1 == 4; }
 constexpr int MEDIAN_CELLS_PER_PATCH = 8;   // generic kernel
 

@@ -10,6 +10,10 @@
 //   other window sizes: median_filter_kernel -- every thread selects the median of its clamped window by a
 //     value-bounded quickselect (exact order statistics; even counts average the two middle values like
 //     stats::median).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 #include "icnv_internal.h"
 
 // v_min_f64 / v_max_f64 without the compiler's canonicalisation of operands that come straight from memory (one
@@ -116,21 +120,39 @@ __global__ void __launch_bounds__(MF_TG *MF_TC) median_filter_kernel(
 }
 
 
-// Majority shortcut (exact, data-dependent).  A window in which one value occupies more than half of the positions has that
-// value as its median, whatever the rest is.  That is the common case on the matrix this filter is made for:
-// apply_median_filtering runs on the DENOISED matrix, where clear_noise_via_ref_mean_sd (R/inferCNV_ops.R:2302-2346) has set
-// every entry inside the noise band -- typically 80-90 % of them -- to one and the same value mu.  The kernels count, per
-// output, the window positions equal to a candidate value (row masks of the patch through ballots / LDS atomics, one
-// popcount per window row); an output whose count exceeds half its window takes the candidate, a wavefront whose outputs all
-// do skips its networks, a patch whose outputs all do skips the column sorts as well.  Any candidate is correct (the test is
-// exact); a good one is the last value that won, re-seeded from the patch itself when it fails.
+// ---------------------------------------------------------------------------------------------------------------------
+// 9 x 9 windows (window_size 7, the default) in three launches.
 //
-// One patch of the 9 x 9 interior kernel: stage A (column sorts into LDS), then the outputs of thread (tx, ty).  The
-// patch holds interior outputs only: genes [g0, gend) with gend <= xdim - 4, cells [c0, cend) with c0 >= 4, cend <= ydim - 4.
-// `majA` / `majB`: this thread's outputs are decided by the majority value `vmaj`; `wave_skip`: so are all outputs of its wavefront.
+// Majority shortcut (exact, data-dependent).  A window in which one value occupies more than half of the positions has that
+// value as its median, whatever the rest is (for an even number of positions -- clamped border windows -- both middle values
+// are that value).  That is the common case on the matrix this filter is made for: apply_median_filtering runs on the
+// DENOISED matrix, where clear_noise_via_ref_mean_sd (R/inferCNV_ops.R:2302-2346) has set every entry inside the noise band
+// -- typically 80-90 % of them -- to one and the same value mu.
+//
+//   1. median9_classify_kernel  streams the matrix in tiles of 56 genes x 32 cells of one (tile, chromosome) block (borders
+//      included; 2 x 2 tiles of the dense pass each), counts per output the window positions BELOW and ABOVE a candidate value (row masks of the tile built from
+//      ballots, two popcounts per window row) and writes the candidate where fewer than half of the window's positions lie on
+//      either side of it -- then it IS the median: not only where it fills more than half of the window, also where the other
+//      values balance around it, which is what noise around mu does.  What is
+//      left undecided goes three ways: a tile with many undecided interior outputs is put on the DENSE list (its interior
+//      outputs are all recomputed by kernel 2); every other undecided output -- the few of a neutral region, and every
+//      undecided border output -- is queued as one record; a tile whose records do not fit the workgroup's queue segment is
+//      put on the SLOW list as a whole.  No LDS patch, ~40 registers: eight workgroups per CU keep enough loads in flight to
+//      run at memory speed.  Any candidate is correct (the test is exact); a good one is the last value that won, re-seeded
+//      from the tile when it decides nothing; a workgroup that meets no majority for eight tiles in a row stops loading for
+//      the next 120 (data without a dominant value: everything is marked for the dense pass or queued unseen).
+//   2. median_filter9_kernel    the dense pass over the tiles of the dense list: sorted columns shared through LDS, two
+//      outputs per thread that share eight of their nine columns, branch-free min/max networks (interior outputs only).
+//   3. median9_sparse_kernel    one queued output per lane (interior or border: clamped windows are padded with -inf / +inf so
+//      that the wanted order statistics sit at ranks 40 / 41 of 81), nine column sorts and the two-rank network straight
+//      from global memory (L2); also every output of the slow list's tiles.
+// All lists are per-workgroup segments of kernel 1's grid: no atomics, deterministic content.
+
+// One tile of the dense pass: stage A (column sorts into LDS), then the outputs of thread (tx, ty).  The patch covers genes
+// [g0 - 4, g0 + 36) and cells [c0 - 4, c0 + 20) of the block; outputs are the INTERIOR ones of the tile: genes
+// [max(g0, 4), gend) with gend <= xdim - 4, cells [max(c0, 4), cend) with cend <= ydim - 4.
 __device__ inline void median9_patch(int cs, int g0, int gend, int c0, int cend, const int32_t *rows /* LDS: cell of patch row r */,
-                                     int tx, int ty, const double *patch, double *sortedc, double *__restrict__ out, int G,
-                                     bool majA, bool majB, bool wave_skip, double vmaj) {
+                                     int tx, int ty, const double *patch, double *sortedc, double *__restrict__ out, int G) {
     constexpr int h = 4;
     constexpr int PW = MF_TG + 2 * h;
     constexpr int PH = MF9_TC + 2 * h;
@@ -146,16 +168,12 @@ __device__ inline void median9_patch(int cs, int g0, int gend, int c0, int cend,
     }
     __syncthreads();
     const int gx = g0 + tx;
+    if (gx < 4 || gx >= gend) return;
     const int r0 = 2 * ty;                       // patch row of the first column of output A's window
     const int cyA = c0 + r0, cyB = cyA + 1;
-    if (wave_skip) {                             // (wave-uniform) every output of this wavefront is its window's majority value
-        if (gx < gend && cyA < cend) out[(int64_t)rows[r0 + 4] * G + cs + gx] = vmaj;
-        if (gx < gend && cyB < cend) out[(int64_t)rows[r0 + 5] * G + cs + gx] = vmaj;
-        return;
-    }
-    if (gx >= gend) return;
-    if (cyA >= cend) return;
-    if (cyB < cend) {
+    const bool okA = cyA >= 4 && cyA < cend, okB = cyB >= 4 && cyB < cend;
+    if (!okA && !okB) return;
+    if (okA && okB) {
         double w[10];
         {
             double s[72];
@@ -168,115 +186,43 @@ __device__ inline void median9_patch(int cs, int g0, int gend, int c0, int cend,
         double p[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) p[k] = sortedc[(r0 * MF_TG + tx) * 9 + k];
-        const double mA = median_window_finish(w, p);
-        out[(int64_t)rows[r0 + 4] * G + cs + gx] = majA ? vmaj : mA;
+        out[(int64_t)rows[r0 + 4] * G + cs + gx] = median_window_finish(w, p);
 #pragma unroll
         for (int k = 0; k < 9; ++k) p[k] = sortedc[((r0 + 9) * MF_TG + tx) * 9 + k];
-        const double mB = median_window_finish(w, p);
-        out[(int64_t)rows[r0 + 5] * G + cs + gx] = majB ? vmaj : mB;
+        out[(int64_t)rows[r0 + 5] * G + cs + gx] = median_window_finish(w, p);
         return;
     }
-    // the last interior cell of a tile with an odd number of them: the single-output network over its nine columns
+    // one interior output only (the first or the last interior cell of the tile): the single-output network over its nine columns
+    const int rs = okA ? r0 : r0 + 1;
     double a[81];
 #pragma unroll
     for (int c = 0; c < 9; ++c)
 #pragma unroll
-        for (int k = 0; k < 9; ++k) a[9 * c + k] = sortedc[((r0 + c) * MF_TG + tx) * 9 + k];
-    out[(int64_t)rows[r0 + 4] * G + cs + gx] = median81_sorted_columns(a);
+        for (int k = 0; k < 9; ++k) a[9 * c + k] = sortedc[((rs + c) * MF_TG + tx) * 9 + k];
+    out[(int64_t)rows[rs + 4] * G + cs + gx] = median81_sorted_columns(a);
 }
 
-// The value held by at least two of three probes (else the first): a cheap guess at a patch's most common value.
-__device__ inline double majority_of_three(double a, double b, double c) { return (b == c) ? b : a; }
-
-// Border outputs of the 9 x 9 filter (clamped windows, m < 81 values; R/noise_reduction.R:101-106), one per thread,
-// no interior outputs in the workgroup: the missing positions are padded with n_lo x -inf and +inf so that the wanted
-// order statistics of the real values sit at ranks 40 (and 41 for an even m: stats::median averages the two middle
-// values) of the padded 81; the thread sorts its own nine columns and runs the two-rank variant of the single-output
-// network.  Branch-free like the interior path; kept apart from it because a wavefront that mixes the two pays for both
-// (border outputs are 3.4 % of a 500-cell x 450-gene block but cost 3 x an interior output).
-//   mode 0: the border GENES of one chromosome (first and last four; all genes of a chromosome shorter than nine) for 32
-//           consecutive cells of a tile, corners included;  b0 = first cell
-//   mode 1: the border CELLS of one tile (first and last four; all cells of a tile smaller than nine) for 32 consecutive
-//           interior genes [4, xdim - 4) of a chromosome;  b0 = first gene
-__global__ void __launch_bounds__(256, 2) median_filter9_edge_kernel(const double *__restrict__ in, double *__restrict__ out, int G,
-                                                                     const int32_t *__restrict__ tile_idx,
-                                                                     const int4 *__restrict__ item_desc) {
-    __shared__ double ep[40 * 17];   // mode 0 rows are padded to 17 doubles: a lane's cell is its row, 16 would put all lanes on one bank
-    const int4 d0 = item_desc[2 * blockIdx.x], d1 = item_desc[2 * blockIdx.x + 1];
-    const int mode = d0.x, cs = d0.y, xdim = d0.z, ydim = d1.x, b0 = d1.y;
-    const int32_t *idx = tile_idx + d0.w;
-    const int t = threadIdx.x;
-    int g, cy;          // this thread's output (chromosome-relative gene, tile-relative cell)
-    bool active;
-    if (mode == 0) {    // LDS: 40 cells (b0 - 4 ..) x 16 genes (0..7 | xdim-8 .. xdim-1)
-        for (int e = t; e < 640; e += 256) {
-            const int row = e >> 4, col = e & 15;
-            const int c = b0 - 4 + row, gx = col < 8 ? col : xdim - 16 + col;
-            ep[row * 17 + col] = (c >= 0 && c < ydim && gx >= 0 && gx < xdim) ? in[(int64_t)idx[c] * G + cs + gx] : 0.0;
-        }
-        const int og = t >> 5;
-        cy = b0 + (t & 31);
-        g = (xdim >= 9 && og >= 4) ? xdim - 8 + og : og;
-        active = cy < ydim && (xdim >= 9 || og < xdim);
-    } else {            // LDS: 16 cells (0..7 | ydim-8 .. ydim-1) x 40 genes (b0 - 4 ..)
-        for (int e = t; e < 640; e += 256) {
-            const int row = e / 40, col = e - row * 40;
-            const int c = row < 8 ? row : ydim - 16 + row, gx = b0 - 4 + col;
-            ep[e] = (c >= 0 && c < ydim && gx >= 0 && gx < xdim) ? in[(int64_t)idx[c] * G + cs + gx] : 0.0;
-        }
-        const int oc = t >> 5;
-        g = b0 + (t & 31);
-        cy = (ydim >= 9 && oc >= 4) ? ydim - 8 + oc : oc;
-        active = g < xdim - 4 && (ydim >= 9 || oc < ydim);
-    }
-    __syncthreads();
-    if (!active) return;
-    const int xa = g - 4 < 0 ? 0 : g - 4, xb = g + 4 > xdim - 1 ? xdim - 1 : g + 4;
-    const int ya = cy - 4 < 0 ? 0 : cy - 4, yb = cy + 4 > ydim - 1 ? ydim - 1 : cy + 4;
-    const int m = (xb - xa + 1) * (yb - ya + 1);
+// One output straight from global memory: position p in the tile's cell list (the window's cells are tile_idx[p - up .. p + dn]),
+// absolute gene a (the window's genes a - lf .. a + rt); up / dn / lf / rt <= 4 are what the block leaves of the 9 x 9 window
+// (R/noise_reduction.R:101-106).  The missing positions are padded with n_lo x -inf and +inf so that the wanted order
+// statistics of the m real values sit at ranks 40 (and 41 for an even m: stats::median averages the two middle values).
+__device__ __forceinline__ void median9_general_output(const double *__restrict__ in, double *__restrict__ out, int G,
+                                                       const int32_t *__restrict__ tile_idx, int p, int a, unsigned int clamp) {
+    const int up = (int)(clamp & 15u), dn = (int)((clamp >> 4) & 15u), lf = (int)((clamp >> 8) & 15u), rt = (int)((clamp >> 12) & 15u);
+    const int m = (up + dn + 1) * (lf + rt + 1);
     const int n_lo = (m & 1) ? (81 - m) / 2 : 41 - m / 2;
-    // LDS position of (gene xx, cell yy) of this thread's window: left / right (upper / lower) group of its mode
-    int base, sx, sy;
-    if (mode == 0) {
-        sx = 1; sy = 17;
-        base = ((g < 4 || xdim < 9) ? 0 : 16 - xdim) - (b0 - 4) * 17;
-    } else {
-        sx = 1; sy = 40;
-        base = ((cy < 4 || ydim < 9) ? 0 : (16 - ydim) * 40) - (b0 - 4);
-    }
-    {   // majority shortcut (see above): a value on more than half of the window's m positions is its median (for an even m both
-        // middle values are that value); a wavefront whose outputs are all decided this way skips its networks
-        const double vc = mode == 0 ? majority_of_three(ep[8 * 17 + 2], ep[20 * 17 + 10], ep[30 * 17 + 5])
-                                    : majority_of_three(ep[2 * 40 + 10], ep[5 * 40 + 20], ep[12 * 40 + 30]);
-        int cnt = 0;
-#pragma unroll
-        for (int c = 0; c < 9; ++c) {
-            const int yy = cy - 4 + c;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const int xx = g - 4 + k;
-                const bool in_win = yy >= ya && yy <= yb && xx >= xa && xx <= xb;
-                cnt += (in_win && ep[in_win ? base + yy * sy + xx * sx : 0] == vc) ? 1 : 0;
-            }
-        }
-        const bool maj = 2 * cnt > m;
-        if (__ballot(!maj) == 0ull) {
-            out[(int64_t)idx[cy] * G + cs + g] = vc;
-            return;
-        }
-    }
     int npad = 0;
-    double a[81];
+    double arr[81];
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
-        const int yy = cy - 4 + c;
+        const bool row_ok = c - 4 >= -up && c - 4 <= dn;
+        const double *src = in + (int64_t)tile_idx[row_ok ? p - 4 + c : p] * G + (a - 4);
         double v[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const int xx = g - 4 + k;
-            const bool in_win = yy >= ya && yy <= yb && xx >= xa && xx <= xb;
-            double val = in_win ? ep[base + yy * sy + xx * sx] : 0.0;
-            if (!in_win) {
+            const bool ok = row_ok && k - 4 >= -lf && k - 4 <= rt;
+            double val = ok ? src[k] : 0.0;
+            if (!ok) {
                 val = (npad < n_lo) ? -__builtin_inf() : __builtin_inf();
                 ++npad;
             }
@@ -284,28 +230,273 @@ __global__ void __launch_bounds__(256, 2) median_filter9_edge_kernel(const doubl
         }
         ICNV_SORT9(v);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) a[9 * c + k] = v[k];
+        for (int k = 0; k < 9; ++k) arr[9 * c + k] = v[k];
     }
     double r40, r41;
-    median81_pair_sorted_columns(a, r40, r41);
-    out[(int64_t)idx[cy] * G + cs + g] = (m & 1) ? r40 : (r40 + r41) * 0.5;
+    median81_pair_sorted_columns(arr, r40, r41);
+    out[(int64_t)tile_idx[p] * G + a] = (m & 1) ? r40 : (r40 + r41) * 0.5;
 }
 
-// window_size 7 -> 9 x 9 windows.
-//   Stage A: every (output gene, patch cell) pair gets its nine values along the genes sorted once (25
-//     compare-exchanges) and shared through LDS by the nine outputs whose window contains it.
-//   Stage B: a thread owns the outputs of two neighbouring cells.  Their windows share eight of the nine sorted
-//     columns: positions 31..40 of the merged 72 shared values -- the only ones that can be the median of 72 + 9 --
-//     come from one pruned odd-even merge network per PAIR (668 min/max), and each output finishes with its own
-//     column (18 min/max): 352 min/max per output instead of the 686 of a network per output (median9x9_net.h,
-//     generated and verified by gen_median_net.py; no branches, no data-dependent loops).
-//   This kernel produces the INTERIOR outputs only (gene >= 4 from either end of the chromosome, cell >= 4 from either
-//     end of the tile); median_filter9_edge_kernel above produces the rest.
+constexpr int MF9_SPARSE_T = 128;   // more undecided interior outputs than this in a tile (of up to 512): the tile goes to the dense list
+constexpr int MF9_NT = MF_TG * MF_TC;
+
+struct Median9Lists {       // per-workgroup segments of kernel 1's grid
+    uint4 *queue;           // [n_seg][qcap] {p, a, clamp, 0}
+    int32_t *qcount;        // [n_seg]
+    int32_t *slow;          // [n_seg][lcap] tiles of kernel 1
+    int32_t *scount;        // [n_seg]
+    uint8_t *dflag;         // [tiles of the dense pass] 1: the dense pass computes this tile (zeroed before kernel 1)
+    int qcap, lcap, n_seg;
+};
+
+__device__ inline unsigned int median9_clamp_bits(int gx, int xdim, int cy, int ydim) {
+    const int up = cy < 4 ? cy : 4, dn = ydim - 1 - cy < 4 ? ydim - 1 - cy : 4;
+    const int lf = gx < 4 ? gx : 4, rt = xdim - 1 - gx < 4 ? xdim - 1 - gx : 4;
+    return (unsigned int)up | ((unsigned int)dn << 4) | ((unsigned int)lf << 8) | ((unsigned int)rt << 12);
+}
+
+// Kernel 1.  A workgroup (four wavefronts) takes a tile of K1G = 56 genes x K1C = 32 cells of one (cell tile, chromosome)
+// block.  With the four-gene halo on either side a tile row is exactly 64 genes wide: ONE wavefront reads a whole row with
+// one coalesced load per lane, and its two ballots (below / above the candidate) ARE the row's masks -- no atomics, no
+// shifting.  Wavefront w reads rows 10 w .. 10 w + 9 of the tile's 40 and decides the outputs of cells 8 w .. 8 w + 7 (eight
+// per lane, one gene column: the counts of the window rows are computed once per row and slide down the column).
+// A tile covers 2 x 2 tiles of the dense pass (32 genes x 16 cells each): each of the four is classified on its own.
+constexpr int K1G = 56, K1C = 32, K1ROWS = K1C + 8, K1RPW = K1ROWS / 4, K1OPW = K1C / 4;
+
+__global__ void __launch_bounds__(256, 4) median9_classify_kernel(
+    const double *__restrict__ in, double *__restrict__ out, int G, const int32_t *__restrict__ tile_idx,
+    const int4 *__restrict__ gene1_desc /* {chromosome's first gene, its length, tile's first gene, index of the CHROMOSOME's first dense-pass gene block} */,
+    const int4 *__restrict__ cell1_desc /* {offset of the cell tile's list, its length, tile's first cell, index of its first dense-pass cell block} */,
+    int gene_blocks1, int64_t n_tiles, int gene_blocks2, Median9Lists L, int dev_mode /* developer switch: 1 no test, 2 no queue for interior outputs */) {
+    constexpr int NW = 4;
+    __shared__ unsigned long long lessmask[2][K1ROWS], grtmask[2][K1ROWS];   // per tile row: bit l = the value at gene g0 - 4 + l lies below / above the candidate
+    __shared__ unsigned int wcnt[2][NW];
+    __shared__ double probe[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint4 *queue = L.queue + (int64_t)blockIdx.x * L.qcap;
+    int32_t *slist = L.slow + (int64_t)blockIdx.x * L.lcap;
+    int qn = 0, sn = 0;                  // entries of this workgroup's segments (the same numbers in every thread)
+    const int64_t step = gridDim.x;
+    int64_t pid = blockIdx.x;
+    struct Where { int cs, xdim, g0, kb2, ydim, c0, idx_off, kc2; };
+    auto where = [&](int64_t p) {
+        const int4 gd = gene1_desc[p % gene_blocks1], cd = cell1_desc[p / gene_blocks1];
+        Where w;
+        w.cs = gd.x; w.xdim = gd.y; w.g0 = gd.z; w.kb2 = gd.w; w.idx_off = cd.x; w.ydim = cd.y; w.c0 = cd.z; w.kc2 = cd.w;
+        return w;
+    };
+    __shared__ int32_t rowtab[2][K1ROWS];   // cell (matrix column) of every tile row, -1 outside the block
+    // Three dependent round trips stand between a tile's number and its values (descriptors -> cell indices of its rows ->
+    // values): each is requested one tile earlier than the next, so that a tile waits for none of them -- descriptors three
+    // tiles ahead, row indices two, values one.
+    auto load_ridx = [&](const Where &w) -> int32_t {     // lane j < 10: the cell of row 10 wave + j
+        const int cy = w.c0 - 4 + wave * K1RPW + lane;
+        return (lane < K1RPW && cy >= 0 && cy < w.ydim) ? tile_idx[w.idx_off + cy] : -1;
+    };
+    double stage[K1RPW];                 // this lane's gene in the wavefront's ten rows
+    auto gather = [&](const Where &w, int32_t ridx) {   // (out-of-block positions: their bits are masked out below, whatever is read here)
+        const int gx = w.g0 - 4 + lane;
+        const bool gok = gx >= 0 && gx < w.xdim;
+#pragma unroll
+        for (int j = 0; j < K1RPW; ++j) {
+            const int32_t row = __builtin_amdgcn_readlane(ridx, j);      // (wave-uniform)
+            double v = 0.0;
+            if (row >= 0 && gok) v = in[(int64_t)row * G + w.cs + gx];
+            stage[j] = v;
+        }
+    };
+    double vguess = 0.0;
+    int miss = 0, cold = (dev_mode & 1) ? 0x7fffffff : 0;
+    bool loaded = false;                 // the current tile's values are in `stage`
+    if (pid >= n_tiles) {
+        if (threadIdx.x == 0) { L.qcount[blockIdx.x] = 0; L.scount[blockIdx.x] = 0; }
+        return;
+    }
+    Where D0 = where(pid), D1 = D0, D2 = D0;
+    if (pid + step < n_tiles) D1 = where(pid + step);
+    if (pid + 2 * step < n_tiles) D2 = where(pid + 2 * step);
+    int32_t R0 = load_ridx(D0), R1 = load_ridx(D1);
+    // first candidate: an element of the first tile (wave-uniform address); re-seeded below when it decides nothing
+    vguess = in[(int64_t)tile_idx[D0.idx_off + (D0.c0 + 8 < D0.ydim ? D0.c0 + 8 : D0.c0)] * G + D0.cs + D0.g0];
+    if (cold == 0) { gather(D0, R0); loaded = true; }
+    for (int it = 0; pid < n_tiles; pid += step, ++it) {
+        const Where w = D0;
+        // (workgroup-uniform; a NaN candidate -- a probe can pick one up from the data -- decides nothing: tested on the bits)
+        const bool test = loaded && !(((unsigned long long)__double_as_longlong(vguess) & 0x7fffffffffffffffull) > 0x7ff0000000000000ull);
+        unsigned long long *lmask = lessmask[it & 1], *gmask = grtmask[it & 1];
+        const int gx = w.g0 - 4 + lane;
+        if (test) {
+            const bool gok = gx >= 0 && gx < w.xdim;
+#pragma unroll
+            for (int j = 0; j < K1RPW; ++j) {
+                // (this file is compiled with -fno-honor-nans for its min / max networks: NaN is tested on the bits; a NaN counts on
+                // both sides of the candidate: it decides nothing)
+                const int r = wave * K1RPW + j, cy = w.c0 - 4 + r;
+                const bool ok = gok && cy >= 0 && cy < w.ydim;
+                const bool is_nan = ((unsigned long long)__double_as_longlong(stage[j]) & 0x7fffffffffffffffull) > 0x7ff0000000000000ull;
+                const unsigned long long ml = __ballot(ok && (stage[j] < vguess || is_nan)), mg = __ballot(ok && (stage[j] > vguess || is_nan));
+                if (lane == 0) { lmask[r] = ml; gmask[r] = mg; }
+            }
+        }
+        if (loaded && wave == 1) {
+            // a probe of the tile's own values for the re-seed: the value two of three elements agree on
+            const double a0 = __shfl(stage[5], 10), a1 = __shfl(stage[5], 30), a2 = __shfl(stage[6], 50);
+            if (lane == 0) probe[it & 1] = (a1 == a2) ? a1 : a0;
+        }
+        if (lane < K1RPW) rowtab[it & 1][wave * K1RPW + lane] = R0;
+        __syncthreads();
+        // the next tile's values, the row indices of the tile after it and the descriptors of the one after that are requested
+        // before this tile's decisions are taken
+        const bool had_values = loaded;
+        loaded = false;
+        if (pid + step < n_tiles) {
+            if (cold > 0) --cold;
+            else { gather(D1, R1); loaded = true; }
+        }
+        const int32_t R2 = pid + 2 * step < n_tiles ? load_ridx(D2) : -1;
+        const Where D3 = pid + 3 * step < n_tiles ? where(pid + 3 * step) : D2;
+        // this lane's gene column: outputs of cells c0 + 8 wave + i, i = 0 .. 7
+        const bool g_act = lane >= 4 && lane < 4 + K1G && gx < w.xdim;
+        const bool g_int = g_act && gx >= 4 && gx < w.xdim - 4;
+        const int hg = lane >= 4 + MF_TG ? 1 : 0, hc = wave >> 1;      // which of the 2 x 2 dense-pass tiles
+        const int nx = (gx + 4 < w.xdim - 1 ? gx + 4 : w.xdim - 1) - (gx - 4 > 0 ? gx - 4 : 0) + 1;
+        unsigned int maj = 0, act = 0, inter = 0;     // bit i: output i decided / exists / is an interior output
+#pragma unroll
+        for (int i = 0; i < K1OPW; ++i) {
+            const int cy = w.c0 + wave * K1OPW + i;
+            if (g_act && cy < w.ydim) act |= 1u << i;
+            if (g_int && cy >= 4 && cy < w.ydim - 4) inter |= 1u << i;
+        }
+        if (test) {
+            // the candidate is the median of a window of m positions iff fewer than m / 2 of them lie below it and fewer than m / 2
+            // above it (odd m: at most (m - 1) / 2 on either side; even m: both middle values are the candidate)
+            const int sh = lane >= 4 ? lane - 4 : 0;
+            int hl[K1OPW + 8], hgt[K1OPW + 8];
+#pragma unroll
+            for (int k = 0; k < K1OPW + 8; ++k) {
+                hl[k] = __builtin_popcount((unsigned int)(lmask[wave * K1OPW + k] >> sh) & 0x1FFu);
+                hgt[k] = __builtin_popcount((unsigned int)(gmask[wave * K1OPW + k] >> sh) & 0x1FFu);
+            }
+            int sl = 0, sg = 0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { sl += hl[k]; sg += hgt[k]; }
+#pragma unroll
+            for (int i = 0; i < K1OPW; ++i) {
+                const int cy = w.c0 + wave * K1OPW + i;
+                const int ny = (cy + 4 < w.ydim - 1 ? cy + 4 : w.ydim - 1) - (cy - 4 > 0 ? cy - 4 : 0) + 1;
+                if (2 * sl < nx * ny && 2 * sg < nx * ny) maj |= 1u << i;
+                if (i + 1 < K1OPW) { sl += hl[i + 9] - hl[i]; sg += hgt[i + 9] - hgt[i]; }
+            }
+            maj &= act;
+        }
+        const unsigned int und = act & ~maj;
+        {
+            // undecided interior outputs of this wavefront in the left / right dense-pass tile, undecided border outputs
+            const int ni = __builtin_popcount(und & inter), nb = __builtin_popcount(und & ~inter);
+            int n0 = hg == 0 ? ni : 0, n1 = hg == 1 ? ni : 0, nbw = nb;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                n0 += __shfl_xor(n0, o, 64);
+                n1 += __shfl_xor(n1, o, 64);
+                nbw += __shfl_xor(nbw, o, 64);
+            }
+            const bool wave_maj = __ballot(maj != 0u) != 0ull;
+            if (lane == 0) wcnt[it & 1][wave] = (unsigned int)n0 | ((unsigned int)n1 << 10) | ((unsigned int)nbw << 20) | (wave_maj ? 0x80000000u : 0u);
+        }
+        __syncthreads();
+        int tot[2][2] = {{0, 0}, {0, 0}};      // undecided interior outputs of the dense-pass tile [cell half][gene half]
+        bool any_maj = false;
+#pragma unroll
+        for (int v = 0; v < NW; ++v) {
+            const unsigned int c = wcnt[it & 1][v];
+            tot[v >> 1][0] += (int)(c & 0x3FFu);
+            tot[v >> 1][1] += (int)((c >> 10) & 0x3FFu);
+            any_maj = any_maj || (c & 0x80000000u);
+        }
+        bool dense[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) dense[a][b] = tot[a][b] > MF9_SPARSE_T || ((dev_mode & 2) && tot[a][b] > 0);
+        int n_push = 0, base = 0;
+#pragma unroll
+        for (int v = 0; v < NW; ++v) {
+            const unsigned int c = wcnt[it & 1][v];
+            const int pv = (int)((c >> 20) & 0x3FFu) + (dense[v >> 1][0] ? 0 : (int)(c & 0x3FFu)) + (dense[v >> 1][1] ? 0 : (int)((c >> 10) & 0x3FFu));
+            if (v < wave) base += pv;
+            n_push += pv;
+        }
+        if (qn + n_push > L.qcap) {
+            // the records do not fit this workgroup's segment: the whole tile (interior and border) is left to kernel 3
+            if (threadIdx.x == 0) slist[sn] = (int32_t)pid;
+            ++sn;
+        } else {
+            const bool my_dense = dense[hc][hg];
+            const unsigned int keep = my_dense ? ~inter : ~0u;     // a dense tile's interior outputs are all rewritten by kernel 2
+            const unsigned int wr = maj & keep, push = und & keep;
+            const int a = w.cs + gx;
+            const int p0 = w.idx_off + w.c0 + wave * K1OPW;
+#pragma unroll
+            for (int i = 0; i < K1OPW; ++i)
+                if (wr & (1u << i)) out[(int64_t)rowtab[it & 1][wave * K1OPW + 4 + i] * G + a] = vguess;
+            if (n_push > 0) {
+                // this lane's records go behind those of the lower lanes (exclusive prefix of the per-lane counts)
+                const int mine = __builtin_popcount(push);
+                int incl = mine;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += t;
+                }
+                int at = qn + base + incl - mine;
+#pragma unroll
+                for (int i = 0; i < K1OPW; ++i)
+                    if (push & (1u << i)) {
+                        const int cy = w.c0 + wave * K1OPW + i;
+                        queue[at++] = make_uint4((unsigned int)(p0 + i), (unsigned int)a, median9_clamp_bits(gx, w.xdim, cy, w.ydim), 0u);
+                    }
+                qn += n_push;
+            }
+            // a dense quarter (cell half ch, genes [g0 + 32 gh, g0 + 32 gh + 32 or 24)) marks the dense-pass tiles it overlaps: cell
+            // block kc2 + ch (the cell halves ARE the dense pass's cell blocks) x the one or two 32-gene blocks of the chromosome
+            // (numbered from kb2) its genes fall into.  Plain byte stores of 1: several quarters may mark the same tile.
+            if (threadIdx.x < 8) {
+                const int ch = (threadIdx.x >> 2) & 1, gh = (threadIdx.x >> 1) & 1, which = threadIdx.x & 1;
+                const int lo = w.g0 + MF_TG * gh, hi = (lo + (gh ? K1G - MF_TG : MF_TG) < w.xdim ? lo + (gh ? K1G - MF_TG : MF_TG) : w.xdim) - 1;
+                if (dense[ch][gh] && lo <= hi) {
+                    const int b = which ? hi / MF_TG : lo / MF_TG;
+                    L.dflag[(int64_t)(w.kc2 + ch) * gene_blocks2 + (w.kb2 + b)] = 1;
+                }
+            }
+        }
+        if (had_values) {
+            if (any_maj) {
+                miss = 0;
+            } else {
+                // the candidate decided nothing in a whole tile.  One such tile means little (the dominant value is the same all over
+                // the matrix, a workgroup's tiles hop between neutral and altered regions): the candidate is kept; after three in a
+                // row it is replaced by the tile's own probe, after eight the workgroup stops loading for the next 120 tiles (data without a
+                // dominant value)
+                ++miss;
+                if (miss >= 3) vguess = probe[it & 1];
+                if (miss >= 8) { miss = 0; cold = 120; }
+            }
+        }
+        D0 = D1; D1 = D2; D2 = D3;
+        R0 = R1; R1 = R2;
+    }
+    if (threadIdx.x == 0) {
+        L.qcount[blockIdx.x] = qn;
+        L.scount[blockIdx.x] = sn;
+    }
+}
+
+// Kernel 2: the dense pass over the tiles kernel 1 marked (interior outputs only).  Workgroup b owns the tiles b, b + grid,
+// b + 2 grid, ...; it reads the marks of its next 64 tiles with one load per lane and walks the set bits of the ballot.
 __global__ void __launch_bounds__(MF_TG *MF_TC, 2) median_filter9_kernel(
     const double *__restrict__ in, double *__restrict__ out, int G, const int32_t *__restrict__ tile_idx,
-    const int4 *__restrict__ gene_block_desc /* {chromosome's first gene, its length, block's first gene, end of its interior genes} */,
-    const int4 *__restrict__ cell_patch_desc /* {offset of the tile's cell list, tile length, patch's first cell, end of its interior cells} */,
-    int gene_blocks, int64_t n_patches) {
+    const int4 *__restrict__ gene_block_desc, const int4 *__restrict__ cell_patch_desc, int gene_blocks,
+    const uint8_t *__restrict__ dflag, int64_t n_tiles2) {
     constexpr int h = 4;
     constexpr int PW = MF_TG + 2 * h;    // patch width (genes)
     constexpr int PH = MF9_TC + 2 * h;   // patch height (cells)
@@ -313,29 +504,23 @@ __global__ void __launch_bounds__(MF_TG *MF_TC, 2) median_filter9_kernel(
     constexpr int EPT = (PW * PH + NT - 1) / NT;   // patch elements per thread
     extern __shared__ __attribute__((aligned(16))) double patch2[];  // 2 x [PH][PW], then the sorted columns [PH][MF_TG][9]
     double *sortedc = patch2 + 2 * PW * PH;
-    // Persistent workgroups walk the patches (gene block fastest).  Two things keep the memory latency off the
-    // critical path: a patch is described by two 16-byte records built on the host (one scalar load each instead of
-    // a chromosome scan and a binary search: ~10 dependent loads), requested TWO patches ahead; and the NEXT patch's
-    // values are requested into registers before the current patch's networks run and parked in LDS afterwards, so the
-    // gather (indirect rows through the tile's cell index) hides behind ~1 000 min/max instead of standing between
-    // barriers.
+    // Persistent workgroups walk the dense list.  Two things keep the memory latency off the critical path: a tile is
+    // described by two 16-byte records built on the host, requested TWO tiles ahead; and the NEXT tile's values are
+    // requested into registers before the current tile's networks run and parked in LDS afterwards, so the gather
+    // (indirect rows through the tile's cell index) hides behind ~1 000 min/max instead of standing between barriers.
     struct Where { int cs, xdim, g0, gend, ydim, c0, cend; const int32_t *idx; };
     auto where = [&](const int4 gd, const int4 cd) {
         Where w;
-        w.cs = gd.x; w.xdim = gd.y; w.g0 = gd.z; w.gend = gd.w;
-        w.idx = tile_idx + cd.x; w.ydim = cd.y; w.c0 = cd.z; w.cend = cd.w;
+        w.cs = gd.x; w.xdim = gd.y; w.g0 = gd.z;
+        w.gend = gd.w;                                    // end of this block's outputs (host: its share of kernel 1's tile, inside the interior)
+        w.idx = tile_idx + cd.x; w.ydim = cd.y; w.c0 = cd.z;
+        w.cend = cd.z + MF9_TC < cd.y - 4 ? cd.z + MF9_TC : cd.y - 4;
         return w;
     };
-    // cell index of every patch row, double-buffered in LDS: loaded by PH threads two patches ahead, so neither the
-    // gather nor the output stores wait for an index load
-    // The patch is double-buffered and the row table triple-buffered: a wavefront that runs ahead into the next patch
-    // parks its values and writes the row table of the patch after it while the slowest wavefront still reads the
-    // current ones, so a patch costs two barriers (patch parked | columns sorted) instead of three.
+    // The patch is double-buffered and the row table triple-buffered: a wavefront that runs ahead into the next tile
+    // parks its values and writes the row table of the tile after it while the slowest wavefront still reads the
+    // current ones, so a tile costs two barriers (patch parked | columns sorted) instead of three.
     int32_t *rowbuf = reinterpret_cast<int32_t *>(sortedc + PH * MF_TG * 9);   // [3][PH]
-    // majority shortcut: per patch buffer, one 64-bit mask per patch row (bit g: the value at gene g of the row equals the
-    // candidate) and a word of flags (bit 0: some output needs its network, bit 1: some output took the candidate)
-    unsigned long long *rowmask = reinterpret_cast<unsigned long long *>(rowbuf + 3 * PH + (PH & 1));   // [2][PH], 8-byte aligned
-    unsigned int *mflag = reinterpret_cast<unsigned int *>(rowmask + 2 * PH);                            // [2]
     auto load_rows = [&](const Where &w) -> int32_t {
         const int cy = w.c0 - h + (int)threadIdx.x;
         return ((int)threadIdx.x < PH && cy >= 0 && cy < w.ydim) ? w.idx[cy] : 0;
@@ -354,98 +539,100 @@ __global__ void __launch_bounds__(MF_TG *MF_TC, 2) median_filter9_kernel(
     };
     const int tx = threadIdx.x % MF_TG, ty = threadIdx.x / MF_TG;
     const int64_t step = gridDim.x;
-    int64_t pid = blockIdx.x;
-    if (pid >= n_patches) return;
+    // the marked tiles of this workgroup, in order: a 64-bit window of marks over the tiles wbase + i step
+    int64_t wbase = blockIdx.x;
+    unsigned long long wmask = 0ull;
+    bool wvalid = false;
+    auto next_tile = [&]() -> int64_t {      // (the same value in every thread) -1: no more
+        for (;;) {
+            if (!wvalid) {
+                if (wbase >= n_tiles2) return -1;
+                const int64_t t = wbase + (int64_t)(threadIdx.x & 63) * step;
+                wmask = __ballot(t < n_tiles2 && dflag[t] != 0);
+                wvalid = true;
+            }
+            if (wmask) {
+                const int i = __builtin_ctzll(wmask);
+                wmask &= wmask - 1ull;
+                return wbase + (int64_t)i * step;
+            }
+            wvalid = false;
+            wbase += 64 * step;
+        }
+    };
     auto desc = [&](int64_t p, int4 &gd, int4 &cd) {
         gd = gene_block_desc[p % gene_blocks];
         cd = cell_patch_desc[p / gene_blocks];
     };
+    int64_t t0 = next_tile();
+    if (t0 < 0) return;
+    int64_t t1 = next_tile(), t2 = t1 >= 0 ? next_tile() : -1;
     int4 gd, cd;
-    desc(pid, gd, cd);
+    desc(t0, gd, cd);
     Where cur = where(gd, cd);
     if ((int)threadIdx.x < PH) rowbuf[threadIdx.x] = load_rows(cur);
-    if ((int)threadIdx.x < 2 * PH) rowmask[threadIdx.x] = 0ull;
-    if ((int)threadIdx.x < 2) mflag[threadIdx.x] = 0u;
     __syncthreads();
     gather(cur, rowbuf);
-    // first candidate: an element from the middle of the first patch (wave-uniform address); re-seeded below when it fails
-    double vguess = in[(int64_t)rowbuf[PH / 2] * G + cur.cs + cur.g0];
-    const int lane = threadIdx.x & 63;
-    Where nxt = cur;                 // patch pid + step
+    Where nxt = cur;                 // the next marked tile
     int32_t nxt_row = 0;             // its row table entry of this thread
-    int4 gd2 = gd, cd2 = cd;         // descriptors of patch pid + 2 step
-    if (pid + step < n_patches) {
-        desc(pid + step, gd, cd);
+    int4 gd2 = gd, cd2 = cd;         // descriptors of the marked tile after it
+    if (t1 >= 0) {
+        desc(t1, gd, cd);
         nxt = where(gd, cd);
         nxt_row = load_rows(nxt);
     }
-    if (pid + 2 * step < n_patches) desc(pid + 2 * step, gd2, cd2);
-    int it = 0;   // patch counter of this workgroup: patch buffer it & 1, row table it % 3
-    for (; pid < n_patches; pid += step, ++it) {
-        const bool more = pid + step < n_patches;
+    if (t2 >= 0) desc(t2, gd2, cd2);
+    int it = 0;   // tile counter of this workgroup: patch buffer it & 1, row table it % 3
+    for (; t0 >= 0; ++it) {
+        const bool more = t1 >= 0;
         double *patch = patch2 + (it & 1) * (PW * PH);
         const int rb = it % 3, rb_next = (it + 1) % 3;
-        unsigned long long *rmask = rowmask + (it & 1) * PH;
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
             const int e = (int)threadIdx.x + q * NT;
             if (e < PW * PH) patch[e] = stage[q];
-            // which of the wavefront's 64 consecutive patch elements equal the candidate: one ballot, then at most three
-            // lanes add the bits of the (up to three) patch rows those elements lie in to the rows' masks
-            const unsigned long long m = __ballot(stage[q] == vguess);
-            const int e0 = ((int)threadIdx.x & ~63) + q * NT;
-            const int r = e0 / PW + lane;
-            if (lane < 3 && r < PH) {
-                const int lo = r * PW - e0;                  // element (relative to e0) that sits at gene 0 of row r
-                unsigned long long bits = lo >= 64 ? 0ull : (lo >= 0 ? (m >> lo) : (m << (-lo)));
-                bits &= (1ull << PW) - 1ull;
-                if (bits) atomicOr(&rmask[r], bits);
-            }
         }
         if (more && (int)threadIdx.x < PH) rowbuf[rb_next * PH + threadIdx.x] = nxt_row;
-        __syncthreads();   // also: every wavefront is done with the previous patch's sorted columns
-        // the other buffer's masks and flags (the previous patch's: everybody is past them) are cleared for the patch after next
-        if ((int)threadIdx.x < PH) rowmask[((it + 1) & 1) * PH + threadIdx.x] = 0ull;
-        if (threadIdx.x == 0) mflag[(it + 1) & 1] = 0u;
+        __syncthreads();   // also: every wavefront is done with the previous tile's sorted columns
         const Where w = cur;
+        t0 = t1; t1 = t2;
         if (more) {
             cur = nxt;
             gather(cur, rowbuf + rb_next * PH);
-            if (pid + 2 * step < n_patches) {
+            t2 = t1 >= 0 ? next_tile() : -1;
+            if (t1 >= 0) {
                 nxt = where(gd2, cd2);
                 nxt_row = load_rows(nxt);
-                if (pid + 3 * step < n_patches) desc(pid + 3 * step, gd2, cd2);
+                if (t2 >= 0) desc(t2, gd2, cd2);
             }
         }
-        // majority shortcut: positions equal to the candidate in the windows of this thread's two outputs
-        bool majA, majB;
-        {
-            const int r0 = 2 * ty;
-            int hsum = 0, h0 = 0, h9 = 0;
-#pragma unroll
-            for (int c = 0; c < 10; ++c) {
-                const unsigned int hc = __builtin_popcount((unsigned int)(rmask[r0 + c] >> tx) & 0x1FFu);
-                if (c == 0) h0 = (int)hc;
-                if (c == 9) h9 = (int)hc; else hsum += (int)hc;
-            }
-            majA = hsum >= 41;
-            majB = hsum - h0 + h9 >= 41;
+        median9_patch(w.cs, w.g0, w.gend, w.c0, w.cend, rowbuf + rb * PH, tx, ty, patch, sortedc, out, G);
+    }
+}
+
+// Kernel 3: the queued outputs (one segment per workgroup of kernel 1), one per lane; then every output of the slow list's tiles.
+__global__ void __launch_bounds__(256, 2) median9_sparse_kernel(const double *__restrict__ in, double *__restrict__ out, int G,
+                                                                 const int32_t *__restrict__ tile_idx, const int4 *__restrict__ gene1_desc,
+                                                                 const int4 *__restrict__ cell1_desc, int gene_blocks1, Median9Lists L) {
+    // (block b starts with segment b and walks on: the segments are about equally long)
+    for (int sgm = blockIdx.x; sgm < L.n_seg; sgm += gridDim.x) {
+        const int n = L.qcount[sgm];
+        const uint4 *q = L.queue + (int64_t)sgm * L.qcap;
+        for (int i = (int)threadIdx.x; i < n; i += 256) {
+            const uint4 e = q[i];
+            median9_general_output(in, out, G, tile_idx, (int)e.x, (int)e.y, e.z);
         }
-        const bool actA = w.g0 + tx < w.gend && w.c0 + 2 * ty < w.cend, actB = actA && w.c0 + 2 * ty + 1 < w.cend;
-        const bool wave_net = __ballot((actA && !majA) || (actB && !majB)) != 0ull;       // some output of this wavefront needs its network
-        const bool wave_maj = __ballot((actA && majA) || (actB && majB)) != 0ull;
-        if (lane == 0 && (wave_net || wave_maj)) atomicOr(&mflag[it & 1], (wave_net ? 1u : 0u) | (wave_maj ? 2u : 0u));
-        __syncthreads();
-        const unsigned int fl = mflag[it & 1];
-        if (fl & 1u) {
-            median9_patch(w.cs, w.g0, w.gend, w.c0, w.cend, rowbuf + rb * PH, tx, ty, patch, sortedc, out, G, majA, majB, !wave_net, vguess);
-            // a candidate that decided nothing in a whole patch is replaced by the value two of three probes of this patch agree on
-            if (!(fl & 2u)) vguess = majority_of_three(patch[6 * PW + 10], patch[12 * PW + 20], patch[18 * PW + 30]);
-        } else {
-            // every output of the patch is its window's majority value: no column sorts, no networks
-            const int32_t *rows = rowbuf + rb * PH;
-            if (actA) out[(int64_t)rows[2 * ty + 4] * G + w.cs + w.g0 + tx] = vguess;
-            if (actB) out[(int64_t)rows[2 * ty + 5] * G + w.cs + w.g0 + tx] = vguess;
+        const int ns = L.scount[sgm];
+        for (int j = 0; j < ns; ++j) {
+            // a whole tile of kernel 1 (56 genes x 32 cells): 1 792 outputs, seven per thread
+            const int64_t p = L.slow[(int64_t)sgm * L.lcap + j];
+            const int4 gd = gene1_desc[p % gene_blocks1], cd = cell1_desc[p / gene_blocks1];
+#pragma unroll 1
+            for (int o = (int)threadIdx.x; o < K1G * K1C; o += 256) {
+                const int gx = gd.z + o % K1G, cy = cd.z + o / K1G;
+                if (gx < gd.y && cy < cd.y)
+                    median9_general_output(in, out, G, tile_idx, cd.x + cy, gd.x + gx, median9_clamp_bits(gx, gd.y, cy, cd.y));
+            }
         }
     }
 }
@@ -463,22 +650,65 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
     if (h > MF_MAXH) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "median filter supports window_size <= 15");
     KernelTimer kt("median_filter", stream);
     if (median_is_9x9(window_size)) {
-        const int64_t n_patches = (int64_t)plan9.n_gene_blocks * plan9.n_cell_patches;
-        if (n_patches > 0) {
+        const int64_t n_tiles9 = (int64_t)plan9.n_gene_blocks1 * plan9.n_cell_patches1;       // kernel 1's tiles
+        const int64_t n_tiles2 = (int64_t)plan9.n_gene_blocks * plan9.n_cell_patches;         // the dense pass's (four per tile of kernel 1)
+        if (n_tiles9 > 0) {
+            static_assert(K1G == MEDIAN9_K1_GENES && K1C == MEDIAN9_K1_CELLS && K1G + 8 == 64 && K1C == 2 * MF9_TC && K1G <= 2 * MF_TG, "host tables");
+            if (n_tiles2 > 0x7fffffff) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "median filter: more than 2^31 tiles in one call");
+            static const int dev_mode = std::getenv("ICNV_MF9_MODE") ? std::atoi(std::getenv("ICNV_MF9_MODE")) : 0;   // developer switch
+            // kernel 1: four workgroups per CU (<= 128 registers; ten 8-byte loads in flight per lane), persistent; their list segments
+            int64_t grid1 = (int64_t)num_cus() * 4;
+            if (grid1 > n_tiles9) grid1 = n_tiles9;
+            Median9Lists L;
+            L.n_seg = (int)grid1;
+            L.lcap = (int)(n_tiles9 / grid1 + 2);
+            // queue of single outputs: sized for 5 % of a workgroup's outputs, at least two tiles' worth (a neutral region leaves
+            // next to nothing undecided, the border outputs of undecided regions are ~3 % of those; a tile that does not fit goes to
+            // the slow list as a whole, so the size is a performance knob, not a limit)
+            const int64_t outs_per_wg = n_tiles9 * (K1G * K1C) / grid1 + 1;
+            L.qcap = (int)std::min<int64_t>(std::max<int64_t>(outs_per_wg * 5 / 100, 2 * K1G * K1C), 1 << 24);
+            if (const char *e = std::getenv("ICNV_MF9_QCAP")) L.qcap = std::max(1, std::atoi(e));   // developer / test switch: a tiny queue sends tiles to the slow list
+            const size_t b_queue = (size_t)grid1 * L.qcap * sizeof(uint4);
+            const size_t b_list = ((size_t)grid1 * L.lcap * sizeof(int32_t) + 15) & ~(size_t)15;
+            const size_t b_cnt = ((size_t)grid1 * sizeof(int32_t) + 15) & ~(size_t)15;
+            const size_t b_flag = ((size_t)n_tiles2 + 15) & ~(size_t)15;
+            if (int rc = plan9.queue->alloc(b_queue + b_list + 2 * b_cnt + b_flag)) return rc;
+            char *base = plan9.queue->as<char>();
+            L.queue = reinterpret_cast<uint4 *>(base); base += b_queue;
+            L.slow = reinterpret_cast<int32_t *>(base); base += b_list;
+            L.qcount = reinterpret_cast<int32_t *>(base); base += b_cnt;
+            L.scount = reinterpret_cast<int32_t *>(base); base += b_cnt;
+            L.dflag = reinterpret_cast<uint8_t *>(base);
+            ICNV_HIP(hipMemsetAsync(L.dflag, 0, b_flag, stream));
+            const int4 *gd = reinterpret_cast<const int4 *>(plan9.gene_block_desc), *cd = reinterpret_cast<const int4 *>(plan9.cell_patch_desc);
+            const int4 *g1 = reinterpret_cast<const int4 *>(plan9.gene1_desc), *c1 = reinterpret_cast<const int4 *>(plan9.cell1_desc);
+            hipLaunchKernelGGL(median9_classify_kernel, dim3((unsigned)grid1), dim3(256), 0, stream, in, out, G, tile_idx_dev, g1, c1,
+                               plan9.n_gene_blocks1, n_tiles9, plan9.n_gene_blocks, L, dev_mode);
             const size_t lds = ((size_t)2 * (MF_TG + 8) * (MF9_TC + 8) + (size_t)(MF9_TC + 8) * MF_TG * 9) * sizeof(double) +
-                               (3 * (MF9_TC + 8) + ((MF9_TC + 8) & 1)) * sizeof(int32_t) +
-                               2 * (MF9_TC + 8) * sizeof(unsigned long long) + 2 * sizeof(unsigned int);   // + row masks and flags of the majority shortcut
+                               3 * (MF9_TC + 8) * sizeof(int32_t);
             static DeviceOnce once;
             if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(median_filter9_kernel), 80 * 1024, once)) return rc;
-            int64_t grid = (int64_t)num_cus() * 2;   // two resident workgroups per CU (70 KB of LDS, 256 registers)
-            if (grid > n_patches) grid = n_patches;
-            hipLaunchKernelGGL(median_filter9_kernel, dim3((unsigned)grid), dim3(MF_TG * MF_TC), lds, stream, in, out, G,
-                               tile_idx_dev, reinterpret_cast<const int4 *>(plan9.gene_block_desc),
-                               reinterpret_cast<const int4 *>(plan9.cell_patch_desc), plan9.n_gene_blocks, n_patches);
+            int64_t grid2 = (int64_t)num_cus() * 2;   // two resident workgroups per CU (70 KB of LDS, 256 registers)
+            if (grid2 > n_tiles2) grid2 = n_tiles2;
+            hipLaunchKernelGGL(median_filter9_kernel, dim3((unsigned)grid2), dim3(MF_TG * MF_TC), lds, stream, in, out, G, tile_idx_dev, gd, cd,
+                               plan9.n_gene_blocks, L.dflag, n_tiles2);
+            int64_t grid3 = std::min<int64_t>((int64_t)num_cus() * 4, grid1);
+            hipLaunchKernelGGL(median9_sparse_kernel, dim3((unsigned)grid3), dim3(256), 0, stream, in, out, G, tile_idx_dev, g1, c1,
+                               plan9.n_gene_blocks1, L);
+            if (std::getenv("ICNV_MF9_DEBUG")) {   // developer switch: how the tiles were split (synchronises)
+                std::vector<int32_t> cnt(2 * (b_cnt / sizeof(int32_t)));
+                std::vector<uint8_t> fl((size_t)n_tiles2);
+                (void)hipStreamSynchronize(stream);
+                (void)hipMemcpy(cnt.data(), L.qcount, 2 * b_cnt, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(fl.data(), L.dflag, (size_t)n_tiles2, hipMemcpyDeviceToHost);
+                int64_t q = 0, d = 0, sl = 0;
+                const size_t stride = b_cnt / sizeof(int32_t);
+                for (int64_t i = 0; i < grid1; ++i) { q += cnt[i]; sl += cnt[stride + i]; }
+                for (uint8_t f : fl) d += f;
+                fprintf(stderr, "[median9] %lld tiles (56 x 32): %lld of %lld dense-pass tiles (32 x 16) marked, %lld slow, %lld queued outputs (qcap %d per segment, %lld segments)\n",
+                        (long long)n_tiles9, (long long)d, (long long)n_tiles2, (long long)sl, (long long)q, L.qcap, (long long)grid1);
+            }
         }
-        if (plan9.n_edge_items > 0)
-            hipLaunchKernelGGL(median_filter9_edge_kernel, dim3((unsigned)plan9.n_edge_items), dim3(256), 0, stream, in, out, G,
-                               tile_idx_dev, reinterpret_cast<const int4 *>(plan9.edge_desc));
     } else {
         if (total_cell_patches <= 0) return ICNV_OK;
         int gene_blocks = 0;

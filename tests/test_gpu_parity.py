@@ -706,10 +706,10 @@ def test_median_filter_exact(dev):
 
 
 def test_median_filter_block_boundaries(dev):
-    """The 9 x 9 filter splits every (tile, chromosome) block into interior outputs (32-gene x 16-cell patches starting
-    four in from the edges) and border outputs (separate kernel: border genes of a chromosome, border cells of a tile):
-    chromosome lengths and tile sizes around every boundary of that split (8 | 9, one interior row, odd / even
-    numbers of interior cells, one full patch +- 1, two gene blocks +- 1), ties included."""
+    """The 9 x 9 filter cuts every (tile, chromosome) block into tiles (56 x 32 for the classification pass, 32 x 16 for the dense
+    pass) and treats interior outputs (dense pass or single outputs) and border outputs (single outputs, clamped windows)
+    differently: chromosome lengths and tile sizes around every boundary of those splits (8 | 9, one interior row, odd / even
+    numbers of interior cells, one full tile +- 1, two gene blocks +- 1), ties included."""
     rng = np.random.default_rng(14)
     sizes = [8, 9, 10, 17, 36, 40, 41, 73, 3]
     G = sum(sizes)
@@ -778,6 +778,36 @@ def test_median_filter_majority_shortcut_is_exact(dev, case):
     out = dev.median_filter(to_dev(x), cs, tiles, 7)
     want = oc.median_filter(x, cs, tiles, 7)
     np.testing.assert_array_equal(to_host(out), want)
+
+
+def test_median_filter_slow_list_and_developer_modes(dev, monkeypatch):
+    """The three-kernel 9 x 9 scheme has paths a healthy run hardly takes: a tile whose undecided outputs do not fit the
+    workgroup's queue segment goes to the SLOW list (every one of its outputs is then computed singly), and the developer
+    modes switch the majority test (1) or the queue for interior outputs (2) off.  All of them must give the oracle's matrix.
+    Runs in subprocesses: the switches are read once per process."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np, torch
+sys.path[:0] = [%r, %r + '/oracle']
+import oracle_c as oc
+from infercnv_amd import device
+torch.cuda.set_device(0); device.init(0)
+rng = np.random.default_rng(77)
+sizes = [150, 9, 61, 330, 8, 40, 75]; G = sum(sizes)
+cs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+tsz = [96, 41, 9, 8, 130, 57]; C = sum(tsz)
+x = rng.normal(1.0, 0.2, size=(G, C)); x[rng.random((G, C)) < 0.8] = 1.012490474117089
+x[:, 200:] = rng.normal(1.0, 0.2, size=(G, C - 200))          # a region without a dominant value
+perm = rng.permutation(C); off = np.concatenate([[0], np.cumsum(tsz)])
+tiles = [perm[off[i]:off[i + 1]].astype(np.int32) for i in range(len(tsz))]
+got = device.median_filter(torch.from_numpy(np.ascontiguousarray(x.T)).cuda(), cs, tiles, 7).cpu().numpy().T
+assert np.array_equal(got, oc.median_filter(x, cs, tiles, 7))
+print("MF9_OK")
+""" % (root, root)
+    for env in ({"ICNV_MF9_QCAP": "40"}, {"ICNV_MF9_QCAP": "1"}, {"ICNV_MF9_MODE": "1"}, {"ICNV_MF9_MODE": "2"}, {"ICNV_MF9_MODE": "3"}):
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=300)
+        assert res.returncode == 0 and "MF9_OK" in res.stdout, (env, res.stdout[-1500:], res.stderr[-1500:])
 
 
 # ------------------------------------------------------------------ host mirror == device path == oracle
