@@ -366,15 +366,36 @@ def host_path_rate(x_dev, chr_start, refs, hmm, cells=20000):
         check(L.icnv_viterbi_cells(vp(pre), vp(st), G, C, csp, csa.size - 1, len(means), mp, float(sd),
                                    lp.ctypes.data_as(ct.POINTER(ct.c_double)), ldp))
 
-    res = {"cells": C, "what": "icnv_smooth_chain + icnv_viterbi_cells on host matrices, uploads and downloads included"}
-    for resident in (0, 1):
-        check(L.icnv_residency(resident))
-        run()
+    res = {"cells": C, "what": "icnv_smooth_chain + icnv_viterbi_cells on host matrices (pageable, like R's), uploads and downloads included; "
+                              "phases = icnv_host_path_stats of the timed pair of calls (wall-clock ms; with the pipeline the upload, kernel "
+                              "and download phases overlap)"}
+    names = ("calls", "fingerprint_ms", "hash_ms", "hash_threads", "h2d_ms", "h2d_bytes", "d2h_ms", "d2h_bytes", "device_ms", "pipelined_calls", "wall_ms", "alloc_ms")
+    def timed(label, warm):
+        # warm-up: pool blocks, tables, page faults of the output arrays.  With residency on, the matrices kept on the device
+        # hold pool blocks until they are evicted (six per device): the pool reaches its steady state -- no hipMalloc inside a
+        # call -- after three pairs of calls; rounds 3 and 4 timed the second pair and reported its allocations (172 ms)
+        first = None
+        for k in range(warm):
+            L.icnv_host_path_stats_reset()
+            t0 = time.perf_counter()
+            run()
+            if k == 1:
+                first = (time.perf_counter() - t0) * 1e3
+        L.icnv_host_path_stats_reset()
         t0 = time.perf_counter()
         run()
         t = time.perf_counter() - t0
-        res["residency_on" if resident else "residency_off"] = {"value": C / t, "unit": "cells/s", "ms": t * 1e3}
+        buf = (ct.c_double * 12)()
+        check(L.icnv_host_path_stats(buf, 12))
+        res[label] = {"value": C / t, "unit": "cells/s", "ms": t * 1e3, "warm_up_pairs_of_calls": warm,
+                      "ms_of_the_second_pair_of_calls": first, "phases": {k: float(v) for k, v in zip(names, buf)}}
+    os.environ.pop("ICNV_HOST_PIPELINE", None)
     check(L.icnv_residency(0))
+    timed("residency_off", 2)                        # the default: three-thread pipeline over column blocks
+    check(L.icnv_residency(1))
+    timed("residency_on", 4)
+    check(L.icnv_residency(0))
+    res["default"] = "residency_off (also the R glue's default since round 5)"
     return res
 
 

@@ -93,11 +93,34 @@ int icnv_get_devices(void);
  * reject, then a 64-bit hash of every value (the host's cores hash the incoming matrix at memory speed, several times
  * faster than the upload it saves; a device reduction hashes what the library produced).  A recognised matrix is not
  * uploaded again.  Addresses play no part: the caller may free, reuse or edit host memory at any time -- one changed
- * element changes the hash (collision odds 2^-64) and the matrix is uploaded.  Off by default.
+ * element changes the hash and the matrix is uploaded (the hash is linear inside a 64-byte block: an edit of ONE word is
+ * always seen; edits of several words of one block cancel only if sum_j delta_j K_j = 0 mod 2^64, odds 2^-64 for unrelated
+ * data).  Whether it pays depends on the host: the hash is one pass over the matrix by the cores the process may use, the
+ * upload it saves is one pass by the DMA engines at PCIe speed -- on a 16-core quota the two are about even (the bench
+ * line's `host_path` shows both, with the phase times of icnv_host_path_stats).  Off by default, also in the R glue.
  *   icnv_residency_stats  out4 = {matrices recognised, matrices uploaded, resident bytes, resident matrices} */
 int icnv_residency(int on);
 void icnv_residency_drop(void);
 int icnv_residency_stats(int64_t *out4);
+
+/* Where a host-buffer call spends its time (wall-clock milliseconds accumulated since the last reset, per process):
+ *   out[0] calls            host-buffer entry points that moved a matrix
+ *   out[1] fingerprint_ms   residency: strided samples of incoming matrices
+ *   out[2] hash_ms          residency: full content hashes on the host's cores        out[3] hash_threads (of the last hash)
+ *   out[4] h2d_ms           time the uploading thread was busy                         out[5] h2d_bytes
+ *   out[6] d2h_ms           time the downloading thread was busy                       out[7] d2h_bytes
+ *   out[8] device_ms        waiting for the kernels alone (not overlapped with a copy)
+ *   out[9] pipelined_calls  calls that ran the three-thread pipeline (upload | kernels | download of column blocks)
+ *   out[10] wall_ms         whole calls, entry to return
+ *   out[11] alloc_ms        hipMalloc inside the calls (the workspace pool is grow-only: zero in the steady state; with
+ *                           residency on, the first calls after a change of shape allocate what the residents hold)
+ * n = number of doubles the caller's buffer holds (<= 12 are written).  icnv_host_path_stats_reset() zeroes them.
+ * The smoothing chain and the per-cell Viterbi on ONE device pipeline their transfers over column blocks when
+ * residency is off (the reference cells' blocks first: the chain's statistics need them before any block can be
+ * finished): uploads, kernels and downloads overlap on three streams driven by three host threads, because a copy from
+ * or to pageable memory -- what R hands over -- occupies the thread that issues it.  ICNV_HOST_PIPELINE=0 switches it off. */
+int icnv_host_path_stats(double *out, int32_t n);
+void icnv_host_path_stats_reset(void);
 
 /* ---- smoothing chain ---------------------------------------------------- */
 typedef struct icnv_chain_cfg {

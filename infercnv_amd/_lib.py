@@ -71,6 +71,8 @@ PROTOTYPES = {
     "icnv_residency": (ct.c_int, [ct.c_int]),
     "icnv_residency_drop": (None, []),
     "icnv_residency_stats": (ct.c_int, [ct.POINTER(_i64)]),
+    "icnv_host_path_stats": (ct.c_int, [_dp, _i32]),
+    "icnv_host_path_stats_reset": (None, []),
     "icnv_smooth_chain": (ct.c_int, [_vp, _vp, _vp, ct.POINTER(ChainCfg)]),
     "icnv_smooth_chain_dev": (ct.c_int, [_vp, _vp, _vp, ct.POINTER(ChainCfg), _vp]),
     "icnv_chain_begin": (ct.c_int, [ct.POINTER(_vp), ct.POINTER(ChainCfg)]),

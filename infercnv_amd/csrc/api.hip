@@ -2,6 +2,7 @@
 // orchestration: device workspace pool, descriptor uploads, reference rounds.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -87,6 +88,21 @@ size_t round_size(size_t n) {
 }
 }  // namespace
 
+// wall time spent in hipMalloc by the pool (a host-buffer call that finds no cached block pays for the allocation: what the
+// host path's statistics report as alloc_ms)
+static std::atomic<int64_t> g_malloc_us{0};
+double pool_malloc_ms(bool reset) {
+    const double v = (double)g_malloc_us.load() * 1e-3;
+    if (reset) g_malloc_us.store(0);
+    return v;
+}
+namespace {
+struct MallocTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~MallocTimer() { g_malloc_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
+
 int pool_alloc(void **p, size_t bytes) {
     const size_t sz = round_size(bytes);
     const int dev = pool_domain();
@@ -101,6 +117,7 @@ int pool_alloc(void **p, size_t bytes) {
         }
     }
     void *q = nullptr;
+    MallocTimer malloc_timer;
     hipError_t e = hipMalloc(&q, sz);
     if (e != hipSuccess) {
         // release the idle resident matrices (icnv_residency) and this device's cached blocks, retry once
@@ -702,6 +719,28 @@ int icnv_chain_apply_dev(icnv_chain_t *ch, const double *expr_in, double *expr_o
     }
     return chain_apply_masked(ch, ch->mask, expr_in, expr_out, pre_denoise, s);
 }
+
+}  // extern "C"
+namespace icnv {
+int chain_apply_columns(icnv_chain_t *ch, const double *expr_in, double *expr_out, double *pre_denoise, int64_t c0, int64_t c1,
+                        hipStream_t s) {
+    if (!ch || !expr_in || !expr_out) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
+    if (ch->large || ((ch->mask & ICNV_ST_DENOISE) && ch->cfg.noise_logistic) || (pre_denoise && !(ch->mask & ICNV_ST_DENOISE))) return -1000;
+    if (c1 <= c0) return ICNV_OK;
+    int rc = chain_upload(ch, s);
+    if (rc) return rc;
+    // every cell of the block runs the whole chain (the reference cells too: the cache the rounds left is not used here --
+    // the same arithmetic either way, tests/test_gpu_parity.py compares the two)
+    ChainArgs a = chain_args(ch, expr_in + c0 * ch->cfg.G);
+    a.mask = ch->mask;
+    a.out = expr_out + c0 * ch->cfg.G;
+    a.pre_out = pre_denoise ? pre_denoise + c0 * ch->cfg.G : nullptr;
+    a.cells = nullptr;
+    a.n_cells = (int32_t)(c1 - c0);
+    return launch_chain(a, MODE_APPLY, s);
+}
+}  // namespace icnv
+extern "C" {
 
 int icnv_chain_get_denoise(icnv_chain_t *ch, double *mu_s, void *stream) {
     if (!ch || !mu_s) ICNV_FAIL(ICNV_ERR_ARG, "null argument");

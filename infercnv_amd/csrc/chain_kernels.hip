@@ -38,7 +38,10 @@ int launch_chain_m15s(const ChainArgs &a, int mode, hipStream_t stream);  // ...
 int launch_chain_m15t(const ChainArgs &a, int mode, hipStream_t stream);  // ... and half window 50 at compile time (-1000: not in this form)
 int launch_chain_w11(const ChainArgs &a, int mode, hipStream_t stream);   // 1024 threads, <= 11264 positions, <= 10240 (even) genes
 int launch_chain_w11t(const ChainArgs &a, int mode, hipStream_t stream);  // ... half window 50 at compile time (-1000: not in this form)
-int launch_chain_m23(const ChainArgs &a, int mode, hipStream_t stream);   // 768 threads,  <= 17664
+int launch_chain_m17(const ChainArgs &a, int mode, hipStream_t stream);   // 768 threads,  <= 13056 positions (even G: <= 12288 genes, eight slots)
+int launch_chain_m19(const ChainArgs &a, int mode, hipStream_t stream);   // 768 threads,  <= 14592 (<= 13824 genes, nine slots)
+int launch_chain_m21(const ChainArgs &a, int mode, hipStream_t stream);   // 768 threads,  <= 16128 (<= 15360 genes, ten slots)
+int launch_chain_m23(const ChainArgs &a, int mode, hipStream_t stream);   // 768 threads,  <= 17664 (even G <= 16896: eleven slots)
 int launch_chain_l35(const ChainArgs &a, int mode, hipStream_t stream);   // 512 threads,  <= 17920
 
 
@@ -379,6 +382,11 @@ static bool chain_geom(int64_t G, int n_chr, int T, ChainGeom &g) {
     // barrier-separated phases better than 12 (chain_apply 2.45 -> 2.30 ms at 10 000 genes); even gene counts only
     if (npos <= 1024 * 11 && G <= 1024 * 5 * 2 && (G & 1) == 0) { g.nt = 1024; g.lmax = 11; return true; }
     if (npos <= 768 * 15) { g.nt = 768; g.lmax = 15; return true; }
+    // between the 10 000-gene geometries and 768 x 23: chunk lengths 17 / 19 / 21 with (L - 1) / 2 gene-pair slots for even G
+    // (odd G: one gene per slot, L slots) -- a thread's work follows its chunk length and its slots, so the smallest geometry
+    // that holds the cell is the fastest
+    for (int L = 17; L <= 21; L += 2)
+        if (npos <= 768 * L && ((G & 1) || G <= 768 * ((L - 1) / 2) * 2)) { g.nt = 768; g.lmax = L; return true; }
     if (npos <= 768 * 23) { g.nt = 768; g.lmax = 23; return true; }
     if (npos <= 512 * 35) { g.nt = 512; g.lmax = 35; return true; }
     return false;
@@ -481,6 +489,9 @@ int launch_chain(const ChainArgs &a0, int mode, hipStream_t stream) {
         }
         return launch_chain_m15(a, mode, stream);
     }
+    if (g.lmax == 17) return launch_chain_m17(a, mode, stream);
+    if (g.lmax == 19) return launch_chain_m19(a, mode, stream);
+    if (g.lmax == 21) return launch_chain_m21(a, mode, stream);
     if (g.lmax == 23) return launch_chain_m23(a, mode, stream);
     return launch_chain_l35(a, mode, stream);
 }

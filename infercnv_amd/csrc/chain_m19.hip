@@ -1,0 +1,12 @@
+// chain kernel variants with 768 threads (3 wavefronts per SIMD, 168 VGPRs), chunk length 19 and -- for even gene counts --
+// 9 gene-pair slots per thread (at most 768 * 9 * 2 genes): gene sets between the 10 000-gene geometries and 768 x 23.
+// The chunk-layout phases cost a thread its chunk length, the S-layout phases its slots: a cell of 11 000 genes on the
+// 768 x 23 geometry (12 slots) did 40 % of both for nothing (profiles/r05_sweep.json).
+#include "chain_kernel.inc"
+
+namespace icnv {
+int launch_chain_m19(const ChainArgs &a, int mode, hipStream_t stream) {
+    if ((a.G & 1) == 0) return launch_chain_m<768, 19, 2, 9, 0>(a, mode, stream);
+    return launch_chain_m<768, 19, 1>(a, mode, stream);
+}
+}  // namespace icnv

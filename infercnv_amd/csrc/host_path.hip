@@ -26,9 +26,47 @@
 
 #include "icnv_internal.h"
 
+#include <chrono>
+
 namespace icnv {
 
 int pool_domain();   // api.hip: device ordinal * 256 + pool partition of the calling thread
+
+// ------------------------------------------------------------------ where a host-buffer call spends its time
+namespace {
+struct HostPathStats {
+    std::mutex mu;
+    double v[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    void add(int i, double x) { std::lock_guard<std::mutex> lk(mu); v[i] += x; }
+    void set(int i, double x) { std::lock_guard<std::mutex> lk(mu); v[i] = x; }
+};
+HostPathStats g_hp;
+enum { HP_CALLS = 0, HP_FP_MS, HP_HASH_MS, HP_HASH_THREADS, HP_H2D_MS, HP_H2D_BYTES, HP_D2H_MS, HP_D2H_BYTES, HP_DEV_MS, HP_PIPELINED, HP_WALL_MS };
+struct WallTimer {   // adds the elapsed wall time to one slot when it goes out of scope
+    int slot;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit WallTimer(int s) : slot(s) {}
+    double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+    ~WallTimer() { if (slot >= 0) g_hp.add(slot, ms()); }
+};
+// synchronous copies with their time and bytes on the books
+int timed_h2d(void *dst, const void *src, size_t bytes, hipStream_t s) {
+    if (!bytes) return ICNV_OK;
+    WallTimer t(HP_H2D_MS);
+    ICNV_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+    ICNV_HIP(hipStreamSynchronize(s));
+    g_hp.add(HP_H2D_BYTES, (double)bytes);
+    return ICNV_OK;
+}
+int timed_d2h(void *dst, const void *src, size_t bytes, hipStream_t s) {
+    if (!bytes) return ICNV_OK;
+    WallTimer t(HP_D2H_MS);
+    ICNV_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+    ICNV_HIP(hipStreamSynchronize(s));
+    g_hp.add(HP_D2H_BYTES, (double)bytes);
+    return ICNV_OK;
+}
+}  // namespace
 
 // ------------------------------------------------------------------ residency
 namespace {
@@ -166,6 +204,7 @@ uint64_t content_hash_host(const double *x, int64_t n) {
     static const int nt_max = host_hash_threads();
     int nt = (int)std::max<int64_t>(1, std::min<int64_t>(nt_max, (nb + (1 << 17) - 1) >> 17));   // at least 8 MiB per thread
     std::vector<uint64_t> part((size_t)nt, 0);
+    g_hp.set(HP_HASH_THREADS, (double)nt);
     auto work = [&](int t) {
         const int64_t b = nb * t / nt, e = nb * (t + 1) / nt;
         uint64_t a0 = 0, a1 = 0;
@@ -225,7 +264,8 @@ MatrixLease::~MatrixLease() {
 
 int acquire_input(const double *host, int64_t n, hipStream_t s, MatrixLease &lease) {
     if (g_res_on.load()) {
-        const uint64_t fp = fingerprint(host, n);
+        uint64_t fp;
+        { WallTimer t(HP_FP_MS); fp = fingerprint(host, n); }
         ResidentDomain &d = res_domain();
         uint64_t h = 0;
         bool have_h = false;
@@ -240,7 +280,7 @@ int acquire_input(const double *host, int64_t n, hipStream_t s, MatrixLease &lea
         }
         if (!cands.empty()) {
             // the sample agrees with a resident matrix: identity is decided by the hash of EVERY value
-            h = content_hash_host(host, n);
+            { WallTimer t(HP_HASH_MS); h = content_hash_host(host, n); }
             have_h = true;
             int rc_hash = ICNV_OK;
             std::vector<uint64_t> dev_hash(cands.size(), 0);
@@ -272,7 +312,8 @@ int acquire_input(const double *host, int64_t n, hipStream_t s, MatrixLease &lea
         DevBuf b;
         int rc = b.alloc((size_t)std::max<int64_t>(n, 1) * sizeof(double));
         if (rc) return rc;
-        if (n) ICNV_HIP(hipMemcpyAsync(b.p, host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+        if (n) { WallTimer t(HP_H2D_MS); ICNV_HIP(hipMemcpyAsync(b.p, host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s)); g_hp.add(HP_H2D_BYTES, (double)n * 8.0); }
+        // (a copy from pageable memory returns when the data is staged: its wall time is the upload's)
         // the uploaded matrix stays resident too (the HMM input is read by the Viterbi and again by the median filter);
         // its hash is taken from the device copy the first time a look-alike arrives
         std::lock_guard<std::mutex> lk(d.mu);
@@ -285,7 +326,7 @@ int acquire_input(const double *host, int64_t n, hipStream_t s, MatrixLease &lea
     }
     int rc = lease.own.alloc((size_t)std::max<int64_t>(n, 1) * sizeof(double));
     if (rc) return rc;
-    if (n) ICNV_HIP(hipMemcpyAsync(lease.own.p, host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    if (n) { WallTimer t(HP_H2D_MS); ICNV_HIP(hipMemcpyAsync(lease.own.p, host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s)); g_hp.add(HP_H2D_BYTES, (double)n * 8.0); }
     lease.dev = lease.own.as<double>();
     return ICNV_OK;
 }
@@ -371,6 +412,153 @@ int on_devices(int nd, Body body) {
 }
 }  // namespace
 
+
+// ------------------------------------------------------------------ upload | kernels | download over column blocks
+// A copy from or to pageable memory (what R hands over) occupies the host thread that issues it, so the three stages of
+// a host-buffer call run on three threads and three streams: the uploader copies block after block and records an event per
+// block; the caller's thread waits for the blocks it needs, enqueues the kernels of a block behind its upload event and records
+// an event per finished block; the downloader copies a block back as soon as its event is recorded.  PCIe is full duplex:
+// the downloads of the early blocks overlap the uploads of the late ones.
+namespace {
+bool host_pipeline_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = std::getenv("ICNV_HOST_PIPELINE");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v != 0;
+}
+
+struct HostPipeline {
+    int nb = 0;
+    hipStream_t s_up = nullptr, s_c = nullptr, s_dn = nullptr;
+    std::vector<hipEvent_t> ev_up, ev_c;
+    std::mutex mu;
+    std::condition_variable cv;
+    int up_done = 0, c_done = 0;
+    int rc = ICNV_OK;
+    std::string msg;
+    int home = 0;
+
+    int open(int n_blocks) {
+        nb = n_blocks;
+        ICNV_HIP(hipGetDevice(&home));
+        ICNV_HIP(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking));
+        ICNV_HIP(hipStreamCreateWithFlags(&s_c, hipStreamNonBlocking));
+        ICNV_HIP(hipStreamCreateWithFlags(&s_dn, hipStreamNonBlocking));
+        ev_up.assign((size_t)nb, nullptr);
+        ev_c.assign((size_t)nb, nullptr);
+        for (int i = 0; i < nb; ++i) {
+            ICNV_HIP(hipEventCreateWithFlags(&ev_up[(size_t)i], hipEventDisableTiming));
+            ICNV_HIP(hipEventCreateWithFlags(&ev_c[(size_t)i], hipEventDisableTiming));
+        }
+        return ICNV_OK;
+    }
+    ~HostPipeline() {
+        for (hipEvent_t e : ev_up) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_c) if (e) (void)hipEventDestroy(e);
+        if (s_up) { (void)hipStreamSynchronize(s_up); (void)hipStreamDestroy(s_up); }
+        if (s_c) { (void)hipStreamSynchronize(s_c); (void)hipStreamDestroy(s_c); }
+        if (s_dn) { (void)hipStreamSynchronize(s_dn); (void)hipStreamDestroy(s_dn); }
+    }
+    void fail(int code, const std::string &m) {   // first error wins; everybody is released
+        std::lock_guard<std::mutex> lk(mu);
+        if (rc == ICNV_OK) { rc = code; msg = m; }
+        up_done = nb;
+        c_done = nb;
+        cv.notify_all();
+    }
+    bool failed() { std::lock_guard<std::mutex> lk(mu); return rc != ICNV_OK; }
+
+    // up(i, stream) / down(i, stream): the copies of block i (hipError_t); first(stream): once, behind the uploads of the blocks
+    // [0, n_first); compute(i, stream): the kernels of block i (library return code)
+    template <class Up, class First, class Compute, class Down>
+    int run(int n_first, Up up, First first, Compute compute, Down down) {
+        std::thread uploader([&] {
+            if (hipSetDevice(home) != hipSuccess) { fail(ICNV_ERR_HIP, "uploader: hipSetDevice failed"); return; }
+            WallTimer t(HP_H2D_MS);
+            for (int i = 0; i < nb && !failed(); ++i) {
+                hipError_t e = up(i, s_up);
+                if (e == hipSuccess) e = hipEventRecord(ev_up[(size_t)i], s_up);
+                if (e != hipSuccess) { (void)hipGetLastError(); fail(ICNV_ERR_HIP, std::string("upload failed: ") + hipGetErrorString(e)); return; }
+                std::lock_guard<std::mutex> lk(mu);
+                up_done = std::max(up_done, i + 1);
+                cv.notify_all();
+            }
+            (void)hipStreamSynchronize(s_up);
+        });
+        std::thread downloader([&] {
+            if (hipSetDevice(home) != hipSuccess) { fail(ICNV_ERR_HIP, "downloader: hipSetDevice failed"); return; }
+            double busy = 0.0;
+            for (int i = 0; i < nb; ++i) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return c_done > i || rc != ICNV_OK; });
+                    if (rc != ICNV_OK) break;
+                }
+                WallTimer t(-1);
+                hipError_t e = hipStreamWaitEvent(s_dn, ev_c[(size_t)i], 0);
+                if (e == hipSuccess) e = down(i, s_dn);
+                if (e != hipSuccess) { (void)hipGetLastError(); fail(ICNV_ERR_HIP, std::string("download failed: ") + hipGetErrorString(e)); break; }
+                busy += t.ms();
+            }
+            { WallTimer t(-1); (void)hipStreamSynchronize(s_dn); busy += t.ms(); }
+            g_hp.add(HP_D2H_MS, busy);
+        });
+        auto wait_up = [&](int i) -> bool {   // block i uploaded (its event recorded)?  false: the pipeline failed
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return up_done > i || rc != ICNV_OK; });
+            return rc == ICNV_OK;
+        };
+        bool ok = true;
+        for (int i = 0; i < n_first && ok; ++i) {
+            ok = wait_up(i);
+            if (ok && hipStreamWaitEvent(s_c, ev_up[(size_t)i], 0) != hipSuccess) { fail(ICNV_ERR_HIP, "hipStreamWaitEvent failed"); ok = false; }
+        }
+        if (ok) {
+            const int r = first(s_c);
+            if (r) { fail(r, icnv_last_error()); ok = false; }
+        }
+        for (int i = 0; i < nb && ok; ++i) {
+            ok = wait_up(i);
+            if (!ok) break;
+            if (hipStreamWaitEvent(s_c, ev_up[(size_t)i], 0) != hipSuccess) { fail(ICNV_ERR_HIP, "hipStreamWaitEvent failed"); break; }
+            const int r = compute(i, s_c);
+            if (r) { fail(r, icnv_last_error()); break; }
+            if (hipEventRecord(ev_c[(size_t)i], s_c) != hipSuccess) { fail(ICNV_ERR_HIP, "hipEventRecord failed"); break; }
+            std::lock_guard<std::mutex> lk(mu);
+            c_done = std::max(c_done, i + 1);
+            cv.notify_all();
+        }
+        uploader.join();
+        downloader.join();
+        (void)hipStreamSynchronize(s_c);
+        if (rc != ICNV_OK) { set_error(msg); return rc; }
+        g_hp.add(HP_PIPELINED, 1.0);
+        return ICNV_OK;
+    }
+};
+
+// column blocks of ~128 MB (at least 2, at most 64); `first` = blocks that hold a marked cell come first, in order
+void pipeline_blocks(int64_t G, int64_t C, const std::vector<char> *marked, std::vector<int64_t> &b0, std::vector<int64_t> &b1, int &n_first) {
+    const int64_t bytes = G * C * 8;
+    int64_t nb = std::max<int64_t>(2, std::min<int64_t>(64, (bytes + (128ll << 20) - 1) / (128ll << 20)));
+    nb = std::min<int64_t>(nb, std::max<int64_t>(1, C / 64));
+    nb = std::max<int64_t>(nb, 1);
+    const int64_t per = (C + nb - 1) / nb;
+    std::vector<int64_t> lo, hi;
+    for (int64_t c = 0; c < C; c += per) { lo.push_back(c); hi.push_back(std::min(C, c + per)); }
+    std::vector<char> has((size_t)lo.size(), 0);
+    if (marked)
+        for (size_t k = 0; k < lo.size(); ++k)
+            for (int64_t c = lo[k]; c < hi[k] && !has[k]; ++c) has[k] = (*marked)[(size_t)c];
+    b0.clear(); b1.clear();
+    n_first = 0;
+    for (size_t k = 0; k < lo.size(); ++k) if (has[k]) { b0.push_back(lo[k]); b1.push_back(hi[k]); ++n_first; }
+    for (size_t k = 0; k < lo.size(); ++k) if (!has[k]) { b0.push_back(lo[k]); b1.push_back(hi[k]); }
+}
+}  // namespace
+
 }  // namespace icnv
 
 using namespace icnv;
@@ -411,6 +599,19 @@ int icnv_residency_stats(int64_t *out4) {
     return ICNV_OK;
 }
 
+int icnv_host_path_stats(double *out, int32_t n) {
+    if (!out || n < 1) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(g_hp.mu);
+    for (int i = 0; i < n && i < 11; ++i) out[i] = g_hp.v[i];
+    if (n > 11) out[11] = pool_malloc_ms(false);
+    return ICNV_OK;
+}
+void icnv_host_path_stats_reset(void) {
+    std::lock_guard<std::mutex> lk(g_hp.mu);
+    for (double &x : g_hp.v) x = 0.0;
+    (void)pool_malloc_ms(true);
+}
+
 int icnv_set_devices(int n_devices) {
     int n = 0;
     ICNV_HIP(hipGetDeviceCount(&n));
@@ -439,18 +640,73 @@ int icnv_smooth_chain(const double *expr_in, double *expr_out, double *pre_denoi
     if (cfg->G < 1 || cfg->C < 0) ICNV_FAIL(ICNV_ERR_ARG, "bad matrix dimensions");
     const int64_t G = cfg->G, C = cfg->C;
     const int nd = (int)std::max<int64_t>(1, std::min<int64_t>(g_ndev.load(), C));
+    WallTimer wall(HP_WALL_MS);
+    g_hp.add(HP_CALLS, 1.0);
     if (nd == 1) {
         const int64_t n = G * C;
+        // ---- one device, no residency: upload | kernels | download pipelined over column blocks
+        if (!g_res_on.load() && host_pipeline_enabled() && n * 8 >= (64ll << 20) && C >= 128) {
+            icnv_chain_t *ch = nullptr;
+            int rc = icnv_chain_begin(&ch, cfg);
+            if (rc) return rc;
+            struct ChainGuard { icnv_chain_t *c; ~ChainGuard() { if (c) icnv_chain_end(c); } } guard{ch};
+            const int rounds = icnv_chain_num_rounds(ch);
+            for (int q = 0; q < cfg->n_ref_grp && rounds > 0; ++q)
+                if (cfg->ref_off[q + 1] == cfg->ref_off[q]) ICNV_FAIL(ICNV_ERR_ARG, "empty reference group");
+            if (chain_apply_columns(ch, expr_in, expr_out, pre_denoise, 0, 0, nullptr) != -1000) {
+                std::vector<char> is_ref((size_t)C, 0);
+                if (rounds > 0)
+                    for (int32_t i = 0; i < cfg->ref_off[cfg->n_ref_grp]; ++i) is_ref[(size_t)cfg->ref_idx[i]] = 1;
+                std::vector<int64_t> b0, b1;
+                int n_first = 0;
+                pipeline_blocks(G, C, rounds > 0 ? &is_ref : nullptr, b0, b1, n_first);
+                DevBuf din, dout, dpre;
+                const size_t bytes = (size_t)n * sizeof(double);
+                if ((rc = din.alloc(bytes)) || (rc = dout.alloc(bytes)) || (pre_denoise && (rc = dpre.alloc(bytes)))) return rc;
+                HostPipeline pipe;
+                if ((rc = pipe.open((int)b0.size()))) return rc;
+                const double *x = din.as<double>();
+                double *o = dout.as<double>(), *p = pre_denoise ? dpre.as<double>() : nullptr;
+                rc = pipe.run(
+                    n_first,
+                    [&](int i, hipStream_t s) {
+                        const size_t off = (size_t)(b0[(size_t)i] * G), cnt = (size_t)((b1[(size_t)i] - b0[(size_t)i]) * G);
+                        g_hp.add(HP_H2D_BYTES, (double)cnt * 8.0);
+                        return hipMemcpyAsync(din.as<double>() + off, expr_in + off, cnt * sizeof(double), hipMemcpyHostToDevice, s);
+                    },
+                    [&](hipStream_t s) -> int {   // the reference rounds: every reference cell is on the device
+                        int r = ICNV_OK;
+                        for (int k = 0; k < rounds && !r; ++k) {
+                            r = icnv_chain_round_partial_dev(ch, k, x, nullptr, nullptr, s);
+                            if (!r) r = icnv_chain_round_finish_dev(ch, k, s);
+                        }
+                        return r;
+                    },
+                    [&](int i, hipStream_t s) -> int { return chain_apply_columns(ch, x, o, p, b0[(size_t)i], b1[(size_t)i], s); },
+                    [&](int i, hipStream_t s) {
+                        const size_t off = (size_t)(b0[(size_t)i] * G), cnt = (size_t)((b1[(size_t)i] - b0[(size_t)i]) * G);
+                        g_hp.add(HP_D2H_BYTES, (double)cnt * 8.0 * (pre_denoise ? 2.0 : 1.0));
+                        hipError_t e = hipMemcpyAsync(expr_out + off, o + off, cnt * sizeof(double), hipMemcpyDeviceToHost, s);
+                        if (e == hipSuccess && pre_denoise) e = hipMemcpyAsync(pre_denoise + off, p + off, cnt * sizeof(double), hipMemcpyDeviceToHost, s);
+                        return e;
+                    });
+                return rc;
+            }
+        }
         MatrixLease in;
         DevBuf dout, dpre;
         int rc;
         if ((rc = acquire_input(expr_in, n, nullptr, in))) return rc;
         if ((rc = dout.alloc((size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
         if (pre_denoise && (rc = dpre.alloc((size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
-        rc = icnv_smooth_chain_dev(in.dev, dout.as<double>(), pre_denoise ? dpre.as<double>() : nullptr, cfg, nullptr);
-        if (rc) return rc;
-        ICNV_HIP(hipMemcpy(expr_out, dout.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-        if (pre_denoise) ICNV_HIP(hipMemcpy(pre_denoise, dpre.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        {
+            WallTimer t(HP_DEV_MS);
+            rc = icnv_smooth_chain_dev(in.dev, dout.as<double>(), pre_denoise ? dpre.as<double>() : nullptr, cfg, nullptr);
+            if (rc) return rc;
+            ICNV_HIP(hipStreamSynchronize(nullptr));
+        }
+        if ((rc = timed_d2h(expr_out, dout.p, (size_t)n * sizeof(double), nullptr))) return rc;
+        if (pre_denoise && (rc = timed_d2h(pre_denoise, dpre.p, (size_t)n * sizeof(double), nullptr))) return rc;
         publish_output(expr_out, n, std::move(dout));
         if (pre_denoise) publish_output(pre_denoise, n, std::move(dpre));
         return ICNV_OK;
@@ -567,8 +823,45 @@ int icnv_viterbi_cells(const double *expr, uint8_t *states, int64_t G, int64_t C
         bad_total += bad;
         return ICNV_OK;
     };
+    WallTimer wall(HP_WALL_MS);
+    g_hp.add(HP_CALLS, 1.0);
     int rc;
-    if (nd == 1) rc = block(0, C, nullptr);
+    if (nd == 1 && !g_res_on.load() && host_pipeline_enabled() && G * C * 8 >= (64ll << 20) && C >= 1024) {
+        // one device, no residency: upload | Viterbi | download of the states pipelined over column blocks
+        std::vector<int64_t> b0, b1;
+        int n_first = 0;
+        pipeline_blocks(G, C, nullptr, b0, b1, n_first);
+        DevBuf din, ds, dn;
+        const size_t n = (size_t)G * (size_t)C;
+        if ((rc = din.alloc(n * sizeof(double))) || (rc = ds.alloc(n)) || (rc = dn.alloc(sizeof(int32_t)))) return rc;
+        HostPipeline pipe;
+        if ((rc = pipe.open((int)b0.size()))) return rc;
+        int32_t bad = 0;
+        rc = pipe.run(
+            0,
+            [&](int i, hipStream_t s) {
+                const size_t off = (size_t)(b0[(size_t)i] * G), cnt = (size_t)((b1[(size_t)i] - b0[(size_t)i]) * G);
+                g_hp.add(HP_H2D_BYTES, (double)cnt * 8.0);
+                return hipMemcpyAsync(din.as<double>() + off, expr + off, cnt * sizeof(double), hipMemcpyHostToDevice, s);
+            },
+            [&](hipStream_t s) -> int {
+                ICNV_HIP(hipMemsetAsync(dn.p, 0, sizeof(int32_t), s));
+                return ICNV_OK;
+            },
+            [&](int i, hipStream_t s) -> int {
+                const int64_t c0 = b0[(size_t)i], c1 = b1[(size_t)i];
+                return icnv_viterbi_cells_dev(din.as<double>() + c0 * G, ds.as<uint8_t>() + c0 * G, G, c1 - c0, chr_start, n_chr, K, mean, sd_shared,
+                                              logPi, logDelta, dn.as<int32_t>(), s);
+            },
+            [&](int i, hipStream_t s) {
+                const size_t off = (size_t)(b0[(size_t)i] * G), cnt = (size_t)((b1[(size_t)i] - b0[(size_t)i]) * G);
+                g_hp.add(HP_D2H_BYTES, (double)cnt);
+                return hipMemcpyAsync(states + off, ds.as<uint8_t>() + off, cnt, hipMemcpyDeviceToHost, s);
+            });
+        if (rc) return rc;
+        ICNV_HIP(hipMemcpy(&bad, dn.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+        bad_total += bad;
+    } else if (nd == 1) rc = block(0, C, nullptr);
     else
         rc = on_devices(nd, [&](int w, hipStream_t s, int rc0) -> int {
             if (rc0) return rc0;

@@ -29,6 +29,7 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 int pool_alloc(void **p, size_t bytes);
 void pool_free(void *p);
 void set_pool_part(int part);
+double pool_malloc_ms(bool reset);   // wall time the pool spent in hipMalloc since the last reset
 struct DevBuf {  // RAII over the pool
     void *p = nullptr;
     DevBuf() = default;
@@ -59,6 +60,10 @@ int viterbi_groups_host_one(const double *expr, uint8_t *states, int64_t G, int6
                             const double *sd_shared_per_grp, const double *logPi, const double *logDelta);
 int median_filter_host_one(const double *expr_in, double *expr_out, int64_t G, int64_t C, const int32_t *chr_start, int32_t n_chr,
                            const int32_t *tile_idx, const int32_t *tile_off, int32_t n_tiles, int32_t window_size);
+// api.hip: the fused apply pass over the columns [c0, c1) of the chain's matrix (the reference statistics are in place);
+// -1000 when this chain needs the whole-matrix call (three-pass chain, noise_logistic, HMM input without a denoise stage)
+int chain_apply_columns(icnv_chain_t *ch, const double *expr_in, double *expr_out, double *pre_denoise, int64_t c0, int64_t c1,
+                        hipStream_t s);
 bool residency_release_idle();   // host_path.hip: hand the idle resident matrices of this pool domain back to the pool
 void viterbi_release_contexts();  // api.hip: device tables / pinned words / events of the per-device Viterbi state
 

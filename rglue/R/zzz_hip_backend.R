@@ -341,7 +341,7 @@ hip_ingest_counts <- function(infercnv_obj, min_mean_expr_cutoff, min_cells_per_
 ## on the host at memory speed): editing expr.data between steps, or R reusing a freed address, cannot serve stale
 ## device data -- a changed matrix hashes differently and is uploaded.
 .icnv_enable_hip_backend <- function(devices = getOption("infercnv.hip.devices", 0L),
-                                     residency = getOption("infercnv.hip.residency", TRUE)) {
+                                     residency = getOption("infercnv.hip.residency", FALSE)) {
     .Call("icnv_R_init", as.integer(devices), as.logical(residency))
     ns <- asNamespace("infercnv")
     swap <- c(subtract_ref_expr_from_obs = "hip_subtract_ref_expr_from_obs",

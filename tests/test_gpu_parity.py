@@ -103,7 +103,11 @@ def test_chain_fused_vs_oracle(dev, G, C, nref):
 # (genes, window, kernel variant the geometry rules of chain_kernels.hip pick): the run-time-window and the
 # compile-time-window (101) forms of 1024 x 11 / five slots and 768 x 15 / seven slots, and 768 x 15 / eight slots
 @pytest.mark.parametrize("G,window,variant", [(9000, 61, "w11"), (10060, 101, "w11t"), (10400, 41, "m15s"),
-                                              (10300, 101, "m15t"), (10900, 21, "m15")])
+                                              (10300, 101, "m15t"), (10900, 21, "m15"),
+                                              # round 5: chunk lengths 17 / 19 / 21 with fitted slot counts between the 10 000-gene
+                                              # geometries and 768 x 23 (even G: (L - 1) / 2 gene-pair slots; odd G: one gene per slot)
+                                              (11000, 101, "m17 / 8 slots"), (11001, 101, "m17 odd"), (12400, 101, "m19 / 9 slots"),
+                                              (14000, 101, "m21 / 10 slots"), (14001, 61, "m21 odd"), (16000, 101, "m23 / 11 slots")])
 def test_chain_geometries_and_windows(dev, G, window, variant):
     """Every (threads x chunk length, slots, window form) variant of the fused kernel against the oracle: the full chain,
     the chain without denoise, and stage subsets that run the generic (run-time mask) kernels of the same geometry."""
