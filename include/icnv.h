@@ -63,6 +63,11 @@ extern "C" {
 #define ICNV_ST_DENOISE        0x40u /* step 22 clear_noise_via_ref_mean_sd / clear_noise :2232-2346 */
 #define ICNV_ST_ALL            0x7Fu
 #define ICNV_ST_CENTER_MEAN    0x80u /* modifier: step 11 subtracts the mean instead of the median */
+#define ICNV_ST_NA_AWARE       0x100u /* modifier: the matrix may hold NA / NaN.  The cells that do are recomputed with the reference's
+                                         NA semantics (csrc/chain_na.hip: step 8 / 12 with bounds turn an NA into 0, the smoothing strips
+                                         and re-inserts NAs per chromosome, the centre is taken over the values present,
+                                         R/inferCNV_ops.R:1757-1768, 2098, 2487-2489, 2529); costs one extra pass over the input.  Without
+                                         it a NaN is not looked for (run()'s chain input, log2(x + 1) of counts, has none) */
 
 /* ---- library state ------------------------------------------------------ */
 int icnv_version(void);

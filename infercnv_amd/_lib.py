@@ -23,6 +23,7 @@ ST_INVERT_LOG2 = 0x20
 ST_DENOISE = 0x40
 ST_ALL = 0x7F
 ST_CENTER_MEAN = 0x80
+ST_NA_AWARE = 0x100     # the matrix may hold NaN: cells that do are recomputed with the reference's NA semantics
 
 OK, ERR_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_UNDERFLOW, ERR_NOMEM = 0, 1, 2, 3, 4, 5
 

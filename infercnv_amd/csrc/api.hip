@@ -282,6 +282,8 @@ struct icnv_chain {
     // Reference-cell cache: the round that first runs the expensive stages (smoothing, centring) on the reference
     // cells keeps its output (one column per position of ref_idx), so that the later rounds and the apply pass
     // continue from it instead of smoothing the same cells again (three times per chain otherwise).
+    bool na_aware = false;            // ICNV_ST_NA_AWARE: cells that hold a NaN are recomputed by chain_na.hip
+    DevBuf d_naflags;
     bool cache_enabled = false;
     DevBuf d_cache, d_nonref, d_iota;   // d_iota: 0 .. n_ref - 1 (the cache holds one column per position of ref_idx)
     std::vector<int32_t> nonref;      // cells that are in no reference group
@@ -370,6 +372,7 @@ int icnv_chain_begin(icnv_chain_t **out, const icnv_chain_cfg *cfg) {
     icnv_chain *ch = new icnv_chain();
     ch->cfg = *cfg;
     ch->mask = mask;
+    ch->na_aware = (cfg->stage_mask & ICNV_ST_NA_AWARE) != 0;
     ch->T = (mask & ICNV_ST_SMOOTH) ? (cfg->window_length - 1) / 2 : 0;
     for (int k = 0; k < cfg->n_chr; ++k) ch->max_chr_len = std::max(ch->max_chr_len, cfg->chr_start[k + 1] - cfg->chr_start[k]);
     {
@@ -378,6 +381,10 @@ int icnv_chain_begin(icnv_chain_t **out, const icnv_chain_cfg *cfg) {
         if (ch->large && cfg->inv_log) {
             delete ch;
             ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "inv_log is not available for gene sets that need the three-pass chain");
+        }
+        if (ch->na_aware && (ch->large || cfg->inv_log || cfg->noise_logistic)) {
+            delete ch;
+            ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "ICNV_ST_NA_AWARE is built for the fused chain (not the three-pass chain, inv_log or noise_logistic)");
         }
         if (ch->large && chain_large_lds_bytes(ch->max_chr_len, ch->T) > 152 * 1024) {
             delete ch;
@@ -435,6 +442,7 @@ static int chain_upload(icnv_chain *ch, hipStream_t s) {
         }
     }
     if ((rc = upload(ch->d_ref_off, ch->ref_off.data(), ch->ref_off.size(), s))) return rc;
+    if (ch->na_aware && (rc = ch->d_naflags.alloc((size_t)std::max<int64_t>(ch->cfg.C, 1)))) return rc;
     if (ch->large) {
         ch->cache_enabled = false;
         if (!ch->ref_idx.empty() && (rc = ch->d_large_tmp.alloc(ch->ref_idx.size() * (size_t)G * sizeof(double)))) return rc;
@@ -608,6 +616,8 @@ int icnv_chain_round_partial_dev(icnv_chain_t *ch, int round, const double *expr
         a.out_by_pos = 1;
         const int rc2 = launch_chain(a, MODE_APPLY, s);
         if (rc2) return rc2;
+        // (reference cells that hold a NaN: their cached columns redone with the reference's NA semantics before they are summed)
+        if (ch->na_aware && (rc = launch_chain_na_fixup(a, ch->max_chr_len, ch->d_naflags.as<uint8_t>(), s))) return rc;
         if ((rc = launch_group_gene_sums(ch->d_cache.as<double>(), (int32_t)G, ch->d_iota.as<int32_t>(), ch->d_ref_off.as<int32_t>(), ng,
                                          ch->d_partial.as<double>(), 256, sums, s)))
             return rc;
@@ -678,13 +688,18 @@ static int chain_apply_masked(icnv_chain_t *ch, uint32_t amask, const double *ex
     const bool from_cache = ch->cache_in == expr_in && ch->cache_mask != 0 && (ch->cache_mask & ~amask) == 0;
     const uint32_t cached = ch->cache_mask;
     ch->cache_in = nullptr;
+    auto launch_apply = [&](const ChainArgs &args) -> int {   // the fused pass, then -- ICNV_ST_NA_AWARE -- the cells that hold a NaN again
+        int r = launch_chain(args, MODE_APPLY, s);
+        if (!r && ch->na_aware) r = launch_chain_na_fixup(args, ch->max_chr_len, ch->d_naflags.as<uint8_t>(), s);
+        return r;
+    };
     auto run = [&](ChainArgs args) -> int {
-        if (!from_cache) return launch_chain(args, MODE_APPLY, s);
+        if (!from_cache) return launch_apply(args);
         int r = ICNV_OK;
         if (!ch->nonref.empty()) {
             args.cells = ch->d_nonref.as<int32_t>();
             args.n_cells = (int32_t)ch->nonref.size();
-            if ((r = launch_chain(args, MODE_APPLY, s))) return r;
+            if ((r = launch_apply(args))) return r;
         }
         args.in = ch->d_cache.as<double>();
         args.in_by_pos = 1;
@@ -725,7 +740,7 @@ namespace icnv {
 int chain_apply_columns(icnv_chain_t *ch, const double *expr_in, double *expr_out, double *pre_denoise, int64_t c0, int64_t c1,
                         hipStream_t s) {
     if (!ch || !expr_in || !expr_out) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
-    if (ch->large || ((ch->mask & ICNV_ST_DENOISE) && ch->cfg.noise_logistic) || (pre_denoise && !(ch->mask & ICNV_ST_DENOISE))) return -1000;
+    if (ch->large || ch->na_aware || ((ch->mask & ICNV_ST_DENOISE) && ch->cfg.noise_logistic) || (pre_denoise && !(ch->mask & ICNV_ST_DENOISE))) return -1000;
     if (c1 <= c0) return ICNV_OK;
     int rc = chain_upload(ch, s);
     if (rc) return rc;

@@ -145,13 +145,18 @@ __global__ void bounds_from_sums_kernel(const double *sc, int G, int n_grp, int 
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
     double lo = 0.0, hi = 0.0, tot = 0.0;
+    bool any_nan = false;
     for (int r = 0; r < n_grp; ++r) {
         double m = sc[(int64_t)r * G + g] / sc[(int64_t)n_grp * G + r];
         if (inv_log) m = log2(m + 1.0);   // the sums are over 2^x - 1 (R/inferCNV_ops.R:1716)
         if (r == 0) { lo = m; hi = m; }
         else { lo = fmin(lo, m); hi = fmax(hi, m); }
+        any_nan = any_nan || (m != m);
         tot += m;
     }
+    // R's min() / max() return NA when a group mean is NA (a reference cell with an NA at this gene): fmin / fmax would drop it.
+    // With NaN bounds step 8 / 12 turn the whole gene into 0, as which(x > NA) selects nothing (R/inferCNV_ops.R:1757-1768)
+    if (any_nan) { lo = tot; hi = tot; }   // (tot is NaN)
     if (use_bounds) {
         bounds[g] = lo;
         bounds[G + g] = hi;

@@ -117,6 +117,9 @@ struct ChainArgs {
 };
 
 int launch_chain(const ChainArgs &a, int mode, hipStream_t stream);
+// chain_na.hip: the list positions of `a` whose input column holds a NaN, recomputed with the reference's NA semantics
+// (same arguments as the apply launch it follows; flags_ws: a.n_cells bytes of workspace)
+int launch_chain_na_fixup(const ChainArgs &a, int32_t max_chr_len, uint8_t *flags_ws, hipStream_t stream);
 int chain_max_genes();
 bool chain_fused_fits(int64_t G, int32_t n_chr, int32_t T);   // does the LDS-resident fused kernel take this geometry?
 

@@ -29,6 +29,8 @@ def _run_chain(obj: InfercnvObject, stage_mask, *, window_length=101, max_thresh
     perm, chr_start = obj.chr_layout()
     x = _as_f(obj.expr_data if perm is None else obj.expr_data[perm])
     G, C = x.shape
+    if np.isnan(x).any():      # NA values: the cells that hold one are recomputed with the reference's NA semantics (csrc/chain_na.hip)
+        stage_mask = int(stage_mask) | _lib.ST_NA_AWARE
     cfg = Cfg(G, C, chr_start, obj.ref_groups_or_proxy(), window_length, max_thresh, use_bounds, sd_amplifier,
               noise_filter, stage_mask, inv_log, noise_logistic)
     out = np.empty_like(x, order="F")

@@ -359,6 +359,40 @@ def run_chain(expr, chr_codes, ref_groups, window_length=101, max_centered_thres
     return (x, pre) if return_pre_denoise else x
 
 
+def smooth_by_chromosome_na(expr, chr_codes, window_length):
+    """smooth_by_chromosome on a matrix with NAs: every chromosome of more than one gene goes through .smooth_helper cell by
+    cell, which strips and re-inserts the cell's NAs (R/inferCNV_ops.R:2406-2434, 2487-2489, 2529)."""
+    out = np.array(expr, dtype=np.float64, copy=True)
+    for idx in chr_segments(chr_codes):
+        if idx.size > 1:
+            for c in range(out.shape[1]):
+                out[idx, c] = smooth_window_na(expr[idx, c], window_length)
+    return out
+
+
+def run_chain_na(expr, chr_codes, ref_groups, window_length=101, max_centered_threshold=3.0, sd_amplifier=1.5,
+                 use_bounds=True, denoise=True, return_pre_denoise=False):
+    """run_chain on a matrix that holds NAs, the way the reference's step functions treat them: `.subtract_expr` with bounds
+    selects by which(x > hi) / which(x < lo) -- an NA (value or bound) is never selected, the entry comes out as 0
+    (R/inferCNV_ops.R:1757-1768; the boolean masks of subtract_expr above do exactly that) --, `x[x > thr] <- thr` leaves an
+    NA alone (:2974-2975), the smoothing strips and re-inserts NAs, the centre is median(na.rm = TRUE) (:2098), 2^NA = NA and
+    step 22's which(x > lo & x < hi) never selects one (:2335)."""
+    with np.errstate(invalid="ignore"):
+        x = subtract_expr(expr, get_normal_gene_mean_bounds(expr, ref_groups), use_bounds)       # step 8
+        if max_centered_threshold is not None:
+            x = apply_max_threshold_bounds(x, max_centered_threshold)                            # step 9
+        x = smooth_by_chromosome_na(x, chr_codes, window_length)                                 # step 10
+        x = center_columns_na(x)                                                                 # step 11
+        x = subtract_expr(x, get_normal_gene_mean_bounds(x, ref_groups), use_bounds)             # step 12
+        x = invert_log2(x)                                                                       # step 14
+        pre = x
+        if denoise:
+            ref_idx = np.concatenate([np.asarray(g) for g in ref_groups])
+            mu, s = clear_noise_params_via_ref_mean_sd(x, ref_idx, sd_amplifier)
+            x = clear_noise_bounds(x, mu, s)                                                     # step 22
+    return (x, pre) if return_pre_denoise else x
+
+
 # --------------------------------------------------------------------------
 # A.5 pnorm(q>=0, log.p=TRUE, lower.tail=FALSE)  (R nmath pnorm_both, Cody 1969)
 # --------------------------------------------------------------------------

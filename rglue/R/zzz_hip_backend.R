@@ -40,10 +40,13 @@
     if (!is.matrix(x)) x <- as.matrix(x)                 # dgCMatrix -> dense, like R/inferCNV_ops.R:1924-1926
     if (is.unsorted(lay$perm)) x <- x[lay$perm, , drop = FALSE]
     if (storage.mode(x) != "double") storage.mode(x) <- "double"
-    ## the kernels treat NA as a NaN value; the reference strips NAs (.smooth_helper, median(na.rm = TRUE)) -- DESIGN.md section 2
-    if (anyNA(x)) stop("the hip backend does not take matrices with NA / NaN; impute them or use options(infercnv.backend = 'R')")
     x
 }
+## 0x100 = ICNV_ST_NA_AWARE: the matrix holds NAs -- the library recomputes the cells that do with the reference's NA semantics
+## (.smooth_helper strips and re-inserts them, median(na.rm = TRUE), which() never selects one: csrc/chain_na.hip).  The
+## steps that are not the chain (HMM, median filter, step 5 / 16) have no NA semantics in the reference either: they stop.
+.icnv_na_flag <- function(x) if (anyNA(x)) 256L else 0L
+.icnv_no_na <- function(x, what) if (anyNA(x)) stop(sprintf("%s: the matrix holds NA / NaN values", what)) else x
 .icnv_unpermute <- function(m, lay) if (is.null(m) || !is.unsorted(lay$perm)) m else m[order(lay$perm), , drop = FALSE]
 
 .icnv_chain <- function(infercnv_obj, mask, window_length = 101L, max_thresh = NA_real_, use_bounds = TRUE,
@@ -54,7 +57,7 @@
     x <- .icnv_matrix(infercnv_obj, lay)
     res <- .Call("icnv_R_smooth_chain", x, lay$chr_start, ref$idx, ref$off, as.integer(window_length),
                  as.numeric(max_thresh), as.logical(use_bounds), as.numeric(sd_amplifier),
-                 as.numeric(noise_filter), as.integer(sum(mask)), as.logical(want_pre), as.logical(inv_log),
+                 as.numeric(noise_filter), as.integer(sum(mask) + .icnv_na_flag(x)), as.logical(want_pre), as.logical(inv_log),
                  as.logical(noise_logistic))
     lapply(res, .icnv_unpermute, lay = lay)
 }
@@ -158,7 +161,7 @@ hip_smooth_chain <- function(infercnv_obj, window_length = 101, max_centered_thr
 
 .icnv_hmm_states <- function(infercnv_obj, HMM_info, sd, groups = NULL) {
     lay <- .icnv_chr_layout(infercnv_obj)
-    x <- .icnv_matrix(infercnv_obj, lay)
+    x <- .icnv_no_na(.icnv_matrix(infercnv_obj, lay), "HMM (the reference's Viterbi has no NA handling either)")
     pm <- HMM_info[["state_emission_params"]]
     logPi <- log(HMM_info[["state_transitions"]]); logDelta <- log(HMM_info[["delta"]])
     st <- if (is.null(groups)) {
@@ -292,7 +295,7 @@ hip_apply_median_filtering <- function(infercnv_obj, window_size = 7, on_observa
     if (on_references) tiles <- c(tiles, infercnv_obj@reference_grouped_cell_indices)
     lay <- .icnv_chr_layout(infercnv_obj)
     tl <- .icnv_pack(tiles)
-    x <- .icnv_matrix(infercnv_obj, lay)
+    x <- .icnv_no_na(.icnv_matrix(infercnv_obj, lay), "apply_median_filtering")
     out <- .Call("icnv_R_median_filter", x, lay$chr_start, tl$idx, tl$off, as.integer(window_size))
     infercnv_obj@expr.data <- .icnv_unpermute(out, lay)
     infercnv_obj

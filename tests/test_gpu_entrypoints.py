@@ -117,6 +117,27 @@ def test_config1_example_run_inputs_through_the_hip_path(dev, run_inputs):
         assert (samples.expr_data[np.ix_(rows, ref)] == 3).mean() > 0.9
 
 
+@pytest.mark.parametrize("which", ["B", "C"])
+def test_hmm_states_rda_through_the_hip_path(dev, golden_dir, which):
+    """The reference's only HMM artefact, data/HMM_states.rda, through the HIP path: counts of the example object -> steps
+    3, 4 -> fused chain -> group means -> i6 Viterbi per group (C ABI, device-resident) with a parameter set that reproduces
+    the fixture (tests/test_hmm_pin.py::HMM_STATES_PINS, found by scripts/fit_hmm_pin.py): all 9 226 group-gene calls equal."""
+    import oracle_np as onp
+    from test_hmm_pin import HMM_STATES_PINS
+    d = np.load(os.path.join(golden_dir, "infercnv_object_example.npz"))
+    gold = np.load(os.path.join(golden_dir, "hmm_states_example.npz"))["HMM_states"].astype(np.uint8)
+    log = onp.log2xplus1(onp.normalize_counts_by_seq_depth(d["count_data"]))
+    cs = oc.chr_starts_from_codes(d["chr_codes"])
+    _, pre = dev.smooth_chain(to_dev(log), cs, [d["ref_normal"]], want_pre_denoise=True)
+    groups = [d["obs_tumor"], d["ref_normal"]]
+    Pi, delta = onp.get_HMM_i6(1e-6)
+    mu, sd = HMM_STATES_PINS[which]
+    st, bad = dev.viterbi_groups(pre, cs, groups, np.array(mu), [sd, sd], np.log(Pi), np.log(delta))
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0
+    np.testing.assert_array_equal(to_host(st), gold)
+
+
 def test_below_min_mean_expr_cutoff_reference_literals_through_the_hip_path(dev):
     """tests/testthat/test_infer_cnv.R:175-220 through ops.require_above_min_mean_expr_cutoff -> icnv_gene_stats /
     icnv_select_genes: the genes the reference's literal answers list are the ones removed."""

@@ -1307,6 +1307,80 @@ def test_chain_missing_values_policy_against_the_reference_semantics(dev):
     assert np.abs(to_host(pre)[:, clean] - want_pre[:, clean]).max() < 1e-11
 
 
+@pytest.mark.parametrize("case", ["full_chain", "no_bounds", "smooth_only", "centre_median", "centre_mean", "nan_in_reference_cell"])
+def test_chain_na_aware_reference_semantics(dev, case):
+    """ICNV_ST_NA_AWARE (round 5): the cells that hold a NaN come out the way the reference's step functions treat an NA
+    (oracle_np.run_chain_na: R/inferCNV_ops.R:1757-1768 which() never selects an NA -> 0 with bounds; :2974-2975 the clamp
+    leaves it alone; :2487-2489, 2529 the smoothing strips and re-inserts NAs per chromosome; :2098 median(na.rm = TRUE);
+    2^NA = NA; :2335 step 22 never selects it), every other cell as always.  NaNs at chromosome starts and ends, runs of them,
+    a whole chromosome of one cell, a cell with a single value left on a chromosome, in observation and in reference cells."""
+    from infercnv_amd import synth, _lib
+    G, C = 1500, 40
+    x, cs = synth.make_matrix_np(G, C)
+    x = x - 1.5
+    refs = [np.arange(0, 4, dtype=np.int32), np.arange(4, 9, dtype=np.int32)]
+    chr_codes = np.repeat(np.arange(len(cs) - 1), np.diff(cs))
+    xn = x.copy()
+    rng = np.random.default_rng(len(case))
+    xn[400, 12] = np.nan                                       # a single NA
+    xn[cs[3], 15] = np.nan; xn[cs[4] - 1, 15] = np.nan         # first and last gene of a chromosome
+    xn[600:640, 17] = np.nan                                   # a run
+    xn[cs[5]:cs[6], 20] = np.nan                               # a whole chromosome of one cell
+    xn[cs[7]:cs[8] - 1, 21] = np.nan                           # one value left on a chromosome
+    xn[rng.integers(0, G, 60), 25] = np.nan                    # scattered
+    xn[:, 30] = np.nan                                         # a cell of nothing but NAs
+    if case == "nan_in_reference_cell":
+        xn[700, 2] = np.nan                                    # the gene's reference mean is NA: with bounds the whole gene comes out 0
+        xn[900:905, 6] = np.nan
+    na = _lib.ST_NA_AWARE
+    xd = to_dev(xn)
+    if case in ("full_chain", "no_bounds", "nan_in_reference_cell"):
+        ub = case != "no_bounds"
+        out, pre = dev.smooth_chain(xd, cs, refs, use_bounds=ub, stage_mask=0x7F | na, want_pre_denoise=True)
+        want, want_pre = onp.run_chain_na(xn, chr_codes, refs, use_bounds=ub, return_pre_denoise=True)
+        got_pre, got = to_host(pre), to_host(out)
+        assert np.array_equal(np.isnan(got_pre), np.isnan(want_pre)), case
+        if ub:
+            assert not np.isnan(want_pre[:, :30]).any() and np.isnan(want_pre[:, 30]).sum() == 0   # with bounds step 8 turns every NA into 0
+        ok = ~np.isnan(want_pre)
+        assert np.abs(got_pre[ok] - want_pre[ok]).max() < 1e-11, case
+        if not np.isnan(want).all():
+            mu, s = onp.clear_noise_params_via_ref_mean_sd(want_pre, np.concatenate(refs), 1.5)
+            if np.isfinite(mu) and np.isfinite(s):
+                fin = ~np.isnan(want).any(axis=0)
+                check_denoise_flips(got[:, fin], want[:, fin], want_pre[:, fin], mu, s, tol=1e-11, label=f"NA-aware {case}")
+            assert np.array_equal(np.isnan(got), np.isnan(want))
+    elif case == "smooth_only":
+        got = to_host(dev.smooth_chain(xd, cs, refs, stage_mask=0x04 | na)[0])
+        want = onp.smooth_by_chromosome_na(xn, chr_codes, 101)
+        assert np.array_equal(np.isnan(got), np.isnan(xn))                      # exactly the NA positions stay NA
+        ok = ~np.isnan(want)
+        assert np.abs(got[ok] - want[ok]).max() < 1e-11
+    else:
+        mask = 0x08 if case == "centre_median" else 0x88
+        got = to_host(dev.smooth_chain(xd, cs, refs, stage_mask=mask | na)[0])
+        with np.errstate(invalid="ignore"), __import__("warnings").catch_warnings():
+            __import__("warnings").simplefilter("ignore")
+            want = onp.center_columns_na(xn) if case == "centre_median" else None
+        if case == "centre_median":
+            ok = ~np.isnan(want)
+            assert np.array_equal(np.isnan(got), np.isnan(xn))
+            assert np.abs(got[ok] - want[ok]).max() == 0.0                      # the median of the values present, exactly
+        else:
+            with np.errstate(invalid="ignore"), __import__("warnings").catch_warnings():
+                __import__("warnings").simplefilter("ignore")
+                m = np.nanmean(xn, axis=0)
+            want = xn - m[None, :]
+            ok = ~np.isnan(want)
+            assert np.array_equal(np.isnan(got), np.isnan(xn))
+            assert np.abs(got[ok] - want[ok]).max() < 1e-12
+    # without the flag nothing changes for the cells that hold no NaN (they never went through the slow path)
+    clean = [c for c in range(C) if not np.isnan(xn[:, c]).any()]
+    if case == "full_chain":
+        _, pre0 = dev.smooth_chain(to_dev(x), cs, refs, stage_mask=0x7F, want_pre_denoise=True)
+        assert np.abs(to_host(pre)[:, clean] - to_host(pre0)[:, clean]).max() < 1e-11
+
+
 # ------------------------------------------------------------------ ragged and degenerate layouts (round 4)
 @pytest.mark.parametrize("sizes,C", [
     ((1, 2, 15, 16, 17, 31, 33, 1, 129, 255, 3), 200),      # single-gene chromosomes (state 3, R/inferCNV_HMM.R:1104-1107), lengths around the 16-gene block

@@ -198,6 +198,114 @@ def test_sharded_chain_two_ranks_gloo(tmp_path):
         assert f"rank {r} ok" in o
 
 
+WORKER8 = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "oracle")); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, torch.distributed as dist
+import oracle_np as onp, oracle_c as oc
+from parity_util import check_denoise_flips
+from infercnv_amd import sharded, synth
+oc.set_num_threads(1)
+W = int(sys.argv[4])
+
+class Engine:
+    """device.ChainPlan's four methods: the expensive stages by the C oracle (one thread), the elementwise ones in NumPy;
+    the partial statistics are plain fp64 sums over THIS rank's reference cells -- what the all-reduce then adds in rank order."""
+    def __init__(self, G, cs, refs_local):
+        self.G, self.cs, self.refs, self.num_rounds = G, cs, refs_local, 3
+        self.b1 = self.b2 = self.den = None
+    def _upto(self, x, stage):
+        v = x
+        if stage >= 1:
+            v = onp.apply_max_threshold_bounds(onp.subtract_expr(v, self.b1, True), 3.0)
+            v = oc.center_columns(oc.smooth_by_chromosome(v, self.cs, 101), "median")
+        if stage >= 2: v = onp.invert_log2(onp.subtract_expr(v, self.b2, True))
+        return v
+    def round_partial(self, r, x):
+        v = self._upto(x, r)
+        if r < 2:
+            sums = [v[:, g].sum(axis=1) if len(g) else np.zeros(self.G) for g in self.refs]
+            self.buf = torch.from_numpy(np.concatenate(sums + [np.array([float(len(g)) for g in self.refs])]))
+        else:
+            idx = np.concatenate(self.refs).astype(int)
+            vals = v[:, idx]
+            self.buf = torch.tensor([vals.sum(), vals.std(axis=0, ddof=1).sum() if idx.size else 0.0, float(idx.size), float(idx.size * self.G)], dtype=torch.float64)
+        return self.buf
+    def round_finish(self, r):
+        b = self.buf.numpy()
+        if r < 2:
+            n = len(self.refs)
+            m = (b[:self.G * n].reshape(n, self.G) / b[self.G * n:][:, None]).T
+            if r == 0: self.b1 = m
+            else: self.b2 = m
+        else:
+            self.den = (b[0] / b[3], b[1] / b[2] * 1.5)
+    def apply(self, x, out=None, want_pre_denoise=False):
+        pre = self._upto(x, 2)
+        return onp.clear_noise_bounds(pre, *self.den), pre
+
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=W)
+rank = dist.get_rank()
+G, C = 2000, 4000
+cs = synth.chr_layout(G)
+mine = sharded.cyclic_cells(C, W, rank)                               # the round-robin deal of bench.py --gpus N
+x_mine = np.concatenate([synth.make_matrix_np(G, 1, cell_offset=int(c), C_total=C)[0] for c in mine], axis=1)
+refs, _ = synth.groups(C)
+eng = Engine(G, cs, sharded.localize_groups_cyclic(refs, rank, W))
+out, pre = sharded.ShardedChain(eng).run(x_mine, want_pre_denoise=True)
+# the ONE-rank run of the same engine on the same cells: the reference cells' statistics summed in one go (no rank order)
+ref_all = np.concatenate(refs)
+x_ref = np.concatenate([synth.make_matrix_np(G, 1, cell_offset=int(c), C_total=C)[0] for c in ref_all], axis=1)
+off = np.concatenate([[0], np.cumsum([len(r) for r in refs])])
+one = Engine(G, cs, [np.arange(off[i], off[i + 1]) for i in range(len(refs))])
+for r in range(3):
+    one.round_partial(r, x_ref); one.round_finish(r)
+one_out, one_pre = one.apply(x_mine)
+d_pre = float(np.abs(pre - one_pre).max())
+assert d_pre < 1e-12, d_pre                                             # sums in another order: rounding only
+mu, s = one.den
+flips = check_denoise_flips(out, one_out, one_pre, mu, s, tol=1e-12, label=f"{W} ranks vs one, rank {rank}")
+means, sd, logPi, logDelta = synth.hmm_params_i6()
+st, _ = oc.viterbi_cells(pre, cs, means, sd, logPi, logDelta)
+st1, _ = oc.viterbi_cells(one_pre, cs, means, sd, logPi, logDelta)
+mism = int((st != st1).sum())
+tot = torch.tensor([float(flips), float(mism), float(out.size), d_pre], dtype=torch.float64)
+mx = tot.clone()
+dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+if rank == 0:
+    print(f"WORLD{W}: {int(tot[0])} legal step-22 flips and {int(tot[1])} differing state calls in {int(tot[2])} elements; max |pre - pre_1rank| {float(mx[3]):.2e}")
+assert mism == 0
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_sharded_chain_eight_ranks_vs_one_rank_gloo(tmp_path):
+    """What N ranks change against one: the reference statistics are all-reduced -- partial sums added in rank order --, so the
+    bounds of steps 8 / 12 and the step-22 parameters differ from the one-rank sums in their last bits.  Eight gloo ranks
+    (cells dealt round-robin like bench.py --gpus 8) against the same engine on one rank: the pre-denoise matrix within
+    1e-12, every step-22 difference a legal flip on a bound (counted and printed: 0 expected at 8e6 elements, 0-3 per 1e8),
+    the i6 state calls IDENTICAL."""
+    script = tmp_path / "worker8.py"
+    script.write_text(WORKER8)
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    W = 8
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(port), str(r), str(W)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(W)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
+        assert f"rank {r} ok" in o
+    line = [l for l in outs[0].splitlines() if l.startswith("WORLD8")]
+    assert line, outs[0][-2000:]
+    print(line[0])
+
+
 def test_median_network_header_is_generated_and_verified():
     """median9x9_net.h (the min/max networks of the 9 x 9 median filter) is exactly what gen_median_net.py writes; the
     generator checks every network first: sort9 exhaustively (0-1 principle), the single-output, two-rank (padded
