@@ -460,7 +460,7 @@ def run_group_config(args, world, rank):
     elapsed = time.perf_counter() - t0
     device.timing_enable(False)
     no_ties_ms = None
-    if args.config == 5:
+    if args.config == 5 and not args.no_side_legs:
         step_no_ties()
         fence()
         t1 = time.perf_counter()
@@ -524,6 +524,8 @@ def main():
     ap.add_argument("--cells", type=int, default=50000, help="cells per GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-side-legs", action="store_true",
+                    help="only the warm-up and the timed steps (profiling runs: no extra launches on other data, e.g. config 5's no-ties input)")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5),
                     help="BASELINE.json config: 2 (default) fused smooth chain + per-cell i6 HMM, 50 000 cells per GPU (weak scaling) -- the "
                          "headline metric; 3 the same step on BASELINE configs[2]: --total-cells (1 000 000) cells IN TOTAL dealt over the "

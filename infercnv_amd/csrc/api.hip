@@ -581,7 +581,8 @@ int icnv_chain_round_partial_dev(icnv_chain_t *ch, int round, const double *expr
         }
         if (nref > 0) {
             // from the cache only the elementwise steps 12 / 14 are left: one streaming pass instead of the chain geometry
-            const bool elementwise = a.in_by_pos && cache_cell_stats_covers((int32_t)G) &&
+            const char *force_chain = std::getenv("ICNV_CELL_STATS_CHAIN");   // developer / test switch: 1 = the chain geometry for this round too
+            const bool elementwise = a.in_by_pos && cache_cell_stats_covers((int32_t)G) && !(force_chain && force_chain[0] == '1') &&
                                      (a.mask & ~(uint32_t)(ICNV_ST_SUBTRACT_REF_2 | ICNV_ST_INVERT_LOG2 | ICNV_ST_CENTER_MEAN)) == 0;
             if (elementwise) rc = launch_cache_cell_stats(a.in, (int32_t)G, nref, a.mask, a.b2, a.cell_stats, s);
             else rc = launch_chain(a, MODE_CELL_STATS, s);

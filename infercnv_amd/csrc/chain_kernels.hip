@@ -214,7 +214,7 @@ __device__ inline double exp2_lean_cs(double x) {   // chain_kernel.inc: exp2_le
     p = __builtin_fma(p, f, 1.0);
     return __builtin_ldexp(p, (int)n);
 }
-constexpr int CS_NT = 512, CS_NS = 10, CS_GRP = 2;   // 256 threads x 20 gene pairs = up to 10 240 (even) genes per cell
+constexpr int CS_NT = 512, CS_NS = 10, CS_GRP = 2;   // 512 threads x 10 gene pairs = up to 10 240 (even) genes per cell
 __global__ void __launch_bounds__(CS_NT) __attribute__((amdgpu_waves_per_eu(4, 8))) cache_cell_stats_kernel(const double *__restrict__ cache, int G, int n_cells, uint32_t mask,
                                                                   const double *__restrict__ b2, double *__restrict__ cell_stats) {
     __shared__ double red[CS_NT / 64];

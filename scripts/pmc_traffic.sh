@@ -14,7 +14,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
       python $R/scripts/ablate_chain.py 50000 copyonly > $OUT/copy_$C.log 2>&1
   for c in 4 5; do    # BASELINE configs 4 (group HMM) and 5 (median filter): 1 warm-up + 2 steps = 3 steps per run
     timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -o cfg$c -- \
-        python $R/bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $OUT/cfg${c}_$C.log 2>&1
+        python $R/bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-side-legs > $OUT/cfg${c}_$C.log 2>&1
   done
 done
 ls -R $OUT | head -40

@@ -2,10 +2,10 @@
 # block), the rocprofv3 kernel-trace statistics of the same command, the HBM traffic counters (separate --pmc passes), the
 # memory-system microbenchmarks the ceilings in bench.py come from, the SQ / LDS counters of the fast Viterbi and of the
 # median filter, BASELINE configs 4 / 5, the host-buffer path.
-# usage (on the GPU box):  ICNV_COMMIT=<short hash> bash scripts/refresh_profiles.sh r04
+# usage (on the GPU box):  ICNV_COMMIT=<short hash> bash scripts/refresh_profiles.sh r05
 #   (the box has no .git: the commit travels in the environment and is written into every summary)
 set -x
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
@@ -25,7 +25,7 @@ python $R/scripts/rocprof_summary.py $O/prof/${TAG}_results.db > $O/${TAG}_kerne
 rm -f $O/prof/*.db      # (gpurun merges at most 64 MiB back: the summaries travel, the raw traces do not)
 for c in 4 5; do
   timeout 300 python $R/bench.py --config $c --no-cpu-baseline > $O/bench_config$c.json 2> $O/bench_config$c.err
-  timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof -o ${TAG}_config$c -- python $R/bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing > /dev/null 2> $O/prof/log_config$c.txt
+  timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof -o ${TAG}_config$c -- python $R/bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-side-legs > /dev/null 2> $O/prof/log_config$c.txt
   python $R/scripts/rocprof_summary.py $O/prof/${TAG}_config${c}_results.db > $O/${TAG}_kernel_stats_config$c.txt 2>&1
   rm -f $O/prof/*.db
 done
@@ -36,5 +36,8 @@ cp $R/gpurun_out/pmc_vitfast/summary.txt $O/${TAG}_pmc_viterbi_fast.txt; find $R
 timeout 600 bash $R/scripts/pmc_median.sh > $O/pmc_median_log.txt 2>&1
 cp $R/gpurun_out/pmc_median/summary.txt $O/${TAG}_pmc_median.txt; find $R/gpurun_out/pmc_median -name "*.db" -delete
 timeout 600 python $R/scripts/bench_configs.py > $O/configs_slices.json 2> $O/configs_slices.err
+# the north star's own shape on ONE GPU (BASELINE configs[2]: 10 000 x 1 000 000, parity on the matrix itself) and the (G, sigma) sweep
+timeout 400 python $R/bench.py --config 3 --steps 5 --warmup 2 > $O/bench_config3_n1.json 2> $O/bench_config3_n1.err
+timeout 600 python $R/scripts/sweep_shapes.py > $O/sweep.json 2> $O/sweep.err
 find $R/gpurun_out -name "*.db" -delete; du -sh $R/gpurun_out
 tail -1 $O/bench_full.json | cut -c1-400

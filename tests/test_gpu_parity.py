@@ -1381,6 +1381,34 @@ def test_chain_na_aware_reference_semantics(dev, case):
         assert np.abs(to_host(pre)[:, clean] - to_host(pre0)[:, clean]).max() < 1e-11
 
 
+@pytest.mark.parametrize("G,kw", [(10000, {}), (10240, {}), (6002, {}), (10000, {"stage_mask": 0x7F & ~0x20}), (10000, {"stage_mask": 0x7F & ~0x10})])
+def test_denoise_round_streaming_kernel_equals_chain_geometry(dev, G, kw, monkeypatch):
+    """The step-22 parameters (mean of the reference values, mean of the reference cells' sds) come from a streaming kernel over
+    the reference-cell cache when the remaining stages are elementwise (even G <= 10 240), from the chain geometry otherwise.
+    The two add in different orders: forced through the chain geometry (ICNV_CELL_STATS_CHAIN=1) the parameters must agree to
+    rounding, for the bench's gene count, the largest gene count the streaming kernel takes, a small even one, and chains
+    without step 14 / without step 12."""
+    from infercnv_amd import synth
+    C = 700
+    x, cs = synth.make_matrix_np(G, C)
+    refs, _ = synth.groups(C, ref_frac=0.2)
+    xd = to_dev(x)
+    def params():
+        plan = dev.ChainPlan(G, C, cs, refs, **kw)
+        for r in range(plan.num_rounds):
+            plan.round_partial(r, xd); plan.round_finish(r)
+        mu_s = plan.denoise_params()
+        plan.close()
+        return mu_s
+    monkeypatch.delenv("ICNV_CELL_STATS_CHAIN", raising=False)
+    a = params()
+    monkeypatch.setenv("ICNV_CELL_STATS_CHAIN", "1")
+    b = params()
+    assert abs(a[0] - b[0]) <= 1e-13 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-12 * abs(b[1]), (a, b)
+    want = oc.smooth_chain(x, cs, refs, want_pre_denoise=True, **kw)[2]
+    assert abs(a[0] - want[0]) <= 1e-12 and abs(a[1] - want[1]) <= 1e-12, (a, want)
+
+
 # ------------------------------------------------------------------ ragged and degenerate layouts (round 4)
 @pytest.mark.parametrize("sizes,C", [
     ((1, 2, 15, 16, 17, 31, 33, 1, 129, 255, 3), 200),      # single-gene chromosomes (state 3, R/inferCNV_HMM.R:1104-1107), lengths around the 16-gene block
