@@ -300,9 +300,15 @@ int icnv_viterbi_cells_dev(const double *expr, uint8_t *states, int64_t G, int64
  * flagged sequences with the exact kernel: the states are those of the exact kernel, bit for bit.
  * A column batch with more than 2 % of its sequences flagged is recomputed as a whole by the exact kernel instead
  * (decided on the device from that batch's own flag count: no state carries over from one call to the next).
- *   icnv_viterbi_set_mode   0 = auto (default), 1 = exact kernel only; process-wide
- *   icnv_viterbi_last_stats out4 = {path of the calling thread's device's last call (0 exact / 1 fast / 2 fast,
- *                           last column batch recomputed by the exact kernel), sequences, flagged sequences of
+ * Two kernels serve the fast path: the staged one (observations requested by whole cache lines through LDS-DMA, a short
+ * table: tails of >= 4 sd beyond the outer state means) is tried first; a column batch whose data leave its table is redone
+ * by the register kernel with the full table (tails up to 19 sd), and only a batch that still has > 2 % flagged goes to the
+ * exact kernel -- all decided on the device.
+ *   icnv_viterbi_set_mode   0 = auto (default), 1 = exact kernel only, 2 = auto without the staged kernel (developer A/B);
+ *                           process-wide
+ *   icnv_viterbi_last_stats out4 = {path of the calling thread's device's last call (0 exact / 1 fast, register kernel /
+ *                           2 fast, last column batch recomputed by the exact kernel / 3 fast, staged kernel / 4 staged
+ *                           kernel, last column batch redone with the full table), sequences, flagged sequences of
  *                           the last column batch, table intervals}; synchronises with that call
  *   icnv_hmm_emission_table host-only: the table for (K, mean, sd); meta8 = {n_records, x_lo, x_hi, eps_tab,
  *                           s_max, degree, 1, eps_spec}; seg_out [4] = the uniform grid {origin, 1/width, 0, grid

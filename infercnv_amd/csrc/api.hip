@@ -1084,7 +1084,7 @@ static void chr_order_longest_first(const int32_t *chr_start, int32_t n_chr, std
 // measured 8.9e-16 (tests/test_viterbi_fast_host.py::test_emission_spec_vs_exact), budgeted three orders of
 // magnitude higher: the band only grows from 9.4e-9 to 1.4e-8 for a 1 072-gene chromosome.
 static constexpr double EPS_SPEC = 1e-12;
-static std::atomic<int> g_viterbi_mode{0};   // 0 = auto (fast when eligible), 1 = exact kernel only (process-wide switch)
+static std::atomic<int> g_viterbi_mode{0};   // 0 = auto (fast when eligible), 1 = exact kernel only, 2 = auto without the staged fast kernel (process-wide switch)
 
 // A column batch of the certified fast path whose flagged sequences exceed this share is recomputed as a whole by the
 // lane-per-sequence exact kernel instead of sequence by sequence on the wave-per-sequence redo kernel (which wins only
@@ -1092,6 +1092,7 @@ static std::atomic<int> g_viterbi_mode{0};   // 0 = auto (fast when eligible), 1
 // launched, one of them returns at once): no state survives a call, so which kernels serve a call depends on that
 // call's data alone.
 static constexpr double REDO_MAX_SHARE = 0.02;
+static constexpr int STAGED_MIN_TAIL = 64;   // grid intervals (4 sd) the staged fast Viterbi's short table must reach beyond the outer state means
 
 namespace {
 // State of the per-cell Viterbi of ONE device: the emission table of the last (K, mean, sd), the task / flag counters,
@@ -1105,11 +1106,17 @@ struct ViterbiCtx {
     EmisTable tab;
     void *dev = nullptr;           // device image of the table, owned (hipMalloc)
     size_t dev_bytes = 0;
-    int32_t *counters = nullptr;   // [0] task counter, [1] flag count, device
+    // the short table of the staged kernel (observations through LDS, viterbi_fast.hip) behind the full one in `dev`
+    EmisTable tab_s;
+    bool staged = false;           // tab_s exists and its tails are long enough to try it first
+    size_t dev_s_off = 0;          // its offset in `dev` (bytes)
+    int32_t *counters = nullptr;   // [0] task counter, [1] flag count, [2] / [3] the same for the second attempt of a batch; device
     int32_t *host_flag = nullptr;  // pinned, receives the flag count of the last column batch
     hipEvent_t flag_ev = nullptr;
     int64_t stats[4] = {0, 0, 0, 0};   // last call: path (0 exact / 1 fast), sequences, flagged (-1: pending), table intervals
     int64_t flag_limit = 0;            // of the last column batch: more flagged sequences than this -> exact kernel
+    bool staged_last = false;          // the last call tried the staged kernel first
+    int32_t *host_flag1 = nullptr;     // pinned (behind host_flag): the staged attempt's own flag count of the last column batch
     // chromosome layout of the last call on the device ([n_chr + 1] starts, then [n_chr] chromosomes longest first): a
     // pipeline calls with one layout over and over, and two pageable uploads per call are two stalls of the stream
     std::map<std::vector<int32_t>, int32_t *> layouts;
@@ -1158,7 +1165,7 @@ void viterbi_release_contexts() {
         for (auto &kv2 : c.layouts) (void)hipFree(kv2.second);
         c.layouts.clear();
         c.d_layout = nullptr;
-        c.dev = nullptr; c.dev_bytes = 0; c.counters = nullptr; c.host_flag = nullptr; c.flag_ev = nullptr;
+        c.dev = nullptr; c.dev_bytes = 0; c.counters = nullptr; c.host_flag = nullptr; c.host_flag1 = nullptr; c.flag_ev = nullptr;
         c.valid = false;
     }
     (void)hipSetDevice(home);
@@ -1170,18 +1177,35 @@ void viterbi_release_contexts() {
 static int fast_table_for(ViterbiCtx &c, const HmmParams &p, double sd, hipStream_t s, bool &eligible) {
     eligible = false;
     if (!c.counters) {
-        ICNV_HIP(hipMalloc((void **)&c.counters, 2 * sizeof(int32_t)));
-        ICNV_HIP(hipHostMalloc((void **)&c.host_flag, sizeof(int32_t)));
-        *c.host_flag = 0;
+        ICNV_HIP(hipMalloc((void **)&c.counters, 4 * sizeof(int32_t)));
+        ICNV_HIP(hipHostMalloc((void **)&c.host_flag, 2 * sizeof(int32_t)));
+        c.host_flag[0] = c.host_flag[1] = 0;
+        c.host_flag1 = c.host_flag + 1;
         ICNV_HIP(hipEventCreateWithFlags(&c.flag_ev, hipEventDisableTiming));
     }
     if (!(c.valid && c.K == p.K && c.sd == sd && memcmp(c.mean, p.mean, sizeof(double) * p.K) == 0)) {
         c.valid = false;   // set again only once the table is built AND its device image is in place
         const char *why = nullptr;
-        const bool ok = build_emission_table(p.K, p.mean, sd, viterbi_fast_max_intervals(p.K), c.tab, &why) == 0;
+        const bool ok = build_emission_table(p.K, p.mean, sd, viterbi_fast_max_intervals(p.K, false), c.tab, &why) == 0;
+        c.staged = false;
         if (ok) {
             std::vector<double> img;
             viterbi_fast_table_image(c.tab, img);
+            // the staged kernel's table: the same grid, what fits next to its LDS buffers -- tried first when its tails reach
+            // STAGED_MIN_TAIL grid intervals (sd / 16 each) beyond the outer means (data that leave them flag their sequences;
+            // a batch with too many of those is redone with the full table)
+            const char *why_s = nullptr;
+            if (build_emission_table(p.K, p.mean, sd, viterbi_fast_max_intervals(p.K, true), c.tab_s, &why_s) == 0) {
+                const int n_tail = (c.tab_s.n_grid - (int)(std::ceil((p.mean[p.K - 1] - p.mean[0]) * c.tab_s.inv_w) + 1.0)) / 2;
+                if (n_tail >= STAGED_MIN_TAIL && c.tab_s.n_int < c.tab.n_int) {
+                    std::vector<double> img_s;
+                    viterbi_fast_table_image(c.tab_s, img_s);
+                    if (img.size() & 1) img.push_back(0.0);
+                    c.dev_s_off = img.size() * sizeof(double);
+                    img.insert(img.end(), img_s.begin(), img_s.end());
+                    c.staged = true;
+                }
+            }
             const size_t bytes = img.size() * sizeof(double);
             if (bytes > c.dev_bytes) {
                 if (c.dev) (void)hipFree(c.dev);
@@ -1251,13 +1275,16 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
     bool delta_ok = false;
     for (int k = 0; k < p.K; ++k) delta_ok = delta_ok || std::isfinite(p.logDelta[k]);
     for (int k = 0; k < p.K; ++k) delta_ok = delta_ok && !(std::isnan(p.logDelta[k]) || p.logDelta[k] == INFINITY);
-    if (g_viterbi_mode.load() == 0 && !sd_per_col_dev && ncols >= 64 && delta_ok && structured_pi(p, a, b)) {
+    if (g_viterbi_mode.load() != 1 && !sd_per_col_dev && ncols >= 64 && delta_ok && structured_pi(p, a, b)) {
         if ((rc = fast_table_for(vc, p, sd_shared, s, fast))) return rc;
     }
+    // observations through LDS (the staged kernel, its short table first, the full table for a batch that leaves it)?
+    const bool staged = fast && vc.staged && g_viterbi_mode.load() == 0 && G * 64 < ((int64_t)1 << 32);
     vc.stats[0] = fast ? 1 : 0;
     vc.stats[1] = ncols * n_chr;
     vc.stats[2] = fast ? -1 : 0;
-    vc.stats[3] = fast ? vc.tab.n_int : 0;
+    vc.stats[3] = fast ? (staged ? vc.tab_s.n_int : vc.tab.n_int) : 0;
+    vc.staged_last = staged;
 
     // Few sequences (the group modes: one column per subcluster / sample): the lane-per-sequence kernel would take
     // as long as its longest chromosome on one lane (~2 ms); the wave-per-sequence kernel -- the redo kernel run
@@ -1319,8 +1346,6 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
         fa.chr_start = dev_chr;
         fa.chr_order = dev_ord;
         fa.n_chr = n_chr;
-        fa.table = (const double *)vc.dev;
-        fa.n_int = vc.tab.n_int;
         double dmax = 0.0;
         for (int k = 0; k < p.K; ++k) {
             fa.mean[k] = p.mean[k];
@@ -1329,24 +1354,47 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
         }
         fa.a = a;
         fa.b = b;
-        fa.x_lo = vc.tab.x_lo;
-        fa.x_hi = vc.tab.x_hi;
-        fa.inv_w = vc.tab.inv_w;
-        fa.n_grid = vc.tab.n_grid;
-        fa.eps = vc.tab.eps_tab + 2.0 * EPS_SPEC;   // table: s_k - s_1; the exact kernel's difference carries two of its errors
         fa.b0 = dmax + std::fabs(a);
-        fa.s_step = vc.tab.s_max + std::fabs(b);
         fa.bp = d_bp.as<uint16_t>();
-        fa.task_counter = vc.counters;
-        fa.flag_count = vc.counters + 1;
         fa.flag_list = d_list.as<int32_t>();
-        ICNV_HIP(hipMemsetAsync(vc.counters, 0, 2 * sizeof(int32_t), s));
-        if ((rc = launch_viterbi_fast(fa, p.K, s))) return rc;
+        auto use_table = [&](const EmisTable &t, size_t off) {
+            fa.table = (const double *)((const char *)vc.dev + off);
+            fa.n_int = t.n_int;
+            fa.n_grid = t.n_grid;
+            fa.x_lo = t.x_lo;
+            fa.x_hi = t.x_hi;
+            fa.inv_w = t.inv_w;
+            fa.eps = t.eps_tab + 2.0 * EPS_SPEC;   // table: s_k - s_1; the exact kernel's difference carries two of its errors
+            fa.s_step = t.s_max + std::fabs(b);
+        };
         // flagged sequences: a short list goes to the wave-per-sequence redo kernel; a batch with more than
         // REDO_MAX_SHARE of its sequences flagged (data the table cannot score, or riddled with exact ties) is
         // recomputed as a whole by the lane-per-sequence exact kernel.  Both are launched, the flag count -- on the
         // device -- decides which of them does the work.
         const int32_t limit = (int32_t)std::min<double>(REDO_MAX_SHARE * (double)(nc * n_chr), 2e9);
+        ICNV_HIP(hipMemsetAsync(vc.counters, 0, 4 * sizeof(int32_t), s));
+        const bool staged_here = staged && nc >= 64;
+        if (staged_here) {
+            // first attempt: the staged kernel with its short table ...
+            use_table(vc.tab_s, vc.dev_s_off);
+            fa.task_counter = vc.counters;
+            fa.flag_count = vc.counters + 1;
+            if ((rc = launch_viterbi_fast(fa, p.K, true, s))) return rc;
+            ICNV_HIP(hipMemcpyAsync(vc.host_flag1, fa.flag_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            // ... and, only if it flagged more than the redo kernel takes (observations beyond the short table's tails), the
+            // register kernel with the full table over the whole batch; otherwise that launch hands the first count on
+            use_table(vc.tab, 0);
+            fa.gate_count = vc.counters + 1;
+            fa.gate_limit = limit;
+            fa.task_counter = vc.counters + 2;
+            fa.flag_count = vc.counters + 3;
+            if ((rc = launch_viterbi_fast(fa, p.K, false, s))) return rc;
+        } else {
+            use_table(vc.tab, 0);
+            fa.task_counter = vc.counters;
+            fa.flag_count = vc.counters + 1;
+            if ((rc = launch_viterbi_fast(fa, p.K, false, s))) return rc;
+        }
         if ((rc = launch_viterbi_redo(fa.x, fa.states, (int32_t)G, dev_chr, p, nullptr, sd_shared, fa.flag_count,
                                       fa.flag_list, limit, d_redo.as<uint32_t>(), n_underflow_dev, max_len, "viterbi_redo", s)))
             return rc;
@@ -1361,7 +1409,8 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
 }
 
 int icnv_viterbi_set_mode(int mode) {
-    if (mode != 0 && mode != 1) ICNV_FAIL(ICNV_ERR_ARG, "mode must be 0 (auto) or 1 (exact kernel only)");
+    if (mode != 0 && mode != 1 && mode != 2)
+        ICNV_FAIL(ICNV_ERR_ARG, "mode must be 0 (auto), 1 (exact kernel only) or 2 (auto without the staged fast kernel)");
     g_viterbi_mode.store(mode);
     return ICNV_OK;
 }
@@ -1373,7 +1422,11 @@ int icnv_viterbi_last_stats(int64_t *out4) {
     if (vc.stats[0] >= 1 && vc.flag_ev) {
         ICNV_HIP(hipEventSynchronize(vc.flag_ev));
         vc.stats[2] = *vc.host_flag;   // of the last column batch
-        vc.stats[0] = (vc.stats[2] > vc.flag_limit) ? 2 : 1;   // 2: that batch was recomputed by the exact kernel
+        // 2: that batch was recomputed by the exact kernel; 3: the staged kernel did it; 4: the staged kernel flagged too many
+        // sequences (data beyond its short table) and the register kernel redid the batch with the full table
+        if (vc.stats[2] > vc.flag_limit) vc.stats[0] = 2;
+        else if (vc.staged_last) vc.stats[0] = (*vc.host_flag1 > vc.flag_limit) ? 4 : 3;
+        else vc.stats[0] = 1;
     }
     for (int i = 0; i < 4; ++i) out4[i] = vc.stats[i];
     return ICNV_OK;
@@ -1386,7 +1439,7 @@ int icnv_hmm_emission_table(int32_t K, const double *mean, double sd, double *me
     if (K != 3 && K != 6) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "K must be 3 or 6");
     EmisTable t;
     const char *why = "";
-    if (build_emission_table(K, mean, sd, viterbi_fast_max_intervals(K), t, &why) != 0)
+    if (build_emission_table(K, mean, sd, viterbi_fast_max_intervals(K, false), t, &why) != 0)
         ICNV_FAIL(ICNV_ERR_UNSUPPORTED, std::string("parameters not eligible for the fast Viterbi path: ") + why);
     meta8[0] = t.n_int; meta8[1] = t.x_lo; meta8[2] = t.x_hi; meta8[3] = t.eps_tab;
     meta8[4] = t.s_max; meta8[5] = EMIS_DEG; meta8[6] = 1; meta8[7] = EPS_SPEC;
@@ -1410,7 +1463,7 @@ int icnv_hmm_emission_scores(int32_t K, const double *mean, double sd, const dou
     }
     EmisTable t;
     const char *why = "";
-    if (build_emission_table(K, mean, sd, viterbi_fast_max_intervals(K), t, &why) != 0)
+    if (build_emission_table(K, mean, sd, viterbi_fast_max_intervals(K, false), t, &why) != 0)
         ICNV_FAIL(ICNV_ERR_UNSUPPORTED, std::string("parameters not eligible for the fast Viterbi path: ") + why);
     for (int64_t i = 0; i < n; ++i) {
         const bool ok = emission_table_eval(t, mean, x[i], out + i * K);

@@ -219,12 +219,14 @@ struct FastViterbiArgs {
     int32_t *task_counter;      // zeroed before the launch
     int32_t *flag_count;        // zeroed before the launch
     int32_t *flag_list;         // [2 * n_chr * ncols] (chromosome, column) pairs
+    const int32_t *gate_count;  // null, or: the flag count of a first attempt on this batch -- the kernel runs only if it
+    int32_t gate_limit;         // exceeds gate_limit, and hands it on as its own count otherwise
 };
 size_t viterbi_fast_scratch_bytes(int32_t G, int32_t n_chr, int64_t n_cols);
-size_t viterbi_fast_lds_bytes(int K, int n_int, int n_grid);
-int viterbi_fast_max_intervals(int K);
+size_t viterbi_fast_lds_bytes(int K, int n_int, int n_grid, bool staged);
+int viterbi_fast_max_intervals(int K, bool staged);   // staged: the variant that streams the observations through LDS (shorter table)
 void viterbi_fast_table_image(const EmisTable &t, std::vector<double> &img);
-int launch_viterbi_fast(const FastViterbiArgs &a, int K, hipStream_t stream);
+int launch_viterbi_fast(const FastViterbiArgs &a, int K, bool staged, hipStream_t stream);
 int viterbi_redo_slots();
 size_t viterbi_redo_scratch_bytes(int32_t max_chr_len);
 int launch_viterbi_redo(const double *x, uint8_t *states, int32_t G, const int32_t *chr_start_dev, const HmmParams &p,

@@ -144,7 +144,19 @@ __device__ inline uint32_t near_top_bits<3>(const double (&e)[3], double t2) {
         : "vcc");
     return b;
 }
-template <int K>
+// STAGE (round 5): the observations of a chunk reach the lanes THROUGH LDS.  A lane that walks a column of its own asks for
+// 16 bytes of each of 64 cache lines per request, eight requests per line; the memory system serves that pattern at 2.8-3.7
+// TB/s (scripts/ubench/column_walk).  Requested BY ROWS -- request q fetches the eight lines of the columns 8 q .. 8 q + 7
+// whole, eight lanes x 16 bytes per line -- the same 64 lines arrive at 4.6 TB/s, and at 5.5 TB/s when the requests are LDS-DMA
+// (global_load_lds_dwordx4: lane l's 16 bytes land at M0 + 16 l, no registers, no write instructions): the eight lines of a
+// request lie behind each other in the wavefront's 8 KiB buffer, column after column, and every lane reads its own column
+// back with eight ds_read_b128.  Within a line the eight fetching lanes are permuted (pair p of column r of request q sits
+// at slot 8 r + (p ^ f), f = (r >> 1) | ((q & 1) << 2)) so that the sixteen lanes of a ds_read_b128 pass hit sixteen
+// different bank groups.  Price: 12 x 8 KiB of the LDS, i.e. a table of 256 instead of 694 records (shorter tails; a batch
+// whose data leave them is redone with the full table by the register variant -- gate_count below).
+// The DMA is issued from inline asm: the compiler's wait-count pass knows no alias information for LDS and would make
+// every table gather behind a DMA wait for it (a chunk's HBM latency exposed sixteen times per chunk instead of hidden).
+template <int K, bool STAGE>
 __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbiArgs A_in) {
     // The descriptor (~60 dwords) is read from the kernel-argument segment where it is used (scalar loads) instead of living
     // in scalar registers for the whole launch: held, it does not fit next to the loop state, the allocator parks it in
@@ -163,6 +175,15 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         ap = (ArgsK)ap_bits_;                                                                             \
     } while (0)
     extern __shared__ __attribute__((aligned(16))) double tab[];
+    if (A.gate_count) {
+        // second attempt of a batch (the full table after the staged kernel's short one): only if the first one flagged more
+        // sequences than the redo kernel takes; otherwise its count is handed on and nothing runs
+        const int32_t first = *A.gate_count;
+        if (first <= A.gate_limit) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) *A.flag_count = first;
+            return;
+        }
+    }
     {
         const int n_dbl = A.n_int * rec_doubles(K) + 2 * A.n_grid;   // the records, then the grid entries
         const double2 *src = reinterpret_cast<const double2 *>(A.table);
@@ -182,8 +203,19 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         task = __builtin_amdgcn_readfirstlane(task);
         if (task >= n_tasks) break;
         const int chr = A.chr_order[task / ncg];
-        const int64_t col = (task % ncg) * 64 + lane;
-        if (col >= A.ncols) continue;
+        int64_t col0 = (task % ncg) * 64;
+        bool dup = false;   // STAGE: this lane repeats a column of the task in front (its results are identical, it flags nothing)
+        if constexpr (STAGE) {
+            // every lane fetches for other lanes: the last, partial group of columns is served as the 64 LAST columns of
+            // the matrix (launch_viterbi_fast: ncols >= 64), overlapping its predecessor
+            const int64_t last0 = A.ncols - 64;
+            if (col0 > last0) {
+                dup = last0 + lane < col0;
+                col0 = last0;
+            }
+        }
+        const int64_t col = col0 + lane;
+        if (!STAGE && col >= A.ncols) continue;
         const int s0 = A.chr_start[chr];
         const int n = A.chr_start[chr + 1] - s0;
         const double *xc = A.x + col * (int64_t)A.G + s0;
@@ -396,7 +428,68 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         // the chunks are the 16-gene blocks of the summaries when the observations' line alignment and the states' 16-byte
         // alignment go together (always, for G a multiple of 16 and aligned matrices): a block then ends with a chunk
         const bool use_sum = a0_uniform && ((a0u + i) & (CH - 1)) == 0;
-        if (i + CH <= n) {
+        if constexpr (STAGE) {
+            static_assert(!STAGE || CH == 16, "a chunk is one 128-byte line per column");
+            if (i + CH <= n) {
+                double xcur[CH];
+                // this wavefront's buffer: 64 columns x 128 bytes behind the table
+                const int n_dbl = A.n_int * rec_doubles(K) + 2 * A.n_grid;
+                const double *wbuf = tab + ((n_dbl + 1) & ~1) + (threadIdx.x >> 6) * 1024;
+                const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(
+                    (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)wbuf);
+                // what this lane reads back: its own column = line (lane & 7) of request (lane >> 3)
+                const uint32_t rq = (uint32_t)lane >> 3, rr = (uint32_t)lane & 7u;
+                const uint32_t rf = (rr >> 1) | ((rq & 1u) << 2);
+                const char *rb = reinterpret_cast<const char *>(wbuf) + rq * 1024u + rr * 128u;
+                // what this lane fetches in request q: 16 bytes (pair fp ^ f) of the column 8 q + (lane >> 3)
+                const uint32_t fr = (uint32_t)lane >> 3, fp = (uint32_t)lane & 7u;
+                const uint32_t voff_e = (fr * (uint32_t)A.G + 2u * (fp ^ (fr >> 1))) * 8u;
+                const uint32_t voff_o = (fr * (uint32_t)A.G + 2u * (fp ^ ((fr >> 1) | 4u))) * 8u;
+                const double *xt = A.x + col0 * (int64_t)A.G + s0;   // (wave-uniform) gene 0 of the task's first column
+                const int64_t qstride = 8 * (int64_t)A.G;
+                auto request = [&](int gi) {
+                    const double *tb = xt + gi;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        // (M0 is not in the clobber list -- the compiler reserves it and warns; nothing else in this kernel uses it)
+                        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                                     :
+                                     : "s"(lds_wave + (uint32_t)q * 1024u), "v"((q & 1) ? voff_o : voff_e), "s"(tb + q * qstride)
+                                     : "memory");
+                    }
+                };
+                request(i);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (; i + CH <= n; i += CH) {
+                    // the chunk is in the buffer (waited for in front of the previous chunk's last gene, or above)
+#pragma unroll
+                    for (int p = 0; p < CH / 2; ++p) {
+                        const dbl2_t v = *reinterpret_cast<const dbl2_t *>(rb + (((uint32_t)p ^ rf) << 4));
+                        xcur[2 * p] = v.x;
+                        xcur[2 * p + 1] = v.y;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every lane has its column: the buffer is free
+                    const bool more = i + 2 * CH <= n;
+                    // the observation behind the chunk: the next chunk's first, or -- last chunk -- the tail's first gene, if any
+                    // (requested here; one load address that is either LDS or global would become a flat load, whose wait
+                    // drains every outstanding store)
+                    double xb_g = 0.0;
+                    if (more) request(i + CH);
+                    else xb_g = xc[(i + CH < n) ? i + CH : i + CH - 1];
+#pragma unroll
+                    for (int j = 0; j + 1 < CH; ++j) gene(xcur[j + 1], i + j);
+                    // (fifteen back-pointer stores were issued behind the DMA; the counter returns in order)
+                    if (more) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+                    const double xb_l = *reinterpret_cast<const double *>(rb + (rf << 4));   // (the old chunk's when there is no next)
+                    const double x_behind = more ? xb_l : xb_g;
+                    gene(x_behind, i + CH - 1);
+                    if (use_sum && ((a0u + i + CH) & 15) == 0) {
+                        bsum[((a0u + i) >> 4) * 64] = (uint16_t)sacc;
+                        sacc = 0;
+                    }
+                }
+            }
+        } else if (i + CH <= n) {
             // the chunk behind the current one is requested before the current one's genes run: one chunk (16 gene steps) of lead.
             // (Two buffers taking turns without the copy -- the loop body twice -- measured 5 % slower: 2.10 against 2.00 ms.)
             double xcur[CH], xnext[CH];
@@ -449,7 +542,7 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             else viterbi_traceback<FAST_TG>(st, n, cur, load_bp, step_bp);
             unsure |= (uacc >> 9) & 1u;
         }
-        if (unsure) {
+        if (unsure && !dup) {
             const int e = atomicAdd(A.flag_count, 1);
             A.flag_list[2 * (int64_t)e] = chr;
             A.flag_list[2 * (int64_t)e + 1] = (int32_t)col;
@@ -466,10 +559,14 @@ size_t viterbi_fast_scratch_bytes(int32_t G, int32_t n_chr, int64_t n_cols) {   
     // G rows of back-pointer words, then the block summaries: (G >> 4) + 3 n_chr rows (see the kernel)
     return ((size_t)G + (size_t)(G >> 4) + 3 * (size_t)n_chr + 1) * (size_t)((n_cols + 63) / 64 * 64) * sizeof(uint16_t);
 }
-size_t viterbi_fast_lds_bytes(int K, int n_int, int n_grid) { return ((size_t)n_int * rec_doubles(K) + 2 * (size_t)n_grid) * sizeof(double); }
-int viterbi_fast_max_intervals(int K) {
+constexpr size_t FAST_STAGE_BYTES = (size_t)(FAST_NT / 64) * 8192;   // staged variant: 64 columns x 128 bytes per wavefront
+size_t viterbi_fast_lds_bytes(int K, int n_int, int n_grid, bool staged) {
+    const size_t n_dbl = (size_t)n_int * rec_doubles(K) + 2 * (size_t)n_grid;
+    return ((n_dbl + 1) & ~(size_t)1) * sizeof(double) + (staged ? FAST_STAGE_BYTES : 0);
+}
+int viterbi_fast_max_intervals(int K, bool staged) {
     // records the LDS can hold, each with its 16-byte grid entry; 8 KiB of the 160 KiB are left to the runtime
-    return (int)((152 * 1024) / ((size_t)rec_doubles(K) * sizeof(double) + 16));
+    return (int)((152 * 1024 - (staged ? FAST_STAGE_BYTES : 0)) / ((size_t)rec_doubles(K) * sizeof(double) + 16));
 }
 
 // Device image of the table: the coefficient records, then the grid entries {boundary, {rec, 0}}.
@@ -494,25 +591,35 @@ void viterbi_fast_table_image(const EmisTable &t, std::vector<double> &img) {
     if (img.size() & 1) img.push_back(0.0);   // the kernel copies 16 bytes at a time
 }
 
-int launch_viterbi_fast(const FastViterbiArgs &a, int K, hipStream_t stream) {
+int launch_viterbi_fast(const FastViterbiArgs &a, int K, bool staged, hipStream_t stream) {
     if (a.ncols <= 0 || a.n_chr <= 0) return ICNV_OK;
-    const size_t lds = (viterbi_fast_lds_bytes(K, a.n_int, a.n_grid) + 15) & ~(size_t)15;
+    const size_t lds = (viterbi_fast_lds_bytes(K, a.n_int, a.n_grid, staged) + 15) & ~(size_t)15;
     if (lds > 160 * 1024) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "emission table does not fit the LDS");
+    if (staged && a.ncols < 64) ICNV_FAIL(ICNV_ERR_ARG, "the staged fast Viterbi needs at least 64 columns");
+    if (staged && (int64_t)a.G * 8 * 8 >= ((int64_t)1 << 32)) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "too many genes for the staged fast Viterbi");
     const int64_t ncg = (a.ncols + 63) / 64;
     const int64_t tasks = ncg * a.n_chr;
     if (tasks > 0x7fffff00) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "too many Viterbi tasks for one launch");
     int grid = num_cus();
     const int64_t need = (tasks + FAST_NT / 64 - 1) / (FAST_NT / 64);
     if (grid > need) grid = (int)need;
-    KernelTimer kt("viterbi", stream);
-    if (K == 6) {
+    KernelTimer kt(a.gate_count ? "viterbi_full_table" : "viterbi", stream);
+    if (K == 6 && staged) {
+        static DeviceOnce once6s;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(viterbi_fast_kernel<6, true>), 160 * 1024, once6s)) return rc;
+        hipLaunchKernelGGL((viterbi_fast_kernel<6, true>), dim3(grid), dim3(FAST_NT), lds, stream, a);
+    } else if (K == 3 && staged) {
+        static DeviceOnce once3s;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(viterbi_fast_kernel<3, true>), 160 * 1024, once3s)) return rc;
+        hipLaunchKernelGGL((viterbi_fast_kernel<3, true>), dim3(grid), dim3(FAST_NT), lds, stream, a);
+    } else if (K == 6) {
         static DeviceOnce once6;
-        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(viterbi_fast_kernel<6>), 160 * 1024, once6)) return rc;
-        hipLaunchKernelGGL(viterbi_fast_kernel<6>, dim3(grid), dim3(FAST_NT), lds, stream, a);
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(viterbi_fast_kernel<6, false>), 160 * 1024, once6)) return rc;
+        hipLaunchKernelGGL((viterbi_fast_kernel<6, false>), dim3(grid), dim3(FAST_NT), lds, stream, a);
     } else if (K == 3) {
         static DeviceOnce once3;
-        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(viterbi_fast_kernel<3>), 160 * 1024, once3)) return rc;
-        hipLaunchKernelGGL(viterbi_fast_kernel<3>, dim3(grid), dim3(FAST_NT), lds, stream, a);
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(viterbi_fast_kernel<3, false>), 160 * 1024, once3)) return rc;
+        hipLaunchKernelGGL((viterbi_fast_kernel<3, false>), dim3(grid), dim3(FAST_NT), lds, stream, a);
     } else {
         ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "fast Viterbi is built for K = 6 and K = 3");
     }

@@ -205,7 +205,8 @@ def viterbi_cells(x, chr_start, means, sd_shared, logPi, logDelta, states=None):
 
 
 def viterbi_set_mode(mode):
-    """0 = auto (certified fast path when the parameters are eligible), 1 = exact kernel only."""
+    """0 = auto (certified fast path when the parameters are eligible), 1 = exact kernel only, 2 = auto without the
+    staged fast kernel (developer A/B)."""
     check(_lib.load().icnv_viterbi_set_mode(int(mode)))
 
 
@@ -216,7 +217,10 @@ def viterbi_last_stats():
     buf = (ct.c_int64 * 4)()
     check(_lib.load().icnv_viterbi_last_stats(buf))
     return {"path": "fast" if buf[0] >= 1 else "exact", "sequences": int(buf[1]), "flagged": int(buf[2]),
-            "table_intervals": int(buf[3]), "fallback": buf[0] == 2}
+            "table_intervals": int(buf[3]), "fallback": buf[0] == 2,
+            # which fast kernel: "staged" (observations through LDS, short table), "register" (full table), "staged+register"
+            # (the staged kernel's batch left its table and was redone with the full one)
+            "kernel": {0: "exact", 1: "register", 2: "exact", 3: "staged", 4: "staged+register"}[int(buf[0])]}
 
 
 def viterbi_groups(x, chr_start, groups, means, sd_shared_per_group, logPi, logDelta, states=None):

@@ -509,17 +509,59 @@ def test_viterbi_fast_path_random_models(dev, seed):
         dev.viterbi_set_mode(0)
         st_fast, bad0 = dev.viterbi_cells(xd, cs, means, sd, np.log(Pi), np.log(delta))
         stats = dev.viterbi_last_stats()
+        dev.viterbi_set_mode(2)                              # the register kernel with the full table alone
+        st_reg, bad2 = dev.viterbi_cells(xd, cs, means, sd, np.log(Pi), np.log(delta))
+        stats_reg = dev.viterbi_last_stats()
         dev.viterbi_set_mode(1)
         st_exact, bad1 = dev.viterbi_cells(xd, cs, means, sd, np.log(Pi), np.log(delta))
     finally:
         dev.viterbi_set_mode(0)
-    assert stats["path"] == "fast"
+    assert stats["path"] == "fast" and stats_reg["path"] == "fast" and stats_reg["kernel"] in ("register", "exact")
     assert stats["flagged"] < 0.85 * stats["sequences"]      # a good share of the answers comes from the certified path itself
     assert torch.equal(st_fast, st_exact) and int(bad0.item()) == int(bad1.item())
+    assert torch.equal(st_reg, st_exact) and int(bad2.item()) == int(bad1.item())
     # a sample of columns against the CPU oracle as well
     pick = np.arange(0, C, 37)
     want, _ = oc.viterbi_cells(x[:, pick], cs, means, sd, np.log(Pi), np.log(delta))
     np.testing.assert_array_equal(st_fast.cpu().numpy().T[:, pick], want)
+
+
+def test_viterbi_staged_kernel_and_its_full_table_retry(dev):
+    """Round 5: the staged fast kernel (observations by whole cache lines through LDS-DMA, a 256-record table whose tails
+    end 4.9 sd beyond the outer means for the bench's HMM) runs first; a batch in which more than 2 % of the sequences
+    leave that table is redone by the register kernel with the full table (tails of 19 sd), fewer go to the redo kernel
+    one by one -- decided on the device.  States are the exact kernel's in every case; the column count is not a multiple
+    of 64 (the last group of columns is served as the LAST 64 columns, overlapping its predecessor)."""
+    from infercnv_amd import synth
+    pre, cs = _hmm_input(10000, 1061, seed=5)
+    means, sd, logPi, logDelta = synth.hmm_params_i6()
+    nseq = 22 * 1061
+    far = means[-1] + 8.0 * sd                      # beyond the staged table, well inside the full one
+    rng = np.random.default_rng(8)
+    few, many = pre.copy(), pre.copy()
+    few[rng.integers(0, 10000, 40), rng.choice(1061, 40, replace=False)] = far            # <= 40 sequences: 0.2 %
+    cols = rng.choice(1061, 400, replace=False)
+    for c in cols: many[rng.integers(0, 10000, 3), c] = far                                # ~1 100 sequences: 5 %
+    many[123, cols[:5]] = np.nan                                                           # ... five of them beyond any table
+    want_pre, _ = oc.viterbi_cells(pre, cs, means, sd, logPi, logDelta)
+    for name, x, kernel in (("plain", pre, "staged"), ("few", few, "staged"), ("many", many, "staged+register")):
+        xd = to_dev(x)
+        dev.viterbi_set_mode(0)
+        st0, _ = dev.viterbi_cells(xd, cs, means, sd, logPi, logDelta)
+        s0 = dev.viterbi_last_stats()
+        dev.viterbi_set_mode(2)
+        st2, _ = dev.viterbi_cells(xd, cs, means, sd, logPi, logDelta)
+        s2 = dev.viterbi_last_stats()
+        dev.viterbi_set_mode(1)
+        st1, _ = dev.viterbi_cells(xd, cs, means, sd, logPi, logDelta)
+        assert s0["path"] == "fast" and s0["kernel"] == kernel and not s0["fallback"], (name, s0)
+        assert s2["kernel"] == "register" and s2["table_intervals"] > 600, (name, s2)
+        assert s0["table_intervals"] < 300 and s0["sequences"] == nseq
+        if name == "few": assert 30 <= s0["flagged"] <= 60 and s2["flagged"] <= 5
+        if name == "many": assert 5 <= s0["flagged"] <= 20 and s0["flagged"] == s2["flagged"]     # what the full table leaves: the NaNs (+ chance ties)
+        assert torch.equal(st0, st1) and torch.equal(st2, st1), name
+        if name == "plain": np.testing.assert_array_equal(to_host(st0), want_pre)
+    dev.viterbi_set_mode(0)
 
 
 def test_viterbi_column_batches(dev, monkeypatch):
