@@ -48,7 +48,12 @@ def measure_ceilings():
     Built by __graft_entry__.build() (hipcc, in-tree, git-ignored).  Returns a dict; falls back to the tracked files."""
     import subprocess
     res = {}
+    cache = {}
     def run(name):
+        if name in cache: return cache[name]
+        cache[name] = _run(name)
+        return cache[name]
+    def _run(name):
         exe = os.path.join(ROOT, "scripts", "ubench", name)
         out = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=120, cwd="/tmp")
         if out.returncode != 0:
@@ -78,6 +83,17 @@ def measure_ceilings():
     except Exception as e:
         res["column_walk_gbs"] = 3660.0
         res["column_walk_source"] = f"profiles/r04_ubench_column_walk.txt (NOT measured in this run: {str(e)[:80]})"
+    try:
+        # the same lines requested by rows through LDS-DMA: what the staged fast Viterbi's observation stream can reach
+        best = None
+        for line in run("column_walk").splitlines():
+            if line.startswith("rows via LDS-DMA") and "TB/s" in line:
+                v = float(line.split()[-2]) * 1000.0
+                best = v if best is None else max(best, v)
+        if best:
+            res["row_requests_gbs"], res["row_requests_source"] = best, "scripts/ubench/column_walk quick (whole 128-byte lines by rows through LDS-DMA, 768 lanes per CU), measured in this run on this GPU"
+    except Exception:
+        pass
     return res
 
 
@@ -85,6 +101,7 @@ STREAM_1R2W_GBS, STREAM_1R2W_SOURCE = _stream_ceiling_from_file()     # replaced
 FP64_VECTOR_PEAK_TF = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 VITERBI_VALU_PER_GENE = 93.7   # SQ_INSTS_VALU / (genes x cells / 64), profiles/r04_pmc_viterbi_fast.txt
 COLUMN_WALK_GBS, COLUMN_WALK_SOURCE = 3660.0, "profiles/r04_ubench_column_walk.txt"   # replaced by measure_ceilings() in main()
+ROW_REQUESTS_GBS, ROW_REQUESTS_SOURCE = None, None                                     # set by measure_ceilings() in main()
 
 
 def source_stamp():
@@ -567,11 +584,12 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    global STREAM_1R2W_GBS, STREAM_1R2W_SOURCE, COLUMN_WALK_GBS, COLUMN_WALK_SOURCE
+    global STREAM_1R2W_GBS, STREAM_1R2W_SOURCE, COLUMN_WALK_GBS, COLUMN_WALK_SOURCE, ROW_REQUESTS_GBS, ROW_REQUESTS_SOURCE
     if rank == 0 and args.config in (2, 3) and not os.environ.get("ICNV_BENCH_NO_UBENCH"):
         ceil = measure_ceilings()                    # on this box, in this run, before any bench tensor exists
         STREAM_1R2W_GBS, STREAM_1R2W_SOURCE = ceil["stream_1r2w_gbs"], ceil["stream_1r2w_source"]
         COLUMN_WALK_GBS, COLUMN_WALK_SOURCE = ceil["column_walk_gbs"], ceil["column_walk_source"]
+        ROW_REQUESTS_GBS, ROW_REQUESTS_SOURCE = ceil.get("row_requests_gbs"), ceil.get("row_requests_source")
     if dist_on:
         dist.barrier()
 
@@ -718,14 +736,17 @@ def main():
                 "twice the cells per CU -- it is paced by the memory system, like the Viterbi it shares the step with")
         if "viterbi" in roof:
             st = device.viterbi_last_stats()
-            roof["viterbi"]["note"] = (f"certified fast path ({st['path']}; {st['flagged']} of {st['sequences']} sequences redone exactly): "
+            roof["viterbi"]["note"] = (f"certified fast path ({st['path']}, {st.get('kernel', '?')} kernel, {st['table_intervals']} table records; "
+                                       f"{st['flagged']} of {st['sequences']} sequences redone exactly): "
                                        "table-driven emission scores (degree-4 polynomials on a uniform grid) + max-plus recurrence, one lane per "
                                        "sequence, 768 threads (three wavefronts per SIMD), the gene step software-pipelined (gathers | decision "
-                                       "bookkeeping | rows), 86 vector + 14 LDS-gather + 18 scalar + 1 store instructions per gene and wavefront in "
-                                       "the forward pass, block summaries for the traceback.  What paces it (round 4, DESIGN.md K4b): the observation "
-                                       "stream -- every lane walks a column of its own, one 128-byte line per visit; `column_walk_ceiling` is that "
-                                       "pattern without arithmetic, measured in this run; with the observations served from L2 the 50 000-cell launch "
-                                       "takes 1.73 ms (ablation).  No MFMA-shaped work")
+                                       "bookkeeping | rows), 84 vector + 15 LDS + 18 scalar + 1 store instructions per gene and wavefront in "
+                                       "the forward pass, block summaries for the traceback.  Round 5 (DESIGN.md K4b): the STAGED kernel requests the "
+                                       "observations by whole cache lines -- eight 128-byte lines per request, LDS-DMA, every lane then reads its own "
+                                       "column out of the wavefront's 8 KiB buffer -- instead of every lane walking a column of its own: "
+                                       "`row_requests_ceiling` against `column_walk_ceiling` are the two patterns without arithmetic, both measured "
+                                       "in this run; with the observations served from L2 the 50 000-cell launch took 1.73 ms (round-4 ablation): "
+                                       "the launch is now paced by vector issue.  No MFMA-shaped work")
         if "viterbi" in roof:
             # second ceiling of the Viterbi (SURVEY.md 8d asks for HBM GB/s *and* the fp64 rate): vector instructions per gene and
             # wavefront (SQ_INSTS_VALU of the launch / gene steps, profiles/r04_pmc_viterbi_fast.txt; 86 of them in the forward pass
@@ -739,7 +760,12 @@ def main():
                                                      "clock (the chip holds ~2.05-2.1 GHz under this load)"}
             roof["viterbi"]["column_walk_ceiling"] = {"gbs": COLUMN_WALK_GBS, "source": COLUMN_WALK_SOURCE,
                                                       "frac_of_column_walk": 8.0 * G * C_local / COLUMN_WALK_GBS / 1e6 / kernels["viterbi"]["ms_per_step"],
-                                                      "ms_for_the_observations_alone": 8.0 * G * C_local / COLUMN_WALK_GBS / 1e6}
+                                                      "ms_for_the_observations_alone": 8.0 * G * C_local / COLUMN_WALK_GBS / 1e6,
+                                                      "note": "the register kernel's pattern (icnv_viterbi_set_mode(2); batches that leave the staged kernel's table)"}
+            if ROW_REQUESTS_GBS:
+                roof["viterbi"]["row_requests_ceiling"] = {"gbs": ROW_REQUESTS_GBS, "source": ROW_REQUESTS_SOURCE,
+                                                           "ms_for_the_observations_alone": 8.0 * G * C_local / ROW_REQUESTS_GBS / 1e6,
+                                                           "note": "the staged kernel's pattern"}
         dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
         if "chain_apply" in roof:
             moved = 3 * 8 * G * n_main            # one matrix read, two written (refined below by the counters when present)
@@ -783,7 +809,8 @@ def main():
                       "backend": (dist.get_backend() if dist_on else None),
                       "cells_per_rank": cells_per_rank, "cells_sum": int(sum(cells_per_rank))},
             "ceilings_measured_in_this_run": {"stream_1r2w_gbs": STREAM_1R2W_GBS, "stream_1r2w_source": STREAM_1R2W_SOURCE,
-                                              "column_walk_gbs": COLUMN_WALK_GBS, "column_walk_source": COLUMN_WALK_SOURCE},
+                                              "column_walk_gbs": COLUMN_WALK_GBS, "column_walk_source": COLUMN_WALK_SOURCE,
+                                              "row_requests_gbs": ROW_REQUESTS_GBS, "row_requests_source": ROW_REQUESTS_SOURCE},
             "roofline": roof.get(dominant) or (next(iter(roof.values())) if roof else None),
             "roofline_kernel": dominant,
             # the north star states its roofline target on the fused smooth pass: always there, whichever kernel is the

@@ -1110,13 +1110,13 @@ struct ViterbiCtx {
     EmisTable tab_s;
     bool staged = false;           // tab_s exists and its tails are long enough to try it first
     size_t dev_s_off = 0;          // its offset in `dev` (bytes)
-    int32_t *counters = nullptr;   // [0] task counter, [1] flag count, [2] / [3] the same for the second attempt of a batch; device
-    int32_t *host_flag = nullptr;  // pinned, receives the flag count of the last column batch
+    int32_t *counters = nullptr;   // device: [0], [1] task counters of the first / second attempt of a batch, [2], [3] their flag counts
+    int32_t *host_flag = nullptr;  // pinned [2], receives the flag counts of the last column batch: [0] the staged attempt's own
+                                   // (0 without one), [1] the one the redo / exact kernels acted on
     hipEvent_t flag_ev = nullptr;
     int64_t stats[4] = {0, 0, 0, 0};   // last call: path (0 exact / 1 fast), sequences, flagged (-1: pending), table intervals
     int64_t flag_limit = 0;            // of the last column batch: more flagged sequences than this -> exact kernel
     bool staged_last = false;          // the last call tried the staged kernel first
-    int32_t *host_flag1 = nullptr;     // pinned (behind host_flag): the staged attempt's own flag count of the last column batch
     // chromosome layout of the last call on the device ([n_chr + 1] starts, then [n_chr] chromosomes longest first): a
     // pipeline calls with one layout over and over, and two pageable uploads per call are two stalls of the stream
     std::map<std::vector<int32_t>, int32_t *> layouts;
@@ -1165,7 +1165,7 @@ void viterbi_release_contexts() {
         for (auto &kv2 : c.layouts) (void)hipFree(kv2.second);
         c.layouts.clear();
         c.d_layout = nullptr;
-        c.dev = nullptr; c.dev_bytes = 0; c.counters = nullptr; c.host_flag = nullptr; c.host_flag1 = nullptr; c.flag_ev = nullptr;
+        c.dev = nullptr; c.dev_bytes = 0; c.counters = nullptr; c.host_flag = nullptr; c.flag_ev = nullptr;
         c.valid = false;
     }
     (void)hipSetDevice(home);
@@ -1180,7 +1180,6 @@ static int fast_table_for(ViterbiCtx &c, const HmmParams &p, double sd, hipStrea
         ICNV_HIP(hipMalloc((void **)&c.counters, 4 * sizeof(int32_t)));
         ICNV_HIP(hipHostMalloc((void **)&c.host_flag, 2 * sizeof(int32_t)));
         c.host_flag[0] = c.host_flag[1] = 0;
-        c.host_flag1 = c.host_flag + 1;
         ICNV_HIP(hipEventCreateWithFlags(&c.flag_ev, hipEventDisableTiming));
     }
     if (!(c.valid && c.K == p.K && c.sd == sd && memcmp(c.mean, p.mean, sizeof(double) * p.K) == 0)) {
@@ -1378,21 +1377,20 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
             // first attempt: the staged kernel with its short table ...
             use_table(vc.tab_s, vc.dev_s_off);
             fa.task_counter = vc.counters;
-            fa.flag_count = vc.counters + 1;
+            fa.flag_count = vc.counters + 2;
             if ((rc = launch_viterbi_fast(fa, p.K, true, s))) return rc;
-            ICNV_HIP(hipMemcpyAsync(vc.host_flag1, fa.flag_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
             // ... and, only if it flagged more than the redo kernel takes (observations beyond the short table's tails), the
             // register kernel with the full table over the whole batch; otherwise that launch hands the first count on
             use_table(vc.tab, 0);
-            fa.gate_count = vc.counters + 1;
+            fa.gate_count = vc.counters + 2;
             fa.gate_limit = limit;
-            fa.task_counter = vc.counters + 2;
+            fa.task_counter = vc.counters + 1;
             fa.flag_count = vc.counters + 3;
             if ((rc = launch_viterbi_fast(fa, p.K, false, s))) return rc;
         } else {
             use_table(vc.tab, 0);
             fa.task_counter = vc.counters;
-            fa.flag_count = vc.counters + 1;
+            fa.flag_count = vc.counters + 3;
             if ((rc = launch_viterbi_fast(fa, p.K, false, s))) return rc;
         }
         if ((rc = launch_viterbi_redo(fa.x, fa.states, (int32_t)G, dev_chr, p, nullptr, sd_shared, fa.flag_count,
@@ -1401,7 +1399,8 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
         if ((rc = launch_viterbi(fa.x, fa.states, (int32_t)G, nc, dev_chr, dev_ord, n_chr, 0, p, nullptr,
                                  sd_shared, d_bp.as<uint32_t>(), n_underflow_dev, fa.flag_count, limit, s)))
             return rc;
-        ICNV_HIP(hipMemcpyAsync(vc.host_flag, fa.flag_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        // one copy for both counts: [2] the staged attempt's (0 when there was none), [3] the one acted on
+        ICNV_HIP(hipMemcpyAsync(vc.host_flag, vc.counters + 2, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         ICNV_HIP(hipEventRecord(vc.flag_ev, s));
         vc.flag_limit = limit;
     }
@@ -1421,11 +1420,11 @@ int icnv_viterbi_last_stats(int64_t *out4) {
     std::lock_guard<std::mutex> vlk(vc.mu);
     if (vc.stats[0] >= 1 && vc.flag_ev) {
         ICNV_HIP(hipEventSynchronize(vc.flag_ev));
-        vc.stats[2] = *vc.host_flag;   // of the last column batch
+        vc.stats[2] = vc.host_flag[1];   // of the last column batch
         // 2: that batch was recomputed by the exact kernel; 3: the staged kernel did it; 4: the staged kernel flagged too many
         // sequences (data beyond its short table) and the register kernel redid the batch with the full table
         if (vc.stats[2] > vc.flag_limit) vc.stats[0] = 2;
-        else if (vc.staged_last) vc.stats[0] = (*vc.host_flag1 > vc.flag_limit) ? 4 : 3;
+        else if (vc.staged_last) vc.stats[0] = (vc.host_flag[0] > vc.flag_limit) ? 4 : 3;
         else vc.stats[0] = 1;
     }
     for (int i = 0; i < 4; ++i) out4[i] = vc.stats[i];
