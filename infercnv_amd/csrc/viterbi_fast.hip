@@ -62,7 +62,6 @@ namespace {
 #define VF_NT 768
 #endif
 constexpr int FAST_NT = VF_NT;
-constexpr int FAST_TG = 8;    // traceback group of the non-uniform-alignment walk: 2 x 8 back-pointer lines in flight (registers)
 constexpr int FAST_TB = 16;   // genes per block of the uniform-alignment traceback (16: 2.54 ms, 32: 2.58, 64: 2.61)
 #ifndef VF_CH
 #define VF_CH 16
@@ -232,10 +231,12 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         // aligned 16-gene blocks -- laid out like the words: the rows of a task next to each other
         const int sum_rows = ((s0 + n) >> 4) - (s0 >> 4) + 3;
         uint16_t *bsum = A.bp + ((int64_t)A.G + (s0 >> 4) + 3 * chr) * (ncg * 64) + ((task % ncg) * 64 * (int64_t)sum_rows + lane);
-        // byte position of gene 0 inside its 16-byte word of the state column: wave-uniform whenever G is a multiple of 16
-        const int a0 = (int)((uintptr_t)st & 15u);
-        const int a0u = __builtin_amdgcn_readfirstlane(a0);
-        const bool a0_uniform = __builtin_amdgcn_ballot_w64(a0 != a0u) == 0;
+        // The 16-gene blocks of the traceback (and their summaries) are laid out by LANE 0's byte position of gene 0 inside a 16-byte
+        // word of its state column.  When the number of genes per column is a multiple of 16 every lane shares it and a block is
+        // one aligned 16-byte store; otherwise (round 5 -- real gene counts are not multiples of 16) the other lanes store their
+        // blocks unaligned, which the hardware splits where a store crosses a line, instead of every lane taking the byte-wise
+        // walk over the per-gene words (1.39 -> ~0.95 ms per 20 000 cells at 9 939 genes)
+        const int a0u = __builtin_amdgcn_readfirstlane((int)((uintptr_t)st & 15u));
             // decision band of this task: 4 (n + 1) (eps + 6 u B), B = |logDelta|max + |a| + (n + 1)(s_max + |b|)
         const double np1 = (double)(n + 1);
         const double B = A.b0 + np1 * A.s_step;
@@ -427,7 +428,7 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         }
         // the chunks are the 16-gene blocks of the summaries when the observations' line alignment and the states' 16-byte
         // alignment go together (always, for G a multiple of 16 and aligned matrices): a block then ends with a chunk
-        const bool use_sum = a0_uniform && ((a0u + i) & (CH - 1)) == 0;
+        const bool use_sum = ((a0u + i) & (CH - 1)) == 0;
         if constexpr (STAGE) {
             static_assert(!STAGE || CH == 16, "a chunk is one 128-byte line per column");
             if (i + CH <= n) {
@@ -543,8 +544,7 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
             auto load_sum = [&](int b) { return (uint32_t)bsum[b * 64]; };
             auto note_sum = [&](uint32_t S, int c) { uacc |= S >> c; };
             if (use_sum) viterbi_traceback_blocks(st, n, cur, a0u, load_bp, load_sum, step_bp, note_sum);
-            else if (a0_uniform) viterbi_traceback_uniform<FAST_TB>(st, n, cur, a0u, load_bp, step_bp);
-            else viterbi_traceback<FAST_TG>(st, n, cur, load_bp, step_bp);
+            else viterbi_traceback_uniform<FAST_TB>(st, n, cur, a0u, load_bp, step_bp);
             unsure |= (uacc >> 9) & 1u;
         }
         if (unsure && !dup) {

@@ -89,13 +89,13 @@ __device__ inline void viterbi_traceback_uniform(uint8_t *st, int n, int cur, in
             d[byte >> 2] |= (uint32_t)cur << (8 * (byte & 3));
             cur = step(W[j], cur);
         }
-        uint4 *dst = reinterpret_cast<uint4 *>(st + g - (TB - 1));
+        uint8_t *dst = st + g - (TB - 1);
 #pragma unroll
         for (int q = 0; q < TB / 16; ++q) {
             uint4 v;
             v.x = d[4 * q] + 0x01010101u; v.y = d[4 * q + 1] + 0x01010101u;
             v.z = d[4 * q + 2] + 0x01010101u; v.w = d[4 * q + 3] + 0x01010101u;
-            dst[q] = v;
+            __builtin_memcpy(dst + 16 * q, &v, 16);   // one 16-byte store; aligned for the lane whose a0 this is, and for all when a0 is shared
         }
         g -= TB;
     }
@@ -129,13 +129,13 @@ __device__ inline void viterbi_traceback_blocks(uint8_t *st, int n, int cur, int
     while (g >= TB) {   // genes g .. g-15 fill one aligned 16-byte word, all of them have a predecessor
         const uint32_t S = Sn;
         if (g - TB >= TB) Sn = load_sum((a0 + g - TB) >> 4);   // the next block's summary, a block ahead
-        uint4 *dst = reinterpret_cast<uint4 *>(st + g - (TB - 1));
+        uint8_t *dst = st + g - (TB - 1);   // (16-byte aligned for the lane whose a0 this is, and for all lanes when a0 is shared)
         if (__builtin_amdgcn_ballot_w64(((S >> cur) & 1u) != 0) == 0) {
             note_sum(S, cur);
             const uint32_t v = (uint32_t)(cur + 1) * 0x01010101u;
             uint4 o;
             o.x = v; o.y = v; o.z = v; o.w = v;
-            *dst = o;
+            __builtin_memcpy(dst, &o, 16);
         } else {
             uint32_t W[TB];
 #pragma unroll
@@ -151,7 +151,7 @@ __device__ inline void viterbi_traceback_blocks(uint8_t *st, int n, int cur, int
             }
             uint4 o;
             o.x = d[0] + 0x01010101u; o.y = d[1] + 0x01010101u; o.z = d[2] + 0x01010101u; o.w = d[3] + 0x01010101u;
-            *dst = o;
+            __builtin_memcpy(dst, &o, 16);
         }
         g -= TB;
     }

@@ -46,7 +46,8 @@ def measure(G=10000, C=20000, devices=1, reps=2):
     for name, fn, gb in (("fused_chain_plus_hmm", fused, (3 * 8 + 8 + 1) * G * C / 1e9), ("six_standalone_steps", six_steps, 6 * 16 * G * C / 1e9)):
         for resident in (0, 1):
             check(L.icnv_residency(resident))
-            fn()
+            for _ in range(4 if resident else 2):   # steady state: staging buffers / the pool's blocks exist (bench.py warms up the same way)
+                fn()
             t0 = time.perf_counter()
             for _ in range(reps):
                 fn()
