@@ -384,14 +384,13 @@ static bool chain_geom(int64_t G, int n_chr, int T, ChainGeom &g) {
     const int64_t npos = G + (int64_t)(n_chr + 1) * g.pad;
     if (npos <= 768 * 7) { g.nt = 768; g.lmax = 7; return true; }
     // 1024 threads x 11 positions, five gene-pair slots per thread: 16 wavefronts (4 per SIMD, 128 VGPRs) hide the
-    // barrier-separated phases better than 12 (chain_apply 2.45 -> 2.30 ms at 10 000 genes); even gene counts only
-    if (npos <= 1024 * 11 && G <= 1024 * 5 * 2 && (G & 1) == 0) { g.nt = 1024; g.lmax = 11; return true; }
+    // barrier-separated phases better than 12 (chain_apply 2.45 -> 2.30 ms at 10 000 genes)
+    if (npos <= 1024 * 11 && G <= 1024 * 5 * 2 && G >= 4) { g.nt = 1024; g.lmax = 11; return true; }
     if (npos <= 768 * 15) { g.nt = 768; g.lmax = 15; return true; }
-    // between the 10 000-gene geometries and 768 x 23: chunk lengths 17 / 19 / 21 with (L - 1) / 2 gene-pair slots for even G
-    // (odd G: one gene per slot, L slots) -- a thread's work follows its chunk length and its slots, so the smallest geometry
-    // that holds the cell is the fastest
+    // between the 10 000-gene geometries and 768 x 23: chunk lengths 17 / 19 / 21 with (L - 1) / 2 gene-pair slots -- a
+    // thread's work follows its chunk length and its slots, so the smallest geometry that holds the cell is the fastest
     for (int L = 17; L <= 21; L += 2)
-        if (npos <= 768 * L && ((G & 1) || G <= 768 * ((L - 1) / 2) * 2)) { g.nt = 768; g.lmax = L; return true; }
+        if (npos <= 768 * L && G <= 768 * ((L - 1) / 2) * 2) { g.nt = 768; g.lmax = L; return true; }
     if (npos <= 768 * 23) { g.nt = 768; g.lmax = 23; return true; }
     if (npos <= 512 * 35) { g.nt = 512; g.lmax = 35; return true; }
     return false;
@@ -485,7 +484,7 @@ int launch_chain(const ChainArgs &a0, int mode, hipStream_t stream) {
         return launch_chain_w11(a, mode, stream);
     }
     if (g.lmax == 15) {
-        if ((a.G & 1) == 0 && a.G <= 768 * 7 * 2) {
+        if (a.G >= 4 && a.G <= 768 * 7 * 2) {
             if (smooth && a.T == 50) {
                 const int rc = launch_chain_m15t(a, mode, stream);
                 if (rc != -1000) return rc;

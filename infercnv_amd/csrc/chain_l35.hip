@@ -3,5 +3,5 @@
 #include "chain_kernel.inc"
 
 namespace icnv {
-int launch_chain_l35(const ChainArgs &a, int mode, hipStream_t stream) { return launch_chain_v<512, 35>(a, mode, stream); }
+int launch_chain_l35(const ChainArgs &a, int mode, hipStream_t stream) { return launch_chain_m<512, 35, 2>(a, mode, stream); }
 }  // namespace icnv

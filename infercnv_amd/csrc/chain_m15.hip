@@ -2,5 +2,5 @@
 #include "chain_kernel.inc"
 
 namespace icnv {
-int launch_chain_m15(const ChainArgs &a, int mode, hipStream_t stream) { return launch_chain_v<768, 15>(a, mode, stream); }
+int launch_chain_m15(const ChainArgs &a, int mode, hipStream_t stream) { return launch_chain_m<768, 15, 2>(a, mode, stream); }
 }  // namespace icnv

@@ -6,7 +6,6 @@
 
 namespace icnv {
 int launch_chain_m21(const ChainArgs &a, int mode, hipStream_t stream) {
-    if ((a.G & 1) == 0) return launch_chain_m<768, 21, 2, 10, 0>(a, mode, stream);
-    return launch_chain_m<768, 21, 1>(a, mode, stream);
+    return launch_chain_m<768, 21, 2, 10, 0>(a, mode, stream);   // (even and odd gene counts: the pair layout)
 }
 }  // namespace icnv

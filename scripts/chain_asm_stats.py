@@ -4,8 +4,8 @@ Inserts `; MARK <phase>` comments at the phase boundaries of chain_kernel.inc, c
 assembly and counts VALU / LDS / VMEM / SALU / v_readlane instructions between the markers."""
 import collections, os, re, subprocess, sys, tempfile
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "infercnv_amd", "csrc")
-variant = sys.argv[1] if len(sys.argv) > 1 else "Li1024ELi11ELi2ELi0ELi127ELi5ELi50E"
-launch = sys.argv[2] if len(sys.argv) > 2 else "launch_chain_m<1024, 11, 2, 5, 50>"   # e.g. "launch_chain_v<768, 15>" with Li768ELi15ELi2ELi0ELi127ELi0ELi0E
+variant = sys.argv[1] if len(sys.argv) > 1 else "Li1024ELi11ELi2ELi0ELi127ELi5ELi50ELb0E"   # (the last parameter: Lb1E = the odd-gene-count twin)
+launch = sys.argv[2] if len(sys.argv) > 2 else "launch_chain_m<1024, 11, 2, 5, 50>"   # e.g. "launch_chain_v<768, 15>" with Li768ELi15ELi2ELi0ELi127ELi0ELi0ELb0E
 src = open(os.path.join(root, "chain_kernel.inc")).read()
 marks = [("        // ---------------- [A] steps 8, 9", "A"), ("        // ---------------- [C] step 22", "C"),
          ("        // ---------------- [D] steps 10, 11", "D_smooth_init"),

@@ -27,10 +27,10 @@ def geometry(G, n_chr=22, T=50):
     pad = (T + 3) & ~1
     npos = G + (n_chr + 1) * pad
     if npos <= 768 * 7: return "768x7", npos
-    if npos <= 1024 * 11 and G <= 10240 and G % 2 == 0: return "1024x11", npos
+    if npos <= 1024 * 11 and G <= 10240: return "1024x11", npos
     if npos <= 768 * 15: return "768x15", npos
     for L in (17, 19, 21):
-        if npos <= 768 * L and (G % 2 or G <= 768 * ((L - 1) // 2) * 2): return f"768x{L}", npos
+        if npos <= 768 * L and G <= 768 * ((L - 1) // 2) * 2: return f"768x{L}", npos
     if npos <= 768 * 23: return "768x23", npos
     if npos <= 512 * 35: return "512x35", npos
     return "three-pass", npos

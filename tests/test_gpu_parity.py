@@ -100,6 +100,22 @@ def test_chain_fused_vs_oracle(dev, G, C, nref):
     check_denoise_flips(to_host(out), ref_out, ref_pre, mu, s, tol=1e-11, label=f"fused G={G}")
 
 
+@pytest.mark.parametrize("sizes", [(1,), (2,), (3,), (4,), (5,), (3, 4), (1, 1, 5), (6, 1)])
+def test_chain_tiny_gene_counts(dev, sizes):
+    """One to eight genes: below four genes the one-gene-per-slot kernels serve the cell, from four on the pair layout (odd
+    counts with its repeated element)."""
+    rng = np.random.default_rng(sum(sizes) * 7 + len(sizes))
+    G, C = int(sum(sizes)), 21
+    cs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    x = np.abs(rng.normal(2.0, 1.0, size=(G, C)))
+    refs = [np.arange(0, 4, dtype=np.int32), np.arange(4, 9, dtype=np.int32)]
+    for window in (3, 101):
+        out, pre = dev.smooth_chain(to_dev(x), cs, refs, window_length=window, want_pre_denoise=True)
+        ref_out, ref_pre, (mu, s) = oc.smooth_chain(x, cs, refs, window_length=window, want_pre_denoise=True)
+        assert np.abs(to_host(pre) - ref_pre).max() < 1e-11, (sizes, window)
+        check_denoise_flips(to_host(out), ref_out, ref_pre, mu, s, tol=1e-11, label=f"tiny {sizes} w{window}")
+
+
 # (genes, window, kernel variant the geometry rules of chain_kernels.hip pick): the run-time-window and the
 # compile-time-window (101) forms of 1024 x 11 / five slots and 768 x 15 / seven slots, and 768 x 15 / eight slots
 @pytest.mark.parametrize("G,window,variant", [(9000, 61, "w11"), (10060, 101, "w11t"), (10400, 41, "m15s"),
@@ -107,7 +123,10 @@ def test_chain_fused_vs_oracle(dev, G, C, nref):
                                               # round 5: chunk lengths 17 / 19 / 21 with fitted slot counts between the 10 000-gene
                                               # geometries and 768 x 23 (even G: (L - 1) / 2 gene-pair slots; odd G: one gene per slot)
                                               (11000, 101, "m17 / 8 slots"), (11001, 101, "m17 odd"), (12400, 101, "m19 / 9 slots"),
-                                              (14000, 101, "m21 / 10 slots"), (14001, 61, "m21 odd"), (16000, 101, "m23 / 11 slots")])
+                                              (14000, 101, "m21 / 10 slots"), (14001, 61, "m21 odd"), (16000, 101, "m23 / 11 slots"),
+                                              # odd gene counts in the pair layout (round 5): the slot of the last gene repeats gene
+                                              # G - 2; 10 239 = every slot of 1024 x 5 pairs taken, the repeated element the only spare
+                                              (10239, 21, "w11 odd, all slots"), (9939, 101, "w11t odd"), (10301, 101, "m15t odd")])
 def test_chain_geometries_and_windows(dev, G, window, variant):
     """Every (threads x chunk length, slots, window form) variant of the fused kernel against the oracle: the full chain,
     the chain without denoise, and stage subsets that run the generic (run-time mask) kernels of the same geometry."""
@@ -139,7 +158,7 @@ STAGES = {"st8": 0x01, "st9": 0x02, "st10": 0x04, "st11": 0x08, "st12": 0x10, "s
 def test_chain_each_stage_standalone(dev, stage):
     """Every R-level wrapper is a single-bit stage_mask call (run(up_to_step=), resume)."""
     from infercnv_amd import synth
-    G, C = 3001, 48          # odd G -> scalar-vector path
+    G, C = 3001, 48          # odd G: the pair layout with one repeated element (round 5; before: one gene per slot)
     x, cs = synth.make_matrix_np(G, C)
     x = x - 2.0
     refs = [np.arange(0, 5, dtype=np.int32), np.arange(5, 9, dtype=np.int32)]
