@@ -108,6 +108,34 @@ __global__ void block_cell_reduce_kernel(const double *__restrict__ x, int G, co
     };
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // four independent chains, combined in a fixed order
     int j = threadIdx.x;
+    if (!gene_idx) {
+        // all genes of the cell: 16-byte requests (round 5: 8-byte requests read the reference cells at 3.5 TB/s; a column that
+        // starts at an 8-byte boundary -- odd G -- is read unaligned), the same four chains over gene PAIRS
+        typedef double dbl2_t __attribute__((ext_vector_type(2)));
+        const int np = n_genes >> 1;
+        auto pair = [&](int p) -> dbl2_t { dbl2_t v; __builtin_memcpy(&v, src + 2 * (int64_t)p, 16); return v; };
+        int p = threadIdx.x;
+        for (; p + 1792 < np; p += 2048) {   // eight requests in flight per thread (a block is short-lived: latency, not bandwidth)
+            const dbl2_t v0 = pair(p), v1 = pair(p + 256), v2 = pair(p + 512), v3 = pair(p + 768);
+            const dbl2_t v4 = pair(p + 1024), v5 = pair(p + 1280), v6 = pair(p + 1536), v7 = pair(p + 1792);
+            s0 += term(v0.x); s1 += term(v1.x); s2 += term(v2.x); s3 += term(v3.x);
+            s0 += term(v0.y); s1 += term(v1.y); s2 += term(v2.y); s3 += term(v3.y);
+            s0 += term(v4.x); s1 += term(v5.x); s2 += term(v6.x); s3 += term(v7.x);
+            s0 += term(v4.y); s1 += term(v5.y); s2 += term(v6.y); s3 += term(v7.y);
+        }
+        for (; p + 768 < np; p += 1024) {
+            const dbl2_t v0 = pair(p), v1 = pair(p + 256), v2 = pair(p + 512), v3 = pair(p + 768);
+            s0 += term(v0.x); s1 += term(v1.x); s2 += term(v2.x); s3 += term(v3.x);
+            s0 += term(v0.y); s1 += term(v1.y); s2 += term(v2.y); s3 += term(v3.y);
+        }
+        for (; p < np; p += 256) {
+            const dbl2_t v0 = pair(p);
+            s0 += term(v0.x);
+            s0 += term(v0.y);
+        }
+        if ((n_genes & 1) && threadIdx.x == 0) s1 += term(src[n_genes - 1]);
+        j = n_genes;   // (nothing left for the loops below)
+    }
     for (; j + 768 < n_genes; j += 1024) {
         const double v0 = src[gene_idx ? gene_idx[j] : j], v1 = src[gene_idx ? gene_idx[j + 256] : j + 256];
         const double v2 = src[gene_idx ? gene_idx[j + 512] : j + 512], v3 = src[gene_idx ? gene_idx[j + 768] : j + 768];
