@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/vit; mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests -x -q -m gpu -k "viterbi or hmm or i3 or i6 or config1 or full_size or smoke" > $O/pytest.log 2>&1; tail -2 $O/pytest.log
-timeout 600 python scripts/stress_viterbi_fast.py 6000 1500 > $O/stress.txt 2>&1; tail -1 $O/stress.txt
+timeout 600 python tests/campaigns/stress_viterbi_fast.py 6000 1500 > $O/stress.txt 2>&1; tail -1 $O/stress.txt
 if [ -n "$LIBS" ]; then bash scripts/bench_libs.sh > /dev/null 2>&1; cp gpurun_out/exp.log $O/ab.txt; cat $O/ab.txt; fi
 timeout 300 python bench.py --no-cpu-baseline | tail -1 > $O/bench.json
 python -c "

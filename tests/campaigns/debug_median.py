@@ -1,5 +1,5 @@
 import os, sys
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [root, os.path.join(root, "tests"), os.path.join(root, "oracle")]
 import numpy as np, torch
 import oracle_c as oc

@@ -4,9 +4,9 @@ data/HMM_states.rda holds the group-level i6 states of the reference's example o
 that produced it came from the reference's unseeded RNG (hidden spike-in simulation, R/inferCNV_HMM.R:15-99, 154-212) and are
 not stored.  Random local search over (six state means, shared sd) with the reference's default t = 1e-6, objective = number
 of differing state calls of oracle_c.viterbi_cells on the two groups' mean profiles; several disjoint parameter sets reach 0
-of 9 226.   python scripts/fit_hmm_pin.py <seed> <seconds>"""
+of 9 226.   python tests/campaigns/fit_hmm_pin.py <seed> <seconds>"""
 import sys, os, time
-_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0]=[_root, os.path.join(_root, 'oracle'), os.path.join(_root, 'tests')]
 import numpy as np, oracle_c as oc, oracle_np as onp
 oc.set_num_threads(2)

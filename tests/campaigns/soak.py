@@ -4,9 +4,9 @@ call -- fused chain, per-cell i6 HMM, subcluster HMM, median filter -- every res
 argument errors thrown in between (the library must report them and keep working) and the device memory the library
 holds tracked from call to call: the same sequence of shapes runs twice, and the second pass must not need more device
 memory than the first (a pool that grows with the number of calls, not with the shapes, fails here).
-  python scripts/soak.py [n_iterations_per_pass] [seed]"""
+  python tests/campaigns/soak.py [n_iterations_per_pass] [seed]"""
 import os, sys, time
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [root, os.path.join(root, "tests"), os.path.join(root, "oracle")]
 import numpy as np, torch
 import oracle_c as oc

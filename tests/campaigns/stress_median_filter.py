@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Stress campaign of the 9 x 9 median filter (run on the GPU box): random chromosome lengths, tile sizes, cell
 permutations and tie densities against the CPU oracle, exact equality.
-  python scripts/stress_median_filter.py [first_seed] [n_seeds] [large]
+  python tests/campaigns/stress_median_filter.py [first_seed] [n_seeds] [large]
 "large": chromosomes of up to 700 genes and tiles of up to 500 cells -- many 56 x 32 classification tiles per (chromosome, tile)
 pair, queue segments of several workgroups, dense 32 x 16 patches next to decided ones."""
 import os, sys, time
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [root, os.path.join(root, "tests"), os.path.join(root, "oracle")]
 import numpy as np, torch
 import oracle_c as oc

@@ -2,9 +2,9 @@
 """Stress campaign of the certified fast Viterbi path (run on the GPU box): the random-model generator of
 tests/test_gpu_parity.py::test_viterbi_fast_path_random_models over many more seeds -- certified fast path against the
 exact kernel, bit for bit, plus a sample of columns against the CPU oracle (done inside the test function).
-  python scripts/stress_viterbi_fast.py [first_seed] [n_seeds]"""
+  python tests/campaigns/stress_viterbi_fast.py [first_seed] [n_seeds]"""
 import os, sys, time
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [root, os.path.join(root, "tests"), os.path.join(root, "oracle")]
 import torch
 import test_gpu_parity as T

@@ -1,9 +1,9 @@
 """How long does ONE gene step of the fast Viterbi take when nothing else competes?  A single chromosome of 10 000 genes and
 64 x n columns: n wavefronts, all on one CU (one workgroup) -- the per-wavefront dependent latency of a gene step (n = 1) and
 the issue-bound round time of a full workgroup (n = 12), without any memory-system contention (0.06-0.6 MB of observations).
-    python scripts/viterbi_latency_probe.py"""
+    python tests/campaigns/viterbi_latency_probe.py"""
 import os, sys
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [root, os.path.join(root, "oracle")]
 import numpy as np, torch
 from infercnv_amd import device, synth

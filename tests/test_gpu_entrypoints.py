@@ -121,7 +121,7 @@ def test_config1_example_run_inputs_through_the_hip_path(dev, run_inputs):
 def test_hmm_states_rda_through_the_hip_path(dev, golden_dir, which):
     """The reference's only HMM artefact, data/HMM_states.rda, through the HIP path: counts of the example object -> steps
     3, 4 -> fused chain -> group means -> i6 Viterbi per group (C ABI, device-resident) with a parameter set that reproduces
-    the fixture (tests/test_hmm_pin.py::HMM_STATES_PINS, found by scripts/fit_hmm_pin.py): all 9 226 group-gene calls equal."""
+    the fixture (tests/test_hmm_pin.py::HMM_STATES_PINS, found by tests/campaigns/fit_hmm_pin.py): all 9 226 group-gene calls equal."""
     import oracle_np as onp
     from test_hmm_pin import HMM_STATES_PINS
     d = np.load(os.path.join(golden_dir, "infercnv_object_example.npz"))

@@ -110,7 +110,7 @@ def test_hmm_states_rda_reproduced_to_the_pinned_count(golden_dir):
         assert (st[:, groups[0][0]] != gold[:, groups[0][0]]).sum() > 84
 
 
-# parameter sets found by scripts/fit_hmm_pin.py (random local search, t = 1e-6 as in the reference): (six state means, shared sd)
+# parameter sets found by tests/campaigns/fit_hmm_pin.py (random local search, t = 1e-6 as in the reference): (six state means, shared sd)
 HMM_STATES_PINS = {
     "B": ([0.3164256433041929, 0.7741381517076411, 0.9979107048736667, 1.1571072959212576, 1.2829887975829641, 1.5453209792449107],
           0.04403543890691475),
@@ -124,7 +124,7 @@ def test_hmm_states_rda_reproduced_exactly(golden_dir, which):
     """data/HMM_states.rda -- the only HMM artefact the reference ships -- reproduced in ALL 9 226 group-gene calls (round 4:
     9 142 with the means of data/mcmc_obj.rda, which belong to another run).  The means and the sd that produced the fixture
     came from the reference's unseeded RNG and are not stored; with the reference's default t = 1e-6 there are parameter sets
-    (scripts/fit_hmm_pin.py) for which the restated chain + group means + Viterbi.dthmm.adj return the fixture exactly, and
+    (tests/campaigns/fit_hmm_pin.py) for which the restated chain + group means + Viterbi.dthmm.adj return the fixture exactly, and
     they sit on narrow plateaus (a 1e-3 change of a mean loses calls): every one of the fixture's 9 226 calls -- 2 groups x
     4 613 genes, four states, state changes inside chromosomes -- constrains the restatement's emission arithmetic, its recurrence
     and its traceback.  NumPy oracle == C oracle == fixture here; the HIP path in tests/test_gpu_entrypoints.py."""
