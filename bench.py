@@ -732,8 +732,10 @@ def main():
                 f"1-read : 2-write stream reaches {STREAM_1R2W_GBS:.0f} GB/s on this GPU ({STREAM_1R2W_SOURCE}), so with two output "
                 f"matrices `frac` cannot exceed {STREAM_1R2W_GBS:.0f} / 8000 x 16 / 24 = {cap:.2f}; the north star's 0.70 is out of reach for "
                 f"the pass as specified, and this launch sits at {roof['chain_apply']['frac'] / cap:.2f} of the cap (`hbm_traffic` prices the "
-                "bytes really moved).  Round 4 (profiles/r04_cu_mask_probe.txt): confined to half the CUs the pass takes 1.73 x as long for "
-                "twice the cells per CU -- it is paced by the memory system, like the Viterbi it shares the step with")
+                "bytes really moved).  What paces it (DESIGN.md K2): ~900 vector instructions per thread and cell -- issue for more than half "
+                "of the ~28 000 cycles a CU spends on a cell, the rest barrier-separated latency; across boxes whose stream rates differ by "
+                "15 % the launch time moves by 2 % (round 5), confined to half the CUs it takes 1.73 x as long for twice the cells per CU "
+                "(round 4, profiles/r04_cu_mask_probe.txt)")
         if "viterbi" in roof:
             st = device.viterbi_last_stats()
             roof["viterbi"]["note"] = (f"certified fast path ({st['path']}, {st.get('kernel', '?')} kernel, {st['table_intervals']} table records; "
