@@ -589,3 +589,43 @@ def test_r_wrappers_are_lexically_well_formed():
                "i3HMM_predict_CNV_via_HMM_on_tumor_subclusters", "i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples",
                "assign_HMM_states_to_proxy_expr_vals", "i3HMM_assign_HMM_states_to_proxy_expr_vals", "apply_median_filtering"):
         assert re.search(r"\b" + re.escape(fn) + r"\b", rsrc), fn
+
+
+def test_bench_self_launch_starts_n_ranks_with_every_flag_passed_through(monkeypatch):
+    """`python bench.py --gpus N` without a launcher must not die at argv (the driver's scaling run may be called exactly
+    like its single-GPU one): bench.self_launch re-executes the same command line under torch.distributed.run with N
+    ranks, a free port on 127.0.0.1, every flag passed through, and returns the launcher's exit code.  With WORLD_SIZE set
+    (a real launcher) main() must NOT launch again.  No GPU involved: subprocess.run is intercepted."""
+    import importlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1", "--config", "3"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7                                     # the launcher's exit code is bench.py's
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    k = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[k + 1:] == ["--gpus", "8", "--steps", "3", "--warmup", "1", "--config", "3"]
+    assert seen["env"]["ICNV_BENCH_LAUNCHER"] == "self" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # a mismatch between --gpus and a launcher's WORLD_SIZE is an error message, not a silent one-rank run
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    seen.clear()
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert not seen and "WORLD_SIZE is 2" in str(e.value.code)
