@@ -283,7 +283,7 @@ struct icnv_chain {
     // cells keeps its output (one column per position of ref_idx), so that the later rounds and the apply pass
     // continue from it instead of smoothing the same cells again (three times per chain otherwise).
     bool na_aware = false;            // ICNV_ST_NA_AWARE: cells that hold a NaN are recomputed by chain_na.hip
-    DevBuf d_naflags;
+    DevBuf d_naflags, d_nanbound;     // d_nanbound: [1] set when a no-bounds mean is NaN (every cell then takes the NA pass)
     bool cache_enabled = false;
     DevBuf d_cache, d_nonref, d_iota;   // d_iota: 0 .. n_ref - 1 (the cache holds one column per position of ref_idx)
     std::vector<int32_t> nonref;      // cells that are in no reference group
@@ -442,7 +442,11 @@ static int chain_upload(icnv_chain *ch, hipStream_t s) {
         }
     }
     if ((rc = upload(ch->d_ref_off, ch->ref_off.data(), ch->ref_off.size(), s))) return rc;
-    if (ch->na_aware && (rc = ch->d_naflags.alloc((size_t)std::max<int64_t>(ch->cfg.C, 1)))) return rc;
+    if (ch->na_aware) {
+        if ((rc = ch->d_naflags.alloc((size_t)std::max<int64_t>(ch->cfg.C, 1)))) return rc;
+        if ((rc = ch->d_nanbound.alloc(sizeof(int32_t)))) return rc;
+        ICNV_HIP(hipMemsetAsync(ch->d_nanbound.p, 0, sizeof(int32_t), s));
+    }
     if (ch->large) {
         ch->cache_enabled = false;
         if (!ch->ref_idx.empty() && (rc = ch->d_large_tmp.alloc(ch->ref_idx.size() * (size_t)G * sizeof(double)))) return rc;
@@ -618,7 +622,7 @@ int icnv_chain_round_partial_dev(icnv_chain_t *ch, int round, const double *expr
         const int rc2 = launch_chain(a, MODE_APPLY, s);
         if (rc2) return rc2;
         // (reference cells that hold a NaN: their cached columns redone with the reference's NA semantics before they are summed)
-        if (ch->na_aware && (rc = launch_chain_na_fixup(a, ch->max_chr_len, ch->d_naflags.as<uint8_t>(), s))) return rc;
+        if (ch->na_aware && (rc = launch_chain_na_fixup(a, ch->max_chr_len, ch->d_naflags.as<uint8_t>(), ch->d_nanbound.as<int32_t>(), s))) return rc;
         if ((rc = launch_group_gene_sums(ch->d_cache.as<double>(), (int32_t)G, ch->d_iota.as<int32_t>(), ch->d_ref_off.as<int32_t>(), ng,
                                          ch->d_partial.as<double>(), 256, sums, s)))
             return rc;
@@ -661,8 +665,10 @@ int icnv_chain_round_finish_dev(icnv_chain_t *ch, int round, void *stream) {
         return launch_denoise_from_stats(ch->d_stats.as<double>(), ch->cfg.sd_amplifier, ch->cfg.noise_filter,
                                          ch->d_den.as<double>(), s);
     double *bounds = (bit == ICNV_ST_SUBTRACT_REF_1) ? ch->d_b1.as<double>() : ch->d_b2.as<double>();
+    int32_t *nan_flag = (ch->na_aware && !ch->cfg.use_bounds) ? ch->d_nanbound.as<int32_t>() : nullptr;
+    if (nan_flag && round == 0) ICNV_HIP(hipMemsetAsync(nan_flag, 0, sizeof(int32_t), s));   // (a chain object may be run again)
     return launch_bounds_from_sums(ch->d_sums.as<double>(), (int32_t)ch->cfg.G, ch->cfg.n_ref_grp, ch->cfg.use_bounds,
-                                   ch->cfg.inv_log, bounds, s);
+                                   ch->cfg.inv_log, bounds, nan_flag, s);
 }
 
 // the apply pass with the stage mask `amask` (the chain's own, or -- noise_logistic -- the chain's without step 22)
@@ -689,25 +695,64 @@ static int chain_apply_masked(icnv_chain_t *ch, uint32_t amask, const double *ex
     const bool from_cache = ch->cache_in == expr_in && ch->cache_mask != 0 && (ch->cache_mask & ~amask) == 0;
     const uint32_t cached = ch->cache_mask;
     ch->cache_in = nullptr;
-    auto launch_apply = [&](const ChainArgs &args) -> int {   // the fused pass, then -- ICNV_ST_NA_AWARE -- the cells that hold a NaN again
-        int r = launch_chain(args, MODE_APPLY, s);
-        if (!r && ch->na_aware) r = launch_chain_na_fixup(args, ch->max_chr_len, ch->d_naflags.as<uint8_t>(), s);
+    // the fused pass, then -- ICNV_ST_NA_AWARE -- the cells that hold a NaN again (`host_cells`: the host copy of args.cells)
+    auto launch_apply = [&](const ChainArgs &args, const std::vector<int32_t> *host_cells) -> int {
+        if (!ch->na_aware) return launch_chain(args, MODE_APPLY, s);
+        uint8_t *flags = ch->d_naflags.as<uint8_t>();
+        const int32_t *all_flag = ch->d_nanbound.as<int32_t>();
+        const bool in_place = args.in == args.out || (args.pre_out && args.in == args.pre_out);
+        if (!in_place) {
+            int r = launch_chain(args, MODE_APPLY, s);
+            if (!r) r = launch_chain_na_fixup(args, ch->max_chr_len, flags, all_flag, s);
+            return r;
+        }
+        // The chain runs IN PLACE (expr_out aliases expr_in: include/icnv.h allows it): the fused pass overwrites the input the NA
+        // pass reads, so the cells that hold a NaN are found FIRST and their input columns kept aside.  The flags cross to the host
+        // (this path waits for the stream: a matrix with NAs is not run()'s case), the flagged columns -- a handful -- are gathered
+        // into a stash, the fused pass runs, and the NA pass recomputes the flagged cells from the stash.
+        int r = launch_nan_flags(args, flags, all_flag, s);
+        if (r) return r;
+        std::vector<uint8_t> hflags((size_t)args.n_cells);
+        ICNV_HIP(hipMemcpyAsync(hflags.data(), flags, hflags.size(), hipMemcpyDeviceToHost, s));
+        ICNV_HIP(hipStreamSynchronize(s));
+        std::vector<int32_t> ids;
+        for (int32_t i = 0; i < args.n_cells; ++i)
+            if (hflags[(size_t)i]) ids.push_back(host_cells ? (*host_cells)[(size_t)i] : i);
+        if (ids.empty()) return launch_chain(args, MODE_APPLY, s);
+        const int32_t nf = (int32_t)ids.size();
+        DevBuf d_ids, d_stash, d_ones;
+        if ((r = upload(d_ids, ids.data(), ids.size(), s))) return r;
+        if ((r = d_stash.alloc((size_t)nf * (size_t)args.G * sizeof(double)))) return r;
+        if ((r = d_ones.alloc((size_t)nf))) return r;
+        ICNV_HIP(hipMemsetAsync(d_ones.p, 1, (size_t)nf, s));
+        if ((r = launch_gather_columns(args.in, args.G, d_ids.as<int32_t>(), nf, d_stash.as<double>(), s))) return r;
+        if ((r = launch_chain(args, MODE_APPLY, s))) return r;
+        ChainArgs b = args;            // the flagged cells: input = their stashed columns (by position), output = their own columns
+        b.in = d_stash.as<double>();
+        b.in_by_pos = 1;
+        b.out_by_pos = 0;
+        b.cells = d_ids.as<int32_t>();
+        b.n_cells = nf;
+        r = launch_chain_na_cells(b, ch->max_chr_len, d_ones.as<uint8_t>(), s);
+        ICNV_HIP(hipStreamSynchronize(s));   // `ids` (pageable, uploaded asynchronously) and the three buffers are done with when this returns
         return r;
     };
     auto run = [&](ChainArgs args) -> int {
-        if (!from_cache) return launch_apply(args);
+        if (!from_cache) return launch_apply(args, nullptr);
         int r = ICNV_OK;
         if (!ch->nonref.empty()) {
             args.cells = ch->d_nonref.as<int32_t>();
             args.n_cells = (int32_t)ch->nonref.size();
-            if ((r = launch_apply(args))) return r;
+            if ((r = launch_apply(args, &ch->nonref))) return r;
         }
         args.in = ch->d_cache.as<double>();
         args.in_by_pos = 1;
         args.cells = ch->d_ref.as<int32_t>();
         args.n_cells = (int32_t)ch->ref_idx.size();
         args.mask = amask & ~cached;
-        return launch_chain(args, MODE_APPLY, s);
+        // (NA-aware: a cached column may hold a NaN the stages in front left in place -- e.g. a chain without step 8 -- and
+        // steps 12 / 22 treat it the reference's way only in the NA pass)
+        return launch_apply(args, &ch->ref_idx);
     };
     if (pre_denoise && !(amask & ICNV_ST_DENOISE)) {
         // no denoise stage: the "pre-denoise" matrix is the output itself

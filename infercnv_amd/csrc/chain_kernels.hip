@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(256) reduce_group_partials_kernel(const double
 
 // .get_normal_gene_mean_bounds + the min/max / mean-of-means of .subtract_expr
 // (R/inferCNV_ops.R:1708-1735, 1750-1776).  sc = [G*n_grp sums | n_grp counts].
-__global__ void bounds_from_sums_kernel(const double *sc, int G, int n_grp, int use_bounds, int inv_log, double *bounds) {
+__global__ void bounds_from_sums_kernel(const double *sc, int G, int n_grp, int use_bounds, int inv_log, double *bounds, int32_t *nan_flag) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
     double lo = 0.0, hi = 0.0, tot = 0.0;
@@ -164,6 +164,9 @@ __global__ void bounds_from_sums_kernel(const double *sc, int G, int n_grp, int 
         const double mm = tot / (double)n_grp;
         bounds[g] = mm;
         bounds[G + g] = mm;
+        // x - NA = NA for this gene in EVERY cell (R/inferCNV_ops.R:1770-1776); the fused pass computes x - clamp(x, NaN, NaN) = 0:
+        // an NA-aware chain sends every cell through the NA pass instead (chain_na.hip)
+        if (nan_flag && mm != mm) *nan_flag = 1;
     }
 }
 
@@ -532,10 +535,10 @@ int launch_group_gene_sums(const double *x, int32_t G, const int32_t *cells_dev,
 }
 
 int launch_bounds_from_sums(const double *sums_counts, int32_t G, int32_t n_grp, int32_t use_bounds, int32_t inv_log,
-                            double *bounds, hipStream_t stream) {
+                            double *bounds, int32_t *nan_flag, hipStream_t stream) {
     KernelTimer kt("bounds_from_sums", stream);
     hipLaunchKernelGGL(bounds_from_sums_kernel, dim3((G + 255) / 256), dim3(256), 0, stream, sums_counts, G, n_grp,
-                       use_bounds, inv_log, bounds);
+                       use_bounds, inv_log, bounds, nan_flag);
     ICNV_HIP(hipGetLastError());
     return ICNV_OK;
 }

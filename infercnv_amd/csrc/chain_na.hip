@@ -40,14 +40,29 @@ __device__ inline double na_block_sum(double v, double *red) {   // fixed order:
 }
 
 // cells that hold at least one NaN: flags[c] = 1
+// (`all_flag`, nullable: a device word that flags EVERY cell when it is non-zero -- a step-8 / 12 mean that is NaN in the
+// no-bounds mode, where x - NA = NA for that gene in every cell, R/inferCNV_ops.R:1770-1776)
 __global__ void __launch_bounds__(256) nan_cells_flag_kernel(const double *__restrict__ x, int G, const int32_t *__restrict__ cells,
-                                                            int in_by_pos, int64_t n_cells, uint8_t *__restrict__ flags) {
+                                                            int in_by_pos, int64_t n_cells, uint8_t *__restrict__ flags,
+                                                            const int32_t *__restrict__ all_flag) {
+    const bool all = all_flag && *all_flag != 0;
     for (int64_t i = blockIdx.x; i < n_cells; i += gridDim.x) {
         const int64_t col = (cells && !in_by_pos) ? cells[i] : i;
         const double *p = x + col * (int64_t)G;
-        bool any = false;
-        for (int g = threadIdx.x; g < G; g += 256) any |= na_isnan(p[g]);
+        bool any = all;
+        if (!all)
+            for (int g = threadIdx.x; g < G; g += 256) any |= na_isnan(p[g]);
         if (__builtin_amdgcn_ballot_w64(any) != 0ull && (threadIdx.x & 63) == 0) flags[i] = 1;
+    }
+}
+
+// stash[i * G ..] = x[ids[i] * G ..]: the input columns of the flagged cells, kept when the chain runs in place
+__global__ void __launch_bounds__(256) gather_columns_kernel(const double *__restrict__ x, int G, const int32_t *__restrict__ ids, int n,
+                                                            double *__restrict__ stash) {
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const double *p = x + (int64_t)ids[i] * G;
+        double *d = stash + (int64_t)i * G;
+        for (int g = threadIdx.x; g < G; g += 256) d[g] = p[g];
     }
 }
 
@@ -252,23 +267,46 @@ __global__ void __launch_bounds__(NA_NT) chain_na_cells_kernel(const NaArgs a) {
 
 }  // namespace
 
-// `flags_ws`: n_cells bytes of workspace.  Flags the list positions whose input column holds a NaN and recomputes them.
-int launch_chain_na_fixup(const ChainArgs &a, int32_t max_chr_len, uint8_t *flags_ws, hipStream_t stream) {
+// `flags_ws`: n_cells bytes of workspace.  Flags the list positions whose input column holds a NaN.
+int launch_nan_flags(const ChainArgs &a, uint8_t *flags_ws, const int32_t *all_flag, hipStream_t stream) {
+    if (a.n_cells <= 0) return ICNV_OK;
+    ICNV_HIP(hipMemsetAsync(flags_ws, 0, (size_t)a.n_cells, stream));
+    const int grid1 = (int)std::min<int64_t>(a.n_cells, (int64_t)num_cus() * 16);
+    hipLaunchKernelGGL(nan_cells_flag_kernel, dim3(grid1), dim3(256), 0, stream, a.in, a.G, a.cells, a.in_by_pos, (int64_t)a.n_cells, flags_ws,
+                       all_flag);
+    ICNV_HIP(hipGetLastError());
+    return ICNV_OK;
+}
+
+// the flagged list positions of `a` recomputed from a.in with the reference's NA semantics
+int launch_chain_na_cells(const ChainArgs &a, int32_t max_chr_len, const uint8_t *flags, hipStream_t stream) {
     if (a.n_cells <= 0) return ICNV_OK;
     const size_t lds = (size_t)std::max(max_chr_len, 1) * sizeof(double);
     if (lds > 150 * 1024) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "NA-aware chain: a chromosome does not fit the LDS");
-    ICNV_HIP(hipMemsetAsync(flags_ws, 0, (size_t)a.n_cells, stream));
-    const int grid1 = (int)std::min<int64_t>(a.n_cells, (int64_t)num_cus() * 16);
-    hipLaunchKernelGGL(nan_cells_flag_kernel, dim3(grid1), dim3(256), 0, stream, a.in, a.G, a.cells, a.in_by_pos, (int64_t)a.n_cells, flags_ws);
     NaArgs n;
     n.in = a.in; n.out = a.out; n.pre = a.pre_out; n.G = a.G; n.cells = a.cells; n.in_by_pos = a.in_by_pos; n.out_by_pos = a.out_by_pos;
-    n.n_cells = a.n_cells; n.flags = flags_ws; n.chr_start = a.chr_start; n.n_chr = a.n_chr; n.T = (a.mask & ICNV_ST_SMOOTH) ? a.T : 0;
+    n.n_cells = a.n_cells; n.flags = flags; n.chr_start = a.chr_start; n.n_chr = a.n_chr; n.T = (a.mask & ICNV_ST_SMOOTH) ? a.T : 0;
     n.mask = a.mask; n.use_bounds = a.use_bounds; n.max_thresh = a.max_thresh; n.b1 = a.b1; n.b2 = a.b2; n.denoise = a.denoise;
     static DeviceOnce once;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(chain_na_cells_kernel), 150 * 1024, once)) return rc;
     const int grid2 = (int)std::min<int64_t>(a.n_cells, (int64_t)num_cus() * 2);
     KernelTimer kt("chain_na_cells", stream);
     hipLaunchKernelGGL(chain_na_cells_kernel, dim3(grid2), dim3(NA_NT), lds, stream, n);
+    ICNV_HIP(hipGetLastError());
+    return ICNV_OK;
+}
+
+// Flags the list positions whose input column holds a NaN and recomputes them (a.in must still hold the input: not for a
+// chain that runs in place -- api.hip stashes the flagged columns first, see chain_apply_masked).
+int launch_chain_na_fixup(const ChainArgs &a, int32_t max_chr_len, uint8_t *flags_ws, const int32_t *all_flag, hipStream_t stream) {
+    if (a.n_cells <= 0) return ICNV_OK;
+    if (int rc = launch_nan_flags(a, flags_ws, all_flag, stream)) return rc;
+    return launch_chain_na_cells(a, max_chr_len, flags_ws, stream);
+}
+
+int launch_gather_columns(const double *x, int32_t G, const int32_t *ids_dev, int32_t n, double *stash, hipStream_t stream) {
+    if (n <= 0) return ICNV_OK;
+    hipLaunchKernelGGL(gather_columns_kernel, dim3((unsigned)std::min(n, num_cus() * 8)), dim3(256), 0, stream, x, (int)G, ids_dev, (int)n, stash);
     ICNV_HIP(hipGetLastError());
     return ICNV_OK;
 }

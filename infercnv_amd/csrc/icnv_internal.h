@@ -119,7 +119,11 @@ struct ChainArgs {
 int launch_chain(const ChainArgs &a, int mode, hipStream_t stream);
 // chain_na.hip: the list positions of `a` whose input column holds a NaN, recomputed with the reference's NA semantics
 // (same arguments as the apply launch it follows; flags_ws: a.n_cells bytes of workspace)
-int launch_chain_na_fixup(const ChainArgs &a, int32_t max_chr_len, uint8_t *flags_ws, hipStream_t stream);
+// (all_flag, nullable: a device word that flags every cell when non-zero -- a NaN mean in the no-bounds mode)
+int launch_chain_na_fixup(const ChainArgs &a, int32_t max_chr_len, uint8_t *flags_ws, const int32_t *all_flag, hipStream_t stream);
+int launch_nan_flags(const ChainArgs &a, uint8_t *flags_ws, const int32_t *all_flag, hipStream_t stream);          // its two halves, for a chain
+int launch_chain_na_cells(const ChainArgs &a, int32_t max_chr_len, const uint8_t *flags, hipStream_t stream);       // that runs in place
+int launch_gather_columns(const double *x, int32_t G, const int32_t *ids_dev, int32_t n, double *stash, hipStream_t stream);
 int chain_max_genes();
 bool chain_fused_fits(int64_t G, int32_t n_chr, int32_t T);   // does the LDS-resident fused kernel take this geometry?
 
@@ -156,8 +160,9 @@ int launch_reduce_partials(const double *partial, int nblk, int32_t G, double *o
 // raw per-gene sums of all reference groups in one launch (+ the reduction over its splits): sums_counts = [G*n_grp | n_grp]
 int launch_group_gene_sums(const double *x, int32_t G, const int32_t *cells_dev, const int32_t *off_dev, int32_t n_grp,
                            double *partial, int32_t partial_rows, double *sums_counts, hipStream_t stream);
+// (nan_flag, nullable: set to 1 when a stored bound is NaN -- NA-aware chains in the no-bounds mode look at it)
 int launch_bounds_from_sums(const double *sums_counts, int32_t G, int32_t n_grp, int32_t use_bounds, int32_t inv_log,
-                            double *bounds, hipStream_t stream);
+                            double *bounds, int32_t *nan_flag, hipStream_t stream);
 bool cache_cell_stats_covers(int32_t G);   // even G <= 10 240: the cell fits the streaming kernel's registers
 int launch_cache_cell_stats(const double *cache, int32_t G, int32_t n_cells, uint32_t mask /* steps 12 / 14 still to run */, const double *b2,
                             double *cell_stats, hipStream_t stream);

@@ -12,7 +12,9 @@ Sources (all under /root/reference):
   data/HMM_states.rda               -- i6 states of a `samples`-mode run
       (R/data.R:30-35); emission parameters were RNG-derived, so this is a
       sanity fixture only.
-  data/mcmc_obj.rda                 -- realistic i6 emission means / precisions.
+  data/mcmc_obj.rda                 -- the i6 emission means / precisions of the run that produced HMM_states.rda
+      (@mu, @sig: that run's get_spike_dists output, R/inferCNV_BayesNet.R:154-161) and @cell_gene / @cnv_regions: the
+      nine CNV regions (name, gene rows, cell columns) the reference derived from HMM_states.rda -> mcmc_cell_gene.npz.
   inst/extdata/gencode_downsampled.EXAMPLE_ONLY_DONT_REUSE.txt -- genes per chr
       used to shape the synthetic benchmark.
   inst/extdata/oligodendroglioma_{expression_downsampled.counts.matrix.gz,
@@ -112,6 +114,34 @@ def example_run_inputs():
           "obs", {n: len(out[f"obs_{i}"]) for i, n in enumerate(obs_names)})
 
 
+def mcmc_cell_gene(mc=None):
+    """data/mcmc_obj.rda @cell_gene / @cnv_regions -> mcmc_cell_gene.npz: the nine CNV regions the reference itself derived
+    from data/HMM_states.rda (man/filterHighPNormals.Rd:29-31 uses the two objects as a pair) -- generate_cnv_region_reports
+    (R/inferCNV_HMM.R:790-869: .get_state_consensus, .define_cnv_gene_regions :1005-1057, ignore_neutral_state = 3) wrote
+    17_HMM_pred*.pred_cnv_genes.dat / .cell_groupings, initializeObject / getGenesCells (R/inferCNV_BayesNet.R:245-316) read
+    them back: region names in order of appearance, gene rows and cell columns as 1-BASED indices (kept 1-based here, as
+    stored), the factor's levels (sorted names) and codes.  A reference-held golden for SURVEY.md 8f #2."""
+    if mc is None:
+        mc = rda.read_rda(f"{REF}/data/mcmc_obj.rda")["mcmc_obj"]
+    cr = mc.attrs["cnv_regions"]
+    levels = [str(v) for v in cr.attrs["levels"]]
+    codes = np.asarray(cr.value, dtype=np.int32)
+    out = dict(levels=np.array(levels), codes=codes, names=np.array([levels[c - 1] for c in codes]),
+               group_id=np.asarray(mc.attrs["group_id"], dtype=np.int64),
+               obs_tumor=np.asarray(mc.attrs["observation_grouped_cell_indices"].value["tumor"], dtype=np.int32),
+               ref_normal=np.asarray(mc.attrs["reference_grouped_cell_indices"].value["normal"], dtype=np.int32))
+    for i, e in enumerate(mc.attrs["cell_gene"]):
+        v = e.value
+        f = v["cnv_regions"]
+        f = f[0] if isinstance(f, (list, np.ndarray)) else f
+        name = [str(x) for x in f.attrs["levels"]][int(np.asarray(f.value).ravel()[0]) - 1]
+        assert name == out["names"][i]
+        out[f"genes_{i}"] = np.asarray(v["Genes"], dtype=np.int32)
+        out[f"cells_{i}"] = np.asarray(v["Cells"], dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "mcmc_cell_gene.npz"), **out)
+    print("mcmc_obj@cell_gene:", [(str(n), len(out[f"genes_{i}"]), len(out[f"cells_{i}"])) for i, n in enumerate(out["names"])])
+
+
 def main():
     obj = rda.read_rda(f"{REF}/data/infercnv_object_example.rda")["infercnv_object_example"]
     expr = rda.as_matrix(obj.attrs["expr.data"])
@@ -141,6 +171,8 @@ def main():
     mc = rda.read_rda(f"{REF}/data/mcmc_obj.rda")["mcmc_obj"]
     np.savez_compressed(os.path.join(HERE, "hmm_states_example.npz"), HMM_states=hs,
                         mu=np.asarray(mc.attrs["mu"]), sig=np.asarray(mc.attrs["sig"]))
+
+    mcmc_cell_gene(mc)
 
     # genes per chromosome of the bundled gene-position file, file order
     counts_by_chr = {}

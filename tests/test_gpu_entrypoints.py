@@ -119,9 +119,11 @@ def test_config1_example_run_inputs_through_the_hip_path(dev, run_inputs):
 
 @pytest.mark.parametrize("which", ["B", "C"])
 def test_hmm_states_rda_through_the_hip_path(dev, golden_dir, which):
-    """The reference's only HMM artefact, data/HMM_states.rda, through the HIP path: counts of the example object -> steps
-    3, 4 -> fused chain -> group means -> i6 Viterbi per group (C ABI, device-resident) with a parameter set that reproduces
-    the fixture (tests/test_hmm_pin.py::HMM_STATES_PINS, found by tests/campaigns/fit_hmm_pin.py): all 9 226 group-gene calls equal."""
+    """A regression target, NOT a pin (tests/test_hmm_pin.py says why: seven FITTED parameters; with the fixture's paired means
+    9 142 / 9 226).  data/HMM_states.rda through the HIP path: counts of the example object -> steps 3, 4 -> fused chain ->
+    group means -> i6 Viterbi per group (C ABI, device-resident) with a fitted parameter set (HMM_STATES_PINS): the HIP path
+    agrees with the NumPy and the C restatement in all 9 226 group-gene calls; and with the PAIRED means (mcmc_obj@mu) it gives
+    the oracle's 9 142, call for call."""
     import oracle_np as onp
     from test_hmm_pin import HMM_STATES_PINS
     d = np.load(os.path.join(golden_dir, "infercnv_object_example.npz"))
@@ -136,6 +138,52 @@ def test_hmm_states_rda_through_the_hip_path(dev, golden_dir, which):
     torch.cuda.synchronize()
     assert int(bad.item()) == 0
     np.testing.assert_array_equal(to_host(st), gold)
+    paired = np.load(os.path.join(golden_dir, "hmm_states_example.npz"))["mu"]
+    st2, _ = dev.viterbi_groups(pre, cs, groups, paired, [0.24, 0.24], np.log(Pi), np.log(delta))
+    want2, _ = oc.viterbi_groups(to_host(pre), cs, groups, paired, [0.24, 0.24], np.log(Pi), np.log(delta))
+    np.testing.assert_array_equal(to_host(st2), want2)
+    assert int((want2 == gold).sum()) == 9142 * 10      # 20 cells: 10 per group, every cell carries its group's call
+
+
+def test_mcmc_obj_cell_gene_regions_through_the_hip_path(dev, golden_dir):
+    """SURVEY.md 8f #2 against the reference-held golden (tests/golden/mcmc_cell_gene.npz = data/mcmc_obj.rda @cell_gene /
+    @cnv_regions, the nine CNV regions the reference derived from data/HMM_states.rda): the device consensus
+    (icnv_state_consensus) + the host mirror of .define_cnv_gene_regions / generate_cnv_region_reports give the nine names,
+    their 1-based gene rows and their cell columns exactly, and the pred_cnv_genes.dat / cell_groupings files read back the way
+    getGenesCells does (R/inferCNV_BayesNet.R:245-266) give @cell_gene.  The fixture's counter starts at the tumour group
+    (observation groups only: the legacy group order, R/inferCNV_HMM.R:720), so the object here has no reference group."""
+    import tempfile
+    from infercnv_amd import cnv_regions
+    from infercnv_amd.infercnv_object import GeneOrder, InfercnvObject
+    d = np.load(os.path.join(golden_dir, "infercnv_object_example.npz"))
+    hs = np.load(os.path.join(golden_dir, "hmm_states_example.npz"))["HMM_states"].astype(np.float64)
+    cg = np.load(os.path.join(golden_dir, "mcmc_cell_gene.npz"))
+    names = [str(n) for n in cg["names"]]
+    chr_names = d["chr_levels"][d["chr_codes"] - d["chr_codes"].min()]
+    obj = InfercnvObject(expr_data=hs, gene_order=GeneOrder(chr_names, d["gene_start"], d["gene_stop"]),
+                         reference_grouped_cell_indices={}, observation_grouped_cell_indices={"tumor": d["obs_tumor"]})
+    res = cnv_regions.get_predicted_CNV_regions(obj, "consensus")
+    assert len(res) == 1 and res[0]["cell_group_name"] == "tumor"
+    reported = [(rn, r) for rn, r in res[0]["gene_regions"] if r["state"] != 3]
+    assert [rn for rn, _ in reported] == names
+    for i, (rn, r) in enumerate(reported):
+        assert np.array_equal(r["gene"] + 1, cg[f"genes_{i}"])
+    cells = obj.cells()
+    assert np.array_equal(np.sort(np.nonzero(np.isin(cells, res[0]["cells"]))[0]) + 1, cg["cells_0"])
+    # ... and through the report files, read back like getGenesCells
+    with tempfile.TemporaryDirectory() as tmp:
+        cnv_regions.generate_cnv_region_reports(obj, "17_HMM_pred", tmp, ignore_neutral_state=3, by="consensus")
+        rows = [l.split("\t") for l in open(os.path.join(tmp, "17_HMM_pred.pred_cnv_genes.dat")).read().splitlines()[1:]]
+        grp = [l.split("\t") for l in open(os.path.join(tmp, "17_HMM_pred.cell_groupings")).read().splitlines()[1:]]
+    seen = list(dict.fromkeys(r[1] for r in rows))                       # unique(gene_region_name), order of appearance
+    assert seen == names and sorted(seen) == [str(v) for v in cg["levels"]]
+    genes = obj.genes()
+    for i, n in enumerate(names):
+        cur = [r for r in rows if r[1] == n]
+        gene_idx = np.nonzero(np.isin(genes, [r[3] for r in cur]))[0] + 1
+        sub = {r[0] for r in cur}
+        cells_idx = np.nonzero(np.isin(cells, [c for g, c in grp if g in sub]))[0] + 1
+        assert np.array_equal(gene_idx, cg[f"genes_{i}"]) and np.array_equal(cells_idx, cg[f"cells_{i}"])
 
 
 def test_below_min_mean_expr_cutoff_reference_literals_through_the_hip_path(dev):

@@ -1368,7 +1368,9 @@ def test_chain_missing_values_policy_against_the_reference_semantics(dev):
     assert np.abs(to_host(pre)[:, clean] - want_pre[:, clean]).max() < 1e-11
 
 
-@pytest.mark.parametrize("case", ["full_chain", "no_bounds", "smooth_only", "centre_median", "centre_mean", "nan_in_reference_cell"])
+@pytest.mark.parametrize("case", ["full_chain", "no_bounds", "smooth_only", "centre_median", "centre_mean", "nan_in_reference_cell",
+                                  "full_chain_in_place", "no_bounds_in_place", "no_bounds_nan_in_reference_cell",
+                                  "from_step_9_nan_in_reference_cell"])
 def test_chain_na_aware_reference_semantics(dev, case):
     """ICNV_ST_NA_AWARE (round 5): the cells that hold a NaN come out the way the reference's step functions treat an NA
     (oracle_np.run_chain_na: R/inferCNV_ops.R:1757-1768 which() never selects an NA -> 0 with bounds; :2974-2975 the clamp
@@ -1390,16 +1392,41 @@ def test_chain_na_aware_reference_semantics(dev, case):
     xn[cs[7]:cs[8] - 1, 21] = np.nan                           # one value left on a chromosome
     xn[rng.integers(0, G, 60), 25] = np.nan                    # scattered
     xn[:, 30] = np.nan                                         # a cell of nothing but NAs
-    if case == "nan_in_reference_cell":
-        xn[700, 2] = np.nan                                    # the gene's reference mean is NA: with bounds the whole gene comes out 0
-        xn[900:905, 6] = np.nan
+    if "nan_in_reference_cell" in case:
+        xn[700, 2] = np.nan                                    # the gene's reference mean is NA: with bounds the whole gene comes out 0,
+        xn[900:905, 6] = np.nan                                # without bounds x - NA = NA for that gene in EVERY cell
     na = _lib.ST_NA_AWARE
     xd = to_dev(xn)
-    if case in ("full_chain", "no_bounds", "nan_in_reference_cell"):
-        ub = case != "no_bounds"
-        out, pre = dev.smooth_chain(xd, cs, refs, use_bounds=ub, stage_mask=0x7F | na, want_pre_denoise=True)
+    if case == "from_step_9_nan_in_reference_cell":
+        # round 6 (ADVICE): a chain WITHOUT step 8 leaves a reference cell's NaN in its cached column; the reference cells' share of
+        # the apply continues from the cache and must treat it the reference's way too (step 12 with bounds: NA -> 0)
+        m = 0x7F & ~0x01
+        out, pre = dev.smooth_chain(xd, cs, refs, stage_mask=m | na, want_pre_denoise=True)
+        with np.errstate(invalid="ignore"):                    # the step functions of oracle_np.run_chain_na from step 9 on
+            y = onp.apply_max_threshold_bounds(xn, 3.0)
+            y = onp.smooth_by_chromosome_na(y, chr_codes, 101)
+            y = onp.center_columns_na(y)
+            y = onp.subtract_expr(y, onp.get_normal_gene_mean_bounds(y, refs), True)
+            want_pre = onp.invert_log2(y)
+        got_pre = to_host(pre)
+        assert not np.isnan(want_pre).any()                    # step 12 with bounds turns every NA (value or bound) into 0 ...
+        assert (want_pre[700] == 1.0).all() and (want_pre[900:905] == 1.0).all()   # ... the genes whose reference mean is NA: 2^0
+        assert not np.isnan(got_pre).any()
+        assert np.abs(got_pre - want_pre).max() < 1e-11
+        return
+    if case in ("full_chain", "no_bounds", "nan_in_reference_cell", "full_chain_in_place", "no_bounds_in_place", "no_bounds_nan_in_reference_cell"):
+        ub = not case.startswith("no_bounds")
+        if case.endswith("_in_place"):
+            # round 6 (ADVICE, medium): expr_out may alias expr_in (include/icnv.h); the NA pass must still see the ORIGINAL columns
+            work = xd.clone()
+            out, pre = dev.smooth_chain(work, cs, refs, use_bounds=ub, stage_mask=0x7F | na, want_pre_denoise=True, out=work)
+            assert out.data_ptr() == work.data_ptr()
+        else:
+            out, pre = dev.smooth_chain(xd, cs, refs, use_bounds=ub, stage_mask=0x7F | na, want_pre_denoise=True)
         want, want_pre = onp.run_chain_na(xn, chr_codes, refs, use_bounds=ub, return_pre_denoise=True)
         got_pre, got = to_host(pre), to_host(out)
+        if case == "no_bounds_nan_in_reference_cell":
+            assert np.isnan(want_pre[700]).all() and np.isnan(want_pre[900:905]).all()   # x - NA: the whole gene, every cell
         assert np.array_equal(np.isnan(got_pre), np.isnan(want_pre)), case
         if ub:
             assert not np.isnan(want_pre[:, :30]).any() and np.isnan(want_pre[:, 30]).sum() == 0   # with bounds step 8 turns every NA into 0
