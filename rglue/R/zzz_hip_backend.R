@@ -233,9 +233,20 @@ hip_predict_CNV_via_HMM_on_tumor_subclusters_per_chr <- function(infercnv_obj, s
     if (!is.matrix(x)) x <- as.matrix(x)
     hmm.data <- x
     hmm.data[, ] <- -1
-    for (chr in unique(infercnv_obj@gene_order[[C_CHR]])) {
-        rows <- which(infercnv_obj@gene_order[[C_CHR]] == chr)
-        groups <- subclusters_per_chr[[chr]]
+    ## The reference lapply()s over the FACTOR unique(gene_order$chr) and indexes `subclusters_per_chr[[chr]]` with its elements,
+    ## i.e. by the level's integer CODE (R/inferCNV_HMM.R:430, 443-447); its producer fills the list over levels(chr) under the
+    ## level names (R/inferCNV_tumor_subclusters.R:651-652), so code, name and level order agree there.  Here: by name when the
+    ## list carries this chromosome's name, else by the level code (factor column) / the position in unique() order (character column).
+    chr_col <- infercnv_obj@gene_order[[C_CHR]]
+    chrs <- unique(chr_col)
+    for (k in seq_along(chrs)) {
+        chr <- chrs[k]
+        rows <- which(chr_col == chr)
+        key <- as.character(chr)
+        pos <- if (is.factor(chr_col)) as.integer(chr) else k
+        groups <- if (!is.null(names(subclusters_per_chr)) && key %in% names(subclusters_per_chr)) subclusters_per_chr[[key]]
+                  else if (pos <= length(subclusters_per_chr)) subclusters_per_chr[[pos]]
+                  else NULL
         if (length(rows) == 0 || length(groups) == 0) next
         g <- .icnv_pack(groups)
         xc <- x[rows, , drop = FALSE]

@@ -142,6 +142,37 @@ def mcmc_cell_gene(mc=None):
     print("mcmc_obj@cell_gene:", [(str(n), len(out[f"genes_{i}"]), len(out[f"cells_{i}"])) for i, n in enumerate(out["names"])])
 
 
+STEP_FUNCTIONS = {   # the step functions the R glue re-binds (rglue/R/zzz_hip_backend.R: .icnv_enable_hip_backend), and their files
+    "R/inferCNV_ops.R": ["subtract_ref_expr_from_obs", "apply_max_threshold_bounds", "smooth_by_chromosome",
+                         "center_cell_expr_across_chromosome", "invert_log2", "clear_noise_via_ref_mean_sd", "clear_noise",
+                         "get_average_bounds", "scale_infercnv_expr", "remove_outliers_norm"],
+    "R/inferCNV_HMM.R": ["predict_CNV_via_HMM_on_indiv_cells", "predict_CNV_via_HMM_on_tumor_subclusters",
+                         "predict_CNV_via_HMM_on_tumor_subclusters_per_chr", "predict_CNV_via_HMM_on_whole_tumor_samples",
+                         "assign_HMM_states_to_proxy_expr_vals"],
+    "R/inferCNV_i3HMM.R": ["i3HMM_predict_CNV_via_HMM_on_indiv_cells", "i3HMM_predict_CNV_via_HMM_on_tumor_subclusters",
+                           "i3HMM_predict_CNV_via_HMM_on_whole_tumor_samples", "i3HMM_assign_HMM_states_to_proxy_expr_vals"],
+    "R/noise_reduction.R": ["apply_median_filtering"],
+}
+
+
+def step_function_signatures():
+    """Names, order and default-carrying flags of the formals of the reference's step functions ->
+    r_step_function_signatures.json: what the R glue's replacements must accept (tests/test_host.py)."""
+    import json
+    sys.path.insert(0, HERE)
+    import r_signatures
+    out = {}
+    for f, names in STEP_FUNCTIONS.items():
+        src = open(f"{REF}/{f}").read()
+        for n in names:
+            fm = r_signatures.formals(src, n)
+            assert fm, (f, n)
+            out[n] = {"file": f, "formals": [a for a, _ in fm], "has_default": [bool(d) for _, d in fm]}
+    with open(os.path.join(HERE, "r_step_function_signatures.json"), "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    print("step function signatures:", {k: v["formals"] for k, v in out.items()})
+
+
 def main():
     obj = rda.read_rda(f"{REF}/data/infercnv_object_example.rda")["infercnv_object_example"]
     expr = rda.as_matrix(obj.attrs["expr.data"])
@@ -173,6 +204,7 @@ def main():
                         mu=np.asarray(mc.attrs["mu"]), sig=np.asarray(mc.attrs["sig"]))
 
     mcmc_cell_gene(mc)
+    step_function_signatures()
 
     # genes per chromosome of the bundled gene-position file, file order
     counts_by_chr = {}

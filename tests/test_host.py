@@ -629,3 +629,27 @@ def test_bench_self_launch_starts_n_ranks_with_every_flag_passed_through(monkeyp
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert not seen and "WORLD_SIZE is 2" in str(e.value.code)
+
+
+def test_r_wrappers_take_the_formals_of_the_step_functions_they_replace():
+    """Every `hip_<step function>` of rglue/R/zzz_hip_backend.R is bound over the reference's function of that name
+    (.icnv_enable_hip_backend), so it must accept the same formals in the same order, with a default wherever the reference
+    has one -- infercnv::run() calls them positionally and by name (R/inferCNV_ops.R:771-1589).  The reference's signatures are
+    a committed fixture (tests/golden/r_step_function_signatures.json, extracted by tests/golden/make_golden.py from the
+    reference's sources: names, order, default flags); the glue is read with the same parser (no R in this image).  Also: the
+    backend switch re-binds exactly these functions, and each `hip_*` body closes (its formals parse at all)."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import r_signatures
+    rsrc = open(os.path.join(ROOT, "rglue", "R", "zzz_hip_backend.R")).read()
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "r_step_function_signatures.json")))
+    assert len(want) >= 20
+    swap = dict(re.findall(r'(\w+)\s*=\s*"(hip_\w+)"', rsrc[rsrc.index("swap <- c("):]))
+    for name, sig in want.items():
+        got = r_signatures.formals(rsrc, "hip_" + name)
+        assert got is not None, f"no hip_{name} in the R glue"
+        assert [a for a, _ in got] == sig["formals"], (name, [a for a, _ in got], sig["formals"])
+        for (a, has), ref_has in zip(got, sig["has_default"]):
+            assert has or not ref_has, f"hip_{name}: `{a}` has a default in the reference ({sig['file']}) but not in the glue"
+        assert swap.get(name) == "hip_" + name, f"{name} is not re-bound by .icnv_enable_hip_backend"
+    assert set(swap) == set(want), sorted(set(swap) ^ set(want))
