@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -279,6 +280,18 @@ struct icnv_chain {
     bool large = false;
     int32_t max_chr_len = 0;
     DevBuf d_ref_off, d_large_tmp;
+    // Round 6, pass 1 of the two-pass chain: the chromosomes in groups that fit the 1024 x 11 geometry of the fused kernel, which
+    // runs steps 8 / 9 / 10 on each group as a strided view of the matrix (chain_w11s.hip).  Empty: a chromosome does not fit -- the
+    // (2T + 1)-tap pass of chain_large.hip serves the whole matrix.
+    struct ViewGroup {
+        int32_t chr0, n_chr, g0, G;            // chromosomes [chr0, chr0 + n_chr), genes [g0, g0 + G)
+        std::vector<int32_t> chr_start;        // relative to g0, n_chr + 1 entries
+        std::vector<double> inv_tab, inv_dict;
+        std::vector<uint32_t> inv_codes;
+        bool inv_coded = false;
+        DevBuf d_chr, d_inv, d_inv_codes, d_inv_dict;
+    };
+    std::vector<std::unique_ptr<ViewGroup>> views;
     // Reference-cell cache: the round that first runs the expensive stages (smoothing, centring) on the reference
     // cells keeps its output (one column per position of ref_idx), so that the later rounds and the apply pass
     // continue from it instead of smoothing the same cells again (three times per chain otherwise).
@@ -450,6 +463,32 @@ static int chain_upload(icnv_chain *ch, hipStream_t s) {
     if (ch->large) {
         ch->cache_enabled = false;
         if (!ch->ref_idx.empty() && (rc = ch->d_large_tmp.alloc(ch->ref_idx.size() * (size_t)G * sizeof(double)))) return rc;
+        // pass 1 as strided views of the fused kernel: whole chromosomes, greedily, while the group fits the 1024 x 11 geometry
+        const char *old_s = std::getenv("ICNV_CHAIN_LARGE_TAPS");   // developer / test switch: 1 = the (2T + 1)-tap pass of round 1-5
+        if (ch->T >= 1 && !(old_s && old_s[0] == '1')) {
+            bool ok = true;
+            int k = 0;
+            while (k < ch->cfg.n_chr && ok) {
+                int k1 = k;
+                // (the upper limits only while the group grows; a view also needs four genes -- checked below on the finished groups)
+                while (k1 < ch->cfg.n_chr && chain_view_fits(std::max(ch->chr_start[k1 + 1] - ch->chr_start[k], 4), k1 + 1 - k, ch->T)) ++k1;
+                if (k1 == k) { ok = false; break; }   // one chromosome alone is too long for the geometry
+                auto v = std::make_unique<icnv_chain::ViewGroup>();
+                v->chr0 = k; v->n_chr = k1 - k; v->g0 = ch->chr_start[k]; v->G = ch->chr_start[k1] - ch->chr_start[k];
+                for (int c = k; c <= k1; ++c) v->chr_start.push_back(ch->chr_start[c] - v->g0);
+                ch->views.push_back(std::move(v));
+                k = k1;
+            }
+            for (auto &v : ch->views) ok = ok && chain_view_fits(v->G, v->n_chr, ch->T);
+            if (!ok) ch->views.clear();
+            for (auto &v : ch->views) {
+                if ((rc = chain_build_inv_table(v->chr_start.data(), v->n_chr, v->G, ch->T, v->inv_tab, v->inv_codes, v->inv_dict, v->inv_coded, true))) return rc;
+                if ((rc = upload(v->d_chr, v->chr_start.data(), v->chr_start.size(), s))) return rc;
+                if ((rc = upload(v->d_inv, v->inv_tab.data(), v->inv_tab.size(), s))) return rc;
+                if ((rc = upload(v->d_inv_codes, v->inv_codes.data(), v->inv_codes.size(), s))) return rc;
+                if ((rc = upload(v->d_inv_dict, v->inv_dict.data(), v->inv_dict.size(), s))) return rc;
+            }
+        }
         ch->uploaded = true;
         return ICNV_OK;
     }
@@ -508,8 +547,37 @@ static int large_smooth_center(icnv_chain *ch, uint32_t m, const double *in, con
     LargeChainArgs a = large_args(ch);
     a.in = in; a.in_rows = in_rows; a.out = out; a.out_rows = out_rows; a.n_rows = n_rows;
     a.mask = m & (ICNV_ST_SUBTRACT_REF_1 | ICNV_ST_MAX_THRESH | ICNV_ST_SMOOTH);
-    int rc = launch_chain_large_smooth(a, ch->max_chr_len, s);
-    if (rc) return rc;
+    int rc;
+    if (!ch->views.empty() && (a.mask & ICNV_ST_SMOOTH) && !(in_rows && out_rows)) {
+        // Round 6: steps 8 / 9 / 10 by the fused kernel, one launch per group of chromosomes (a strided view of the matrix): the
+        // O(1) sliding pyramid of chain_kernel.inc instead of 2T + 1 taps per gene, sixteen wavefronts per CU instead of four
+        for (auto &v : ch->views) {
+            ChainArgs c;
+            std::memset(&c, 0, sizeof(c));
+            c.in = in + v->g0;
+            c.out = out + v->g0;
+            c.G = v->G;
+            c.ld = (int32_t)ch->cfg.G;
+            c.cells = in_rows ? in_rows : out_rows;       // (rows read by list entry and written by position, or the other way round)
+            c.in_by_pos = in_rows ? 0 : 1;
+            c.out_by_pos = out_rows ? 0 : 1;
+            c.n_cells = n_rows;
+            c.chr_start = v->d_chr.as<int32_t>();
+            c.n_chr = v->n_chr;
+            c.T = ch->T;
+            c.mask = a.mask;
+            c.use_bounds = ch->cfg.use_bounds;
+            c.max_thresh = ch->cfg.max_thresh;
+            c.b1 = ch->d_b1.as<double>() + v->g0;
+            c.inv_pos = v->d_inv.as<double>();
+            c.inv_codes = v->d_inv_codes.as<uint32_t>();
+            c.inv_dict = v->d_inv_dict.as<double>();
+            c.inv_coded = v->inv_coded ? 1 : 0;
+            if ((rc = launch_chain_strided(c, s))) return rc;
+        }
+    } else if ((rc = launch_chain_large_smooth(a, ch->max_chr_len, s))) {
+        return rc;
+    }
     if (m & ICNV_ST_CENTER) {
         a.mask = m & (ICNV_ST_CENTER | ICNV_ST_CENTER_MEAN);
         if ((rc = launch_chain_large_center(a, s))) return rc;
@@ -523,8 +591,17 @@ static int large_round_partial(icnv_chain *ch, uint32_t bit, uint32_t m, const d
     const int32_t nref = (int32_t)ch->ref_idx.size();
     int rc;
     double *tmp = ch->d_large_tmp.as<double>();   // one row per position of the reference list
-    const bool any_sm = m & (ICNV_ST_SUBTRACT_REF_1 | ICNV_ST_MAX_THRESH | ICNV_ST_SMOOTH | ICNV_ST_CENTER);
-    if (any_sm && nref > 0 && (rc = large_smooth_center(ch, m, expr_in, ch->d_ref.as<int32_t>(), tmp, nullptr, nref, s))) return rc;
+    const uint32_t sm_bits = ICNV_ST_SUBTRACT_REF_1 | ICNV_ST_MAX_THRESH | ICNV_ST_SMOOTH | ICNV_ST_CENTER | ICNV_ST_CENTER_MEAN;
+    const bool any_sm = m & (sm_bits & ~(uint32_t)ICNV_ST_CENTER_MEAN);
+    // (round 6) the staged rows of the round in front serve this round when they hold the same stages of the same matrix: the
+    // denoise round continues from the step-12 round's rows instead of smoothing and centring the reference cells again
+    const bool staged = any_sm && ch->cache_in == expr_in && ch->cache_mask == (m & sm_bits);
+    if (any_sm && nref > 0 && !staged) {
+        ch->cache_in = nullptr;
+        if ((rc = large_smooth_center(ch, m, expr_in, ch->d_ref.as<int32_t>(), tmp, nullptr, nref, s))) return rc;
+        ch->cache_in = expr_in;
+        ch->cache_mask = m & sm_bits;
+    }
     if (bit == ICNV_ST_DENOISE) {
         if (nref > 0) {
             LargeChainArgs a = large_args(ch);
@@ -544,8 +621,16 @@ static int large_round_partial(icnv_chain *ch, uint32_t bit, uint32_t m, const d
 
 static int large_apply(icnv_chain *ch, const double *expr_in, double *expr_out, double *pre_denoise, hipStream_t s) {
     const int32_t C = (int32_t)ch->cfg.C;
-    int rc = large_smooth_center(ch, ch->mask, expr_in, nullptr, expr_out, nullptr, C, s);
-    if (rc) return rc;
+    int rc;
+    if (!ch->views.empty() && (ch->mask & ICNV_ST_SMOOTH) && chain_large_center_finish_covers((int32_t)ch->cfg.G)) {
+        // the two-pass form (round 6): pass 1 = steps 8 - 10 into expr_out, pass 2 = the centre and steps 12 - 22 from registers
+        if ((rc = large_smooth_center(ch, ch->mask & ~(uint32_t)(ICNV_ST_CENTER | ICNV_ST_CENTER_MEAN), expr_in, nullptr, expr_out, nullptr, C, s))) return rc;
+        LargeChainArgs a = large_args(ch);
+        a.in = expr_out; a.out = expr_out; a.pre = pre_denoise; a.n_rows = C;
+        a.mask = ch->mask & (ICNV_ST_CENTER | ICNV_ST_CENTER_MEAN | ICNV_ST_SUBTRACT_REF_2 | ICNV_ST_INVERT_LOG2 | ICNV_ST_DENOISE);
+        return launch_chain_large_center_finish(a, s);
+    }
+    if ((rc = large_smooth_center(ch, ch->mask, expr_in, nullptr, expr_out, nullptr, C, s))) return rc;
     LargeChainArgs a = large_args(ch);
     a.in = expr_out; a.out = expr_out; a.pre = pre_denoise; a.n_rows = C;
     a.mask = ch->mask & (ICNV_ST_SUBTRACT_REF_2 | ICNV_ST_INVERT_LOG2 | ICNV_ST_DENOISE);
@@ -561,6 +646,7 @@ int icnv_chain_round_partial_dev(icnv_chain_t *ch, int round, const double *expr
     const uint32_t bit = (uint32_t)ch->round_stage[round];
     const int64_t G = ch->cfg.G;
     const int ng = ch->cfg.n_ref_grp;
+    if (round == 0) ch->cache_in = nullptr;   // a new run: whatever the rounds of an earlier run staged is not this matrix's (same address or not)
     ChainArgs a = chain_args(ch, expr_in);
     a.mask = stages_before(ch->mask, bit) | (ch->mask & ICNV_ST_CENTER_MEAN);
     if (ch->large) {
@@ -676,6 +762,7 @@ static int chain_apply_masked(icnv_chain_t *ch, uint32_t amask, const double *ex
                               hipStream_t s) {
     int rc;
     if (ch->large) {
+        ch->cache_in = nullptr;   // (the rounds' staged rows are not used by the apply)
         const uint32_t keep = ch->mask;
         ch->mask = amask;
         rc = large_apply(ch, expr_in, expr_out, (amask & ICNV_ST_DENOISE) ? pre_denoise : nullptr, s);

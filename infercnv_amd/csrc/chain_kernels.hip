@@ -406,14 +406,17 @@ bool chain_fused_fits(int64_t G, int32_t n_chr, int32_t T) {
 }
 
 int chain_build_inv_table(const int32_t *chr_start, int32_t n_chr, int32_t G, int32_t T, std::vector<double> &tab,
-                          std::vector<uint32_t> &codes, std::vector<double> &dict, bool &coded) {
+                          std::vector<uint32_t> &codes, std::vector<double> &dict, bool &coded, bool view_1024x11) {
     ChainGeom g;
     coded = true;
     tab.clear();
     codes.clear();
     dict.clear();
     if (T < 1) return ICNV_OK;
-    if (!chain_geom(G, n_chr, T, g))
+    if (view_1024x11) {   // a strided view (launch_chain_strided) always runs the 1024 x 11 geometry, however few genes it holds
+        g.nt = 1024; g.lmax = 11; g.pad = (T + 3) & ~1;
+        if (!chain_view_fits(G, n_chr, T)) ICNV_FAIL(ICNV_ERR_ARG, "normalisation table of a view that does not fit the 1024 x 11 geometry");
+    } else if (!chain_geom(G, n_chr, T, g))
         ICNV_FAIL(ICNV_ERR_UNSUPPORTED,
                   "fused smoothing chain: genes + (n_chr+1)*(window/2+2) padding exceed the LDS-resident limit of 17920 positions");
     tab.assign((size_t)g.nt * (g.lmax + 1), 0.0);

@@ -104,12 +104,16 @@ __global__ void __launch_bounds__(256) large_smooth_kernel(const LargeChainArgs 
 
 // ---------------------------------------------------------------- M: step 11 (in place)
 // value of 0-based rank `rank` among the G values of row p (NaN when fewer than rank + 1 values are comparable)
-template <int NT>
-__device__ double lg_select_rank(const double *p, int G, int rank, uint32_t *hist, double *cand, double *red, int32_t *sel,
-                                 double *seld) {
+// (`each(f)`: calls f(x) for every value this thread holds of the row -- read from global memory, or kept in registers)
+// `next` (nullable): receives the value of rank + 1 when it lies among the ranked candidates of the same bin (the usual case: the
+// two middle values of an even G in one selection instead of two), NaN-boxed "unknown" otherwise: *have_next = 0
+template <int NT, class Each>
+__device__ __forceinline__ double lg_select_rank_of(Each each, int rank, uint32_t *hist, double *cand, double *red, int32_t *sel,
+                                                    double *seld, double *next = nullptr, int *have_next = nullptr) {
     const int t = threadIdx.x;
+    if (have_next) *have_next = 0;
     double lo = __builtin_inf(), hi = -__builtin_inf();
-    for (int g = t; g < G; g += NT) { const double x = p[g]; lo = fmin(lo, x); hi = fmax(hi, x); }
+    each([&](double x) { lo = fmin(lo, x); hi = fmax(hi, x); });
     lg_block_minmax<NT>(lo, hi, red);
     int base = 0;
     for (int level = 0; level < 80; ++level) {
@@ -118,24 +122,33 @@ __device__ double lg_select_rank(const double *p, int G, int rank, uint32_t *his
         if (t == 0) { sel[0] = -1; sel[3] = 0; }
         __syncthreads();
         const double scale = fmin((double)LG_BINS / (hi - lo), 0x1p1000);
-        for (int g = t; g < G; g += NT) {
-            const double x = p[g];
+        each([&](double x) {
             if (x >= lo && x <= hi) atomicAdd(&hist[min((uint32_t)__double2uint_rz((x - lo) * scale), (uint32_t)(LG_BINS - 1))], 1u);
-        }
+        });
         __syncthreads();
         if (t < 64) {   // one wavefront scans: lane l owns 32 bins
             constexpr int BPL = LG_BINS / 64;
+            // (an opaque copy of the lane index: the 32 bin addresses of a lane are invariant across levels and rows, and the compiler
+            // would otherwise keep them -- in scratch -- for the whole kernel)
+            int tl = t;
+            asm volatile("" : "+v"(tl));
+            const uint32_t *hb = hist + tl * BPL;
             uint32_t mine = 0;
-            for (int b = 0; b < BPL; ++b) mine += hist[t * BPL + b];
+#pragma unroll 1
+            for (int b = 0; b < BPL; b += 4) {
+                const uint4 h4 = *reinterpret_cast<const uint4 *>(hb + b);
+                mine += (h4.x + h4.y) + (h4.z + h4.w);
+            }
             uint32_t inc = mine;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o, 64); if (t >= o) inc += v; }
             const uint32_t before = inc - mine, rel = (uint32_t)(rank - base);
             if (rel >= before && rel < before + mine) {
                 uint32_t acc = before;
+#pragma unroll 1
                 for (int b = 0; b < BPL; ++b) {
-                    const uint32_t h = hist[t * BPL + b];
-                    if (rel >= acc && rel < acc + h) { sel[0] = t * BPL + b; sel[1] = (int)acc; sel[2] = (int)h; }
+                    const uint32_t h = hb[b];
+                    if (rel >= acc && rel < acc + h) { sel[0] = tl * BPL + b; sel[1] = (int)acc; sel[2] = (int)h; }
                     acc += h;
                 }
             }
@@ -144,13 +157,12 @@ __device__ double lg_select_rank(const double *p, int G, int rank, uint32_t *his
         const int sbin = sel[0], sbefore = sel[1], scnt = sel[2];
         if (sbin < 0) return __builtin_nan("");   // the rank lies beyond the comparable values (NaNs in the row)
         if (scnt <= LG_CAND) {
-            for (int g = t; g < G; g += NT) {
-                const double x = p[g];
+            each([&](double x) {
                 if (x >= lo && x <= hi && (int)min((uint32_t)__double2uint_rz((x - lo) * scale), (uint32_t)(LG_BINS - 1)) == sbin) {
                     const int pos = atomicAdd(&sel[3], 1);
                     if (pos < LG_CAND) cand[pos] = x;
                 }
-            }
+            });
             __syncthreads();
             const int want = rank - base - sbefore;
             for (int ci = t; ci < scnt; ci += NT) {
@@ -161,27 +173,35 @@ __device__ double lg_select_rank(const double *p, int G, int rank, uint32_t *his
                     less += (o < cv || (o == cv && cj < ci)) ? 1 : 0;
                 }
                 if (less == want) seld[0] = cv;
+                if (less == want + 1) seld[1] = cv;
             }
             __syncthreads();
             const double r = seld[0];
+            if (next && want + 1 < scnt) { *next = seld[1]; *have_next = 1; }
             __syncthreads();
             return r;
         }
         // refine inside the selected bin
         base += sbefore;
         double nlo = __builtin_inf(), nhi = -__builtin_inf();
-        for (int g = t; g < G; g += NT) {
-            const double x = p[g];
+        each([&](double x) {
             if (x >= lo && x <= hi && (int)min((uint32_t)__double2uint_rz((x - lo) * scale), (uint32_t)(LG_BINS - 1)) == sbin) {
                 nlo = fmin(nlo, x);
                 nhi = fmax(nhi, x);
             }
-        }
+        });
         lg_block_minmax<NT>(nlo, nhi, red);
         lo = nlo;
         hi = nhi;
     }
     return lo;
+}
+
+template <int NT>
+__device__ double lg_select_rank(const double *p, int G, int rank, uint32_t *hist, double *cand, double *red, int32_t *sel,
+                                 double *seld) {
+    const int t = threadIdx.x;
+    return lg_select_rank_of<NT>([&](auto f) { for (int g = t; g < G; g += NT) f(p[g]); }, rank, hist, cand, red, sel, seld);
 }
 
 __global__ void __launch_bounds__(LG_NT) large_center_kernel(const LargeChainArgs a) {
@@ -200,9 +220,15 @@ __global__ void __launch_bounds__(LG_NT) large_center_kernel(const LargeChainArg
             for (int g = t; g < G; g += LG_NT) s += p[g];
             center = lg_block_sum<LG_NT>(s, red) / (double)G;
         } else {   // R/inferCNV_ops.R:2098: median, mean of the two middle values for even G
-            const double m_lo = lg_select_rank<LG_NT>(p, G, (G - 1) >> 1, hist, cand, red, sel, seld);
+            double m_hi = 0.0;
+            int have = 0;
+            auto each = [&](auto f) { for (int g = t; g < G; g += LG_NT) f(p[g]); };
+            const double m_lo = lg_select_rank_of<LG_NT>(each, (G - 1) >> 1, hist, cand, red, sel, seld, &m_hi, &have);
             center = m_lo;
-            if (!(G & 1)) center = (m_lo + lg_select_rank<LG_NT>(p, G, G >> 1, hist, cand, red, sel, seld)) * 0.5;
+            if (!(G & 1)) {
+                if (!have) m_hi = lg_select_rank_of<LG_NT>(each, G >> 1, hist, cand, red, sel, seld);   // (workgroup-uniform: `have` comes from LDS)
+                center = (m_lo + m_hi) * 0.5;
+            }
         }
         __syncthreads();
         for (int g = t; g < G; g += LG_NT) p[g] -= center;
@@ -245,6 +271,102 @@ __global__ void __launch_bounds__(LG_NT) large_finish_kernel(const LargeChainArg
             if ((a.mask & ICNV_ST_DENOISE) && o > lo_d && o < hi_d) o = mu;   // strict bounds, R/inferCNV_ops.R:2335
             dst[g] = o;
         }
+    }
+}
+
+// ---------------------------------------------------------------- M + E in one pass (round 6): steps 11, 12, 14, 22
+// Pass 2 of the two-pass chain: the smoothed row (pass 1's output) is read ONCE into registers -- NS slots of two genes per thread,
+// G <= 2 NS x 1024 --, the median comes from the same histogram select (slots beyond G hold NaN: no comparison selects them, like a NaN
+// of the data), then steps 11 - 22 run on the registers and the denoised row and the HMM input are written: 8 B read + 16 B written
+// per gene and cell, where the M and E kernels read the row five to six times.  Arithmetic per value exactly as in those two kernels.
+template <int NS>
+__global__ void __launch_bounds__(LG_NT) large_center_finish_kernel(const LargeChainArgs a) {
+    __shared__ uint32_t hist[LG_BINS];
+    __shared__ double cand[LG_CAND];
+    __shared__ double red[2 * LG_NT / 64];
+    __shared__ int32_t sel[4];
+    __shared__ double seld[2];
+    typedef double dv2 __attribute__((ext_vector_type(2)));
+    const int G = a.G, t = threadIdx.x;
+    double mu = 0.0, lo_d = 0.0, hi_d = 0.0;
+    if (a.mask & ICNV_ST_DENOISE) { mu = a.denoise[0]; lo_d = mu - a.denoise[1]; hi_d = mu + a.denoise[1]; }
+    for (int row = blockIdx.x; row < a.n_rows; row += gridDim.x) {
+        const int64_t ri = a.in_rows ? a.in_rows[row] : row, ro = a.out_rows ? a.out_rows[row] : row;
+        const double *src = a.in + ri * (int64_t)G;
+        double v[NS][2];
+        // (opaque copies of the thread index, one per phase: computed from `t` itself, the per-slot addresses and validity masks are
+        // loop-invariant, get hoisted out of the row loop and spilled -- 600 to 1 200 bytes of scratch per lane before this)
+        int t1 = t;
+        asm volatile("" : "+v"(t1));
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int g = 2 * (t1 + s * LG_NT);
+            v[s][0] = v[s][1] = __builtin_nan("");
+            if (g + 1 < G) {
+                const dv2 d = __builtin_nontemporal_load(reinterpret_cast<const dv2 *>(src + g));
+                v[s][0] = d.x;
+                v[s][1] = d.y;
+            } else if (g < G) {
+                v[s][0] = src[g];
+            }
+        }
+        auto each = [&](auto f) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                f(v[s][0]);
+                f(v[s][1]);
+            }
+        };
+        double center = 0.0;
+        if (a.mask & ICNV_ST_CENTER_MEAN) {
+            double sum = 0.0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int g = 2 * (t1 + s * LG_NT);
+                if (g < G) sum += v[s][0];
+                if (g + 1 < G) sum += v[s][1];
+            }
+            center = lg_block_sum<LG_NT>(sum, red) / (double)G;
+        } else if (a.mask & ICNV_ST_CENTER) {   // R/inferCNV_ops.R:2098: median, mean of the two middle values for even G
+            double m_hi = 0.0;
+            int have = 0;
+            const double m_lo = lg_select_rank_of<LG_NT>(each, (G - 1) >> 1, hist, cand, red, sel, seld, &m_hi, &have);
+            center = m_lo;
+            if (!(G & 1)) {
+                if (!have) m_hi = lg_select_rank_of<LG_NT>(each, G >> 1, hist, cand, red, sel, seld);   // (workgroup-uniform: `have` comes from LDS)
+                center = (m_lo + m_hi) * 0.5;
+            }
+        }
+        double *dst = a.out + ro * (int64_t)G;
+        double *dpre = a.pre ? a.pre + ro * (int64_t)G : nullptr;
+        int t2 = t;
+        asm volatile("" : "+v"(t2));
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int g = 2 * (t2 + s * LG_NT);
+            double o[2], p2[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                double x = v[s][j];
+                if (g + j < G) {
+                    if (a.mask & (ICNV_ST_CENTER | ICNV_ST_CENTER_MEAN)) x -= center;
+                    if (a.mask & ICNV_ST_SUBTRACT_REF_2) x = lg_subtract_ref(x, a.b2[g + j], a.b2[G + g + j]);
+                    if (a.mask & ICNV_ST_INVERT_LOG2) x = exp2(x);   // R/inferCNV_ops.R:2818
+                }
+                p2[j] = x;
+                o[j] = ((a.mask & ICNV_ST_DENOISE) && x > lo_d && x < hi_d) ? mu : x;   // strict bounds, R/inferCNV_ops.R:2335
+            }
+            if (g + 1 < G) {
+                dv2 d;
+                if (dpre) { d.x = p2[0]; d.y = p2[1]; __builtin_nontemporal_store(d, reinterpret_cast<dv2 *>(dpre + g)); }
+                d.x = o[0]; d.y = o[1];
+                __builtin_nontemporal_store(d, reinterpret_cast<dv2 *>(dst + g));
+            } else if (g < G) {
+                if (dpre) dpre[g] = p2[0];
+                dst[g] = o[0];
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -300,6 +422,22 @@ int launch_chain_large_finish(const LargeChainArgs &a, hipStream_t stream) {
     const int grid = a.n_rows < 8 * num_cus() ? a.n_rows : 8 * num_cus();
     KernelTimer kt("chain_large_finish", stream);
     hipLaunchKernelGGL(large_finish_kernel, dim3(grid), dim3(LG_NT), 0, stream, a);
+    ICNV_HIP(hipGetLastError());
+    return ICNV_OK;
+}
+
+// steps 11 - 22 of `a.in` (the smoothed rows) in one pass; false when the row does not fit the kernel's registers (G > 32 768)
+bool chain_large_center_finish_covers(int32_t G) { return G <= 2 * 16 * LG_NT; }
+int launch_chain_large_center_finish(const LargeChainArgs &a, hipStream_t stream) {
+    if (a.n_rows <= 0) return ICNV_OK;
+    const int grid = a.n_rows < 2 * num_cus() ? a.n_rows : 2 * num_cus();
+    KernelTimer kt("chain_large_center_finish", stream);
+    const int need = (a.G + 2 * LG_NT - 1) / (2 * LG_NT);
+    if (need <= 8) hipLaunchKernelGGL(large_center_finish_kernel<8>, dim3(grid), dim3(LG_NT), 0, stream, a);
+    else if (need <= 10) hipLaunchKernelGGL(large_center_finish_kernel<10>, dim3(grid), dim3(LG_NT), 0, stream, a);
+    else if (need <= 12) hipLaunchKernelGGL(large_center_finish_kernel<12>, dim3(grid), dim3(LG_NT), 0, stream, a);
+    else if (need <= 16) hipLaunchKernelGGL(large_center_finish_kernel<16>, dim3(grid), dim3(LG_NT), 0, stream, a);
+    else ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "large_center_finish: more than 32 768 genes");
     ICNV_HIP(hipGetLastError());
     return ICNV_OK;
 }

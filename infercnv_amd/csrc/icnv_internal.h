@@ -114,9 +114,15 @@ struct ChainArgs {
     int32_t in_by_pos;      // 1: `in` holds one column per list position (a cache written through cache_out)
     double *cell_stats;     // MODE_CELL_STATS: [n_cells * 2] {sum, sd}
     int32_t out_by_pos;     // 1: `out` receives one column per list position (the reference-cell cache written by round B)
+    int32_t ld;             // 0, or (strided view, launch_chain_strided): doubles between the columns of in / out / pre_out, and between b1 / b2's lower and upper vectors
 };
 
 int launch_chain(const ChainArgs &a, int mode, hipStream_t stream);
+// Steps 8 / 9 / 10 (a.mask: any of them, with step 10) of a VIEW: the genes [g0, g0 + a.G) of every column -- a group of whole
+// chromosomes that fits the 1024 x 11 geometry (chain_view_fits) -- a.in / a.out point at gene g0 of column 0, a.b1 at gene g0 of the
+// lower vector, columns a.ld doubles apart (chain_w11s.hip).  Pass 1 of the chain for gene sets beyond the LDS-resident limit.
+int launch_chain_strided(const ChainArgs &a, hipStream_t stream);
+bool chain_view_fits(int64_t G_view, int32_t n_chr_view, int32_t T);
 // chain_na.hip: the list positions of `a` whose input column holds a NaN, recomputed with the reference's NA semantics
 // (same arguments as the apply launch it follows; flags_ws: a.n_cells bytes of workspace)
 // (all_flag, nullable: a device word that flags every cell when non-zero -- a NaN mean in the no-bounds mode)
@@ -149,12 +155,14 @@ size_t chain_large_lds_bytes(int32_t max_chr_len, int32_t T);
 int launch_chain_large_smooth(const LargeChainArgs &a, int32_t max_chr_len, hipStream_t stream);
 int launch_chain_large_center(const LargeChainArgs &a, hipStream_t stream);
 int launch_chain_large_finish(const LargeChainArgs &a, hipStream_t stream);
+bool chain_large_center_finish_covers(int32_t G);
+int launch_chain_large_center_finish(const LargeChainArgs &a, hipStream_t stream);   // steps 11, 12, 14, 22 in ONE pass over the smoothed rows
 int launch_chain_large_group_sums(const double *x, int32_t G, const int32_t *idx_dev, const int32_t *off_dev, int32_t n_grp,
                                   double *sums_counts, hipStream_t stream);
 // Host: per-position normalisation table of the smoothing stage for this geometry, in the kernel's
 // [(LMAX+1)/2][NT] double2 layout (R/inferCNV_ops.R:2410-2440: pyramid weights renormalised at chromosome edges).
 int chain_build_inv_table(const int32_t *chr_start, int32_t n_chr, int32_t G, int32_t T, std::vector<double> &tab,
-                          std::vector<uint32_t> &codes, std::vector<double> &dict, bool &coded);
+                          std::vector<uint32_t> &codes, std::vector<double> &dict, bool &coded, bool view_1024x11 = false);
 int launch_reduce_partials(const double *partial, int nblk, int32_t G, double *out, double count,
                            double *count_out, hipStream_t stream);
 // raw per-gene sums of all reference groups in one launch (+ the reduction over its splits): sums_counts = [G*n_grp | n_grp]

@@ -33,11 +33,11 @@ def geometry(G, n_chr=22, T=50):
         if npos <= 768 * L and G <= 768 * ((L - 1) // 2) * 2: return f"768x{L}", npos
     if npos <= 768 * 23: return "768x23", npos
     if npos <= 512 * 35: return "512x35", npos
-    return "three-pass", npos
+    return ("three-pass (2T+1 taps)" if os.environ.get("ICNV_CHAIN_LARGE_TAPS") == "1" else "two-pass (views + centre/finish)"), npos
 
 
 means, sd, logPi, logDelta = synth.hmm_params_i6()
-for G in [int(a) for a in (sys.argv[1].split(",") if len(sys.argv) > 1 else "6000,8000,10000,11000,12000,14000,16000,18000,20000".split(","))]:
+for G in [int(a) for a in (sys.argv[1].split(",") if len(sys.argv) > 1 else "6000,8000,9939,10000,11000,12000,14000,16000,18000,20000,24000".split(","))]:
     x, cs = synth.make_matrix_torch(G, C, "cuda")
     refs, _ = synth.groups(C)
     out, pre = torch.empty_like(x), torch.empty_like(x)

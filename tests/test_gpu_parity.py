@@ -216,15 +216,26 @@ def _random_chr_layout(G, n_chr, rng, with_single=True):
     return cs
 
 
+@pytest.mark.parametrize("taps", [False, True])
 @pytest.mark.parametrize("G,C,n_chr,kw", [(24000, 20, 30, {}), (19001, 9, 24, {"window_length": 151}),
                                           (30000, 6, 2, {"stage_mask": 0x3F}), (26000, 8, 40, {"stage_mask": 0x8F}),
-                                          (21000, 7, 25, {"use_bounds": False, "max_thresh": None})])
-def test_chain_large_gene_sets_vs_oracle(dev, G, C, n_chr, kw):
-    """Gene sets beyond the fused kernel's LDS-resident limit run the three-pass chain (chain_large.hip)."""
+                                          (21000, 7, 25, {"use_bounds": False, "max_thresh": None}),
+                                          (18000, 300, 22, {}), (20000, 300, 22, {}), (33001, 5, 60, {}), (40000, 4, 50, {"window_length": 31})])
+def test_chain_large_gene_sets_vs_oracle(dev, G, C, n_chr, kw, taps, monkeypatch):
+    """Gene sets beyond the fused kernel's LDS-resident limit.  Round 6: the TWO-PASS chain -- pass 1 = steps 8 - 10 by the fused
+    kernel on groups of whole chromosomes (strided views of the matrix, chain_w11s.hip), pass 2 = the centre and steps 12 - 22 from
+    registers (chain_large.hip: large_center_finish_kernel) -- and, with ICNV_CHAIN_LARGE_TAPS=1 or when a chromosome alone exceeds a
+    view (the 14 000 / 16 000-gene case) or the row exceeds 32 768 genes, the three-pass chain of rounds 1 - 5.  18 000 and 20 000
+    genes in the bench's chromosome layout: the sizes profiles/r05_sweep.json showed at 14 x the 10 000-gene per-cell cost."""
     from infercnv_amd import synth
+    if taps:
+        monkeypatch.setenv("ICNV_CHAIN_LARGE_TAPS", "1")
     rng = np.random.default_rng(G)
     x = rng.normal(0.0, 1.0, size=(G, C)) + rng.normal(0.0, 0.5, size=(G, 1))
-    cs = _random_chr_layout(G, n_chr, rng) if n_chr > 2 else np.array([0, 14000, G], dtype=np.int32)
+    if n_chr == 22:
+        cs = synth.make_matrix_np(G, 1)[1]                  # the bench's chromosome layout
+    else:
+        cs = _random_chr_layout(G, n_chr, rng) if n_chr > 2 else np.array([0, 14000, G], dtype=np.int32)
     refs = [np.array([1, 0], dtype=np.int32), np.arange(2, max(3, C // 3), dtype=np.int32)]
     out, pre = dev.smooth_chain(to_dev(x), cs, refs, want_pre_denoise=True, **kw)
     okw = {k: v for k, v in kw.items() if k != "stage_mask"}
@@ -253,9 +264,13 @@ def test_chain_three_pass_equals_fused(dev, monkeypatch):
     xd = to_dev(x)
     out_f, pre_f = dev.smooth_chain(xd, cs, refs, want_pre_denoise=True)
     monkeypatch.setenv("ICNV_CHAIN_LARGE", "1")
+    monkeypatch.setenv("ICNV_CHAIN_LARGE_TAPS", "1")        # the (2T + 1)-tap pass: an implementation that shares no smoothing code with the fused kernel
     out_l, pre_l = dev.smooth_chain(xd, cs, refs, want_pre_denoise=True)
+    monkeypatch.delenv("ICNV_CHAIN_LARGE_TAPS")
+    out_2, pre_2 = dev.smooth_chain(xd, cs, refs, want_pre_denoise=True)   # the two-pass form (round 6) on the same size
     monkeypatch.delenv("ICNV_CHAIN_LARGE")
     assert (pre_f - pre_l).abs().max().item() < 1e-12
+    assert (pre_2 - pre_l).abs().max().item() < 1e-12 and (pre_2 - pre_f).abs().max().item() < 1e-12
     _, ref_pre, (mu, s) = oc.smooth_chain(x, cs, refs, want_pre_denoise=True)
     # two GPU implementations against each other: the fused kernel's output as `got`, the three-pass one as the reference
     check_denoise_flips(to_host(out_f), to_host(out_l), to_host(pre_l), mu, s, tol=1e-12, label="fused vs three-pass")
