@@ -188,6 +188,13 @@ int icnv_chain_round_partial_dev(icnv_chain_t *chain, int round, const double *e
 int icnv_chain_round_finish_dev(icnv_chain_t *chain, int round, void *stream);
 int icnv_chain_apply_dev(icnv_chain_t *chain, const double *expr_in, double *expr_out,
                          double *pre_denoise, void *stream);
+/* The same with a LEADING DIMENSION for the HMM input: column c of pre_denoise starts at pre_denoise + c * ld_pre (ld_pre >= G;
+ * 0 or G: contiguous columns, the R layout).  A multiple of 16 puts every column on a cache line of its own, which is what
+ * icnv_viterbi_cells_ld_dev reads fastest when G is not a multiple of 16 (every real, filtered gene set).  Device-resident
+ * pipelines only -- an R matrix is contiguous; the host-buffer entry points pad on upload by themselves.  Fused chain with
+ * step 22 only (ICNV_ERR_UNSUPPORTED otherwise).  Replaces nothing in the reference: a layout option of this library. */
+int icnv_chain_apply_ld_dev(icnv_chain_t *chain, const double *expr_in, double *expr_out,
+                            double *pre_denoise, int64_t ld_pre, void *stream);
 /* Copies {mu, s} of the denoise stage to the host (synchronises the stream). */
 int icnv_chain_get_denoise(icnv_chain_t *chain, double *mu_s, void *stream);
 void icnv_chain_end(icnv_chain_t *chain);
@@ -292,6 +299,14 @@ int icnv_viterbi_cells_dev(const double *expr, uint8_t *states, int64_t G, int64
                            const int32_t *chr_start, int32_t n_chr, int32_t K, const double *mean,
                            double sd_shared, const double *logPi, const double *logDelta,
                            int32_t *n_underflow_dev, void *stream);
+/* The same on matrices with LEADING DIMENSIONS: expr[g + ld_expr * c], states[g + ld_states * c] (both >= G).  The per-cell
+ * kernels read one cache line per cell and request and write the states in 16-byte words: with columns that start on line /
+ * word boundaries (ld a multiple of 16) a gene count that is not a multiple of 16 runs as fast as one that is (+27 % otherwise,
+ * profiles/r05_sweep.json).  icnv_viterbi_cells (host buffers -- what R hands over) uploads into such a layout by itself. */
+int icnv_viterbi_cells_ld_dev(const double *expr, int64_t ld_expr, uint8_t *states, int64_t ld_states, int64_t G, int64_t C,
+                              const int32_t *chr_start, int32_t n_chr, int32_t K, const double *mean,
+                              double sd_shared, const double *logPi, const double *logDelta,
+                              int32_t *n_underflow_dev, void *stream);
 
 /* Certified fast path of the per-cell Viterbi (DESIGN.md "Certified fast Viterbi").  With a shared sd and the
  * transition structure of .get_HMM / .i3HMM_get_HMM (R/inferCNV_HMM.R:230-265, R/inferCNV_i3HMM.R:99-156: one

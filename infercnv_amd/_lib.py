@@ -81,6 +81,7 @@ PROTOTYPES = {
     "icnv_chain_round_partial_dev": (ct.c_int, [_vp, ct.c_int, _vp, ct.POINTER(_vp), ct.POINTER(_i64), _vp]),
     "icnv_chain_round_finish_dev": (ct.c_int, [_vp, ct.c_int, _vp]),
     "icnv_chain_apply_dev": (ct.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "icnv_chain_apply_ld_dev": (ct.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "icnv_chain_get_denoise": (ct.c_int, [_vp, _dp, _vp]),
     "icnv_chain_end": (None, [_vp]),
     "icnv_average_bounds": (ct.c_int, [_vp, _i64, _i64, _dp]),
@@ -94,6 +95,7 @@ PROTOTYPES = {
     "icnv_normalize_log2": (ct.c_int, [_vp, _vp, _i64, _i64, _dbl, _i32, _i32, _dp]),
     "icnv_viterbi_cells": (ct.c_int, [_vp, _vp, _i64, _i64, _ip, _i32, _i32, _dp, _dbl, _dp, _dp]),
     "icnv_viterbi_cells_dev": (ct.c_int, [_vp, _vp, _i64, _i64, _ip, _i32, _i32, _dp, _dbl, _dp, _dp, _vp, _vp]),
+    "icnv_viterbi_cells_ld_dev": (ct.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _ip, _i32, _i32, _dp, _dbl, _dp, _dp, _vp, _vp]),
     "icnv_viterbi_groups": (ct.c_int, [_vp, _vp, _i64, _i64, _ip, _i32, _ip, _ip, _i32, _i32, _dp, _dp, _dp, _dp]),
     "icnv_viterbi_groups_dev": (ct.c_int, [_vp, _vp, _i64, _i64, _ip, _i32, _ip, _ip, _i32, _i32, _dp, _dp, _dp, _dp,
                                            _vp, _vp]),

@@ -524,6 +524,7 @@ static ChainArgs chain_args(icnv_chain *ch, const double *in) {
     a.inv_coded = ch->inv_coded ? 1 : 0;
     a.partial = ch->d_partial.as<double>();
     a.cell_stats = ch->d_cellstats.as<double>();
+    a.pre_ld = (int32_t)ch->cfg.G;
     return a;
 }
 
@@ -558,6 +559,7 @@ static int large_smooth_center(icnv_chain *ch, uint32_t m, const double *in, con
             c.out = out + v->g0;
             c.G = v->G;
             c.ld = (int32_t)ch->cfg.G;
+            c.pre_ld = (int32_t)ch->cfg.G;
             c.cells = in_rows ? in_rows : out_rows;       // (rows read by list entry and written by position, or the other way round)
             c.in_by_pos = in_rows ? 0 : 1;
             c.out_by_pos = out_rows ? 0 : 1;
@@ -759,8 +761,15 @@ int icnv_chain_round_finish_dev(icnv_chain_t *ch, int round, void *stream) {
 
 // the apply pass with the stage mask `amask` (the chain's own, or -- noise_logistic -- the chain's without step 22)
 static int chain_apply_masked(icnv_chain_t *ch, uint32_t amask, const double *expr_in, double *expr_out, double *pre_denoise,
-                              hipStream_t s) {
+                              hipStream_t s, int64_t ld_pre = 0) {
     int rc;
+    if (ld_pre > 0 && ld_pre != ch->cfg.G) {
+        // a padded HMM input (icnv_chain_apply_ld_dev): written by the fused pass itself; the side paths that copy or patch whole
+        // matrices (three- / two-pass chain, NA pass, a chain without step 22) keep the contiguous layout
+        if (ld_pre < ch->cfg.G || ld_pre > 0x7fffffff) ICNV_FAIL(ICNV_ERR_ARG, "ld_pre below the number of genes");
+        if (ch->large || ch->na_aware || !pre_denoise || !(amask & ICNV_ST_DENOISE))
+            ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "a padded HMM input needs the fused chain with step 22 (no NA pass, no three-pass chain)");
+    }
     if (ch->large) {
         ch->cache_in = nullptr;   // (the rounds' staged rows are not used by the apply)
         const uint32_t keep = ch->mask;
@@ -775,6 +784,7 @@ static int chain_apply_masked(icnv_chain_t *ch, uint32_t amask, const double *ex
     a.mask = amask;
     a.out = expr_out;
     a.pre_out = pre_denoise;
+    if (ld_pre > 0) a.pre_ld = (int32_t)ld_pre;
     a.cells = nullptr;
     a.n_cells = (int32_t)ch->cfg.C;
     // The reference cells continue from the cache the rounds left (same matrix, stages a prefix of this chain's);
@@ -854,10 +864,19 @@ static int chain_apply_masked(icnv_chain_t *ch, uint32_t amask, const double *ex
 
 int icnv_chain_apply_dev(icnv_chain_t *ch, const double *expr_in, double *expr_out, double *pre_denoise,
                          void *stream) {
+    return icnv_chain_apply_ld_dev(ch, expr_in, expr_out, pre_denoise, 0, stream);
+}
+
+int icnv_chain_apply_ld_dev(icnv_chain_t *ch, const double *expr_in, double *expr_out, double *pre_denoise, int64_t ld_pre,
+                            void *stream) {
     if (!ch || !expr_in || !expr_out) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
     hipStream_t s = (hipStream_t)stream;
     int rc = chain_upload(ch, s);
     if (rc) return rc;
+    if (ld_pre > 0 && ld_pre != ch->cfg.G) {
+        if ((ch->mask & ICNV_ST_DENOISE) && ch->cfg.noise_logistic) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "a padded HMM input is not available with noise_logistic");
+        return chain_apply_masked(ch, ch->mask, expr_in, expr_out, pre_denoise, s, ld_pre);
+    }
     if ((ch->mask & ICNV_ST_DENOISE) && ch->cfg.noise_logistic) {
         // noise_logistic = TRUE (R/inferCNV_ops.R:2249-2252, 2326-2330): the rounds have produced the centre and half width
         // of step 22 as for the select; the matrix before step 22 comes out of the pass, the logistic adjustment
@@ -1363,7 +1382,9 @@ static int fast_table_for(ViterbiCtx &c, const HmmParams &p, double sd, hipStrea
 // scratch stays below ~4 GiB.
 static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t ncols, const int32_t *chr_start,
                            int32_t n_chr, const HmmParams &p, const double *sd_per_col_dev, double sd_shared,
-                           int32_t *n_underflow_dev, hipStream_t s) {
+                           int32_t *n_underflow_dev, hipStream_t s, int64_t ld_x = 0, int64_t ld_st = 0) {
+    if (ld_x <= 0) ld_x = G;      // elements between the columns of x / of states (contiguous columns by default)
+    if (ld_st <= 0) ld_st = G;
     DevBuf d_bp, d_list, d_redo;
     int rc;
     std::vector<int32_t> order;
@@ -1410,7 +1431,7 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
         if ((rc = fast_table_for(vc, p, sd_shared, s, fast))) return rc;
     }
     // observations through LDS (the staged kernel, its short table first, the full table for a batch that leaves it)?
-    const bool staged = fast && vc.staged && g_viterbi_mode.load() == 0 && G * 64 < ((int64_t)1 << 32);
+    const bool staged = fast && vc.staged && g_viterbi_mode.load() == 0 && ld_x * 64 < ((int64_t)1 << 32);
     vc.stats[0] = fast ? 1 : 0;
     vc.stats[1] = ncols * n_chr;
     vc.stats[2] = fast ? -1 : 0;
@@ -1432,7 +1453,7 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
         if ((rc = d_scr.alloc(viterbi_redo_scratch_bytes(max_len)))) return rc;
         return launch_viterbi_redo(x, states, (int32_t)G, dev_chr, p, sd_per_col_dev, sd_shared,
                                    d_all.as<int32_t>() + 2 * (size_t)count, d_all.as<int32_t>(), 0x7fffffff, d_scr.as<uint32_t>(),
-                                   n_underflow_dev, max_len, "viterbi", s);
+                                   n_underflow_dev, max_len, "viterbi", s, ld_x, ld_st);
     }
     // the scratch holds the exact kernel's 4-byte back-pointer words; the fast kernel's 2-byte words and its 16-gene block
     // summaries (viterbi_fast_scratch_bytes: G + G / 16 + 3 n_chr + 1 rows of 2 bytes per column) use its first half -- the
@@ -1462,16 +1483,18 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
     for (int64_t c0 = 0; c0 < ncols; c0 += batch) {
         const int64_t nc = std::min(batch, ncols - c0);
         if (!fast) {
-            rc = launch_viterbi(x + c0 * G, states + c0 * G, (int32_t)G, nc, dev_chr, dev_ord, n_chr,
+            rc = launch_viterbi(x + c0 * ld_x, states + c0 * ld_st, (int32_t)G, nc, dev_chr, dev_ord, n_chr,
                                 0, p, sd_per_col_dev ? sd_per_col_dev + c0 : nullptr, sd_shared, d_bp.as<uint32_t>(),
-                                n_underflow_dev, nullptr, 0, s);
+                                n_underflow_dev, nullptr, 0, s, ld_x, ld_st);
             if (rc) return rc;
             continue;
         }
         FastViterbiArgs fa;
         std::memset(&fa, 0, sizeof(fa));
-        fa.x = x + c0 * G;
-        fa.states = states + c0 * G;
+        fa.x = x + c0 * ld_x;
+        fa.states = states + c0 * ld_st;
+        fa.ld_x = ld_x;
+        fa.ld_st = ld_st;
         fa.G = (int32_t)G;
         fa.ncols = nc;
         fa.chr_start = dev_chr;
@@ -1526,10 +1549,10 @@ static int viterbi_columns(const double *x, uint8_t *states, int64_t G, int64_t 
             if ((rc = launch_viterbi_fast(fa, p.K, false, s))) return rc;
         }
         if ((rc = launch_viterbi_redo(fa.x, fa.states, (int32_t)G, dev_chr, p, nullptr, sd_shared, fa.flag_count,
-                                      fa.flag_list, limit, d_redo.as<uint32_t>(), n_underflow_dev, max_len, "viterbi_redo", s)))
+                                      fa.flag_list, limit, d_redo.as<uint32_t>(), n_underflow_dev, max_len, "viterbi_redo", s, ld_x, ld_st)))
             return rc;
         if ((rc = launch_viterbi(fa.x, fa.states, (int32_t)G, nc, dev_chr, dev_ord, n_chr, 0, p, nullptr,
-                                 sd_shared, d_bp.as<uint32_t>(), n_underflow_dev, fa.flag_count, limit, s)))
+                                 sd_shared, d_bp.as<uint32_t>(), n_underflow_dev, fa.flag_count, limit, s, ld_x, ld_st)))
             return rc;
         // one copy for both counts: [2] the staged attempt's (0 when there was none), [3] the one acted on
         ICNV_HIP(hipMemcpyAsync(vc.host_flag, vc.counters + 2, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -1605,17 +1628,25 @@ int icnv_hmm_emission_scores(int32_t K, const double *mean, double sd, const dou
     return ICNV_OK;
 }
 
-int icnv_viterbi_cells_dev(const double *expr, uint8_t *states, int64_t G, int64_t C, const int32_t *chr_start,
-                           int32_t n_chr, int32_t K, const double *mean, double sd_shared, const double *logPi,
-                           const double *logDelta, int32_t *n_underflow_dev, void *stream) {
+int icnv_viterbi_cells_ld_dev(const double *expr, int64_t ld_expr, uint8_t *states, int64_t ld_states, int64_t G, int64_t C,
+                              const int32_t *chr_start, int32_t n_chr, int32_t K, const double *mean, double sd_shared,
+                              const double *logPi, const double *logDelta, int32_t *n_underflow_dev, void *stream) {
     if (!expr || !states || G < 1 || C < 0 || G > 0x7fffffff) ICNV_FAIL(ICNV_ERR_ARG, "bad argument");
+    if (ld_expr < G || ld_states < G) ICNV_FAIL(ICNV_ERR_ARG, "leading dimension below the number of genes");
     int rc = validate_chr(chr_start, n_chr, G);
     if (rc) return rc;
     if (!(sd_shared > 0.0)) ICNV_FAIL(ICNV_ERR_ARG, "sd_shared must be positive");
     HmmParams p;
     if ((rc = fill_hmm(p, K, mean, logPi, logDelta))) return rc;
     return viterbi_columns(expr, states, G, C, chr_start, n_chr, p, nullptr, sd_shared, n_underflow_dev,
-                           (hipStream_t)stream);
+                           (hipStream_t)stream, ld_expr, ld_states);
+}
+
+int icnv_viterbi_cells_dev(const double *expr, uint8_t *states, int64_t G, int64_t C, const int32_t *chr_start,
+                           int32_t n_chr, int32_t K, const double *mean, double sd_shared, const double *logPi,
+                           const double *logDelta, int32_t *n_underflow_dev, void *stream) {
+    return icnv_viterbi_cells_ld_dev(expr, G, states, G, G, C, chr_start, n_chr, K, mean, sd_shared, logPi, logDelta, n_underflow_dev,
+                                     stream);
 }
 
 int icnv_group_means_dev(const double *expr, int64_t G, int64_t C, const int32_t *grp_idx, const int32_t *grp_off,

@@ -192,14 +192,17 @@ __global__ void reduce_cell_stats_kernel(const double *cs, int n_cells, int G, d
 
 // Round C of the reference rounds when the reference cells continue from their cache (steps 8-11 done): steps 12 and 14
 // are elementwise, so the per-cell (sum, sd) of R/inferCNV_ops.R:2302-2318 come from one streaming pass over the cache
-// instead of a launch of the chain geometry (LDS-resident cell, one 1 024-thread workgroup per CU, the pipeline's barriers):
-// 0.143 -> 0.121 ms for 5 000 cells.  A 512-thread workgroup per cell, two resident per CU (125 registers, no scratch): a
-// cell's values stay in registers between the two passes of R's sd(), the bound vectors come from L2 two slots at a time.
-// Getting here took three attempts (docs/KERNEL_LOG.md, round 4): 256 threads with everything of a cell in flight at once
-// needed 452 registers -- one wavefront per SIMD, 0.505 ms; 1 024 threads per cell, one workgroup per CU, exposed every
-// load latency -- 0.174 ms; the chain geometry it replaces is a software pipeline and was faster than both.  Arithmetic per
-// value as in the chain kernel (x - clamp(x, lo, hi); 2^x by the same degree-11 polynomial inside its range); sums in a fixed
-// order (thread-strided partials, wavefront butterflies, the wavefront sums in wavefront order).
+// instead of a launch of the chain geometry (LDS-resident cell, one 1 024-thread workgroup per CU, the pipeline's barriers).
+// Round 6: ONE pass per cell with shifted moments.  Rounds 4-5 kept a cell's 10 000 values in registers between the two
+// passes of R's sd() -- 512 threads x 125 registers, two cells in flight per CU, the bound vectors fetched in five dependent
+// groups: 0.121 ms for 400 MB (3.3 TB/s).  Here a 256-thread workgroup streams its cell once, four slots in flight per
+// thread and eight cells per CU, accumulating S1 = sum(y - c) and S2 = sum (y - c)^2 around the cell's own first value c:
+//   sum = S1 + G c,   (G - 1) var = S2 - S1^2 / G.
+// c lies within a few sd of the cell's mean, so S1^2 / G is at most a few times S2 (no cancellation to speak of): the sd agrees
+// with the two-pass value to ~1e-15 relative (tests/test_gpu_parity.py::test_denoise_round_streaming_kernel_equals_chain_geometry
+// holds 1e-12 against the chain geometry's two-pass kernel and against the oracle).  Arithmetic per value as in the chain kernel
+// (x - clamp(x, lo, hi); 2^x by the same degree-11 polynomial inside its range); sums in a fixed order (thread-strided partials,
+// wavefront butterflies, the wavefront sums in wavefront order).
 __device__ inline double exp2_lean_cs(double x) {   // chain_kernel.inc: exp2_lean
     const double n = __builtin_rint(x);
     const double f = x - n;
@@ -217,84 +220,56 @@ __device__ inline double exp2_lean_cs(double x) {   // chain_kernel.inc: exp2_le
     p = __builtin_fma(p, f, 1.0);
     return __builtin_ldexp(p, (int)n);
 }
-constexpr int CS_NT = 512, CS_NS = 10, CS_GRP = 2;   // 512 threads x 10 gene pairs = up to 10 240 (even) genes per cell
-__global__ void __launch_bounds__(CS_NT) __attribute__((amdgpu_waves_per_eu(4, 8))) cache_cell_stats_kernel(const double *__restrict__ cache, int G, int n_cells, uint32_t mask,
+constexpr int CS_NT = 256;
+__global__ void __launch_bounds__(CS_NT) cache_cell_stats_kernel(const double *__restrict__ cache, int G, int n_cells, uint32_t mask,
                                                                   const double *__restrict__ b2, double *__restrict__ cell_stats) {
-    __shared__ double red[CS_NT / 64];
+    __shared__ double red[2][CS_NT / 64];
+    typedef double dv2 __attribute__((ext_vector_type(2)));
     const int t = threadIdx.x;
-    auto block_sum = [&](double v) -> double {
-        v = wave_sum(v);
-        if ((t & 63) == 0) red[t >> 6] = v;
-        __syncthreads();
-        double r = red[0];
-#pragma unroll
-        for (int w = 1; w < CS_NT / 64; ++w) r += red[w];
-        __syncthreads();
-        return r;
-    };
     const bool sub = (mask & ICNV_ST_SUBTRACT_REF_2) != 0, inv = (mask & ICNV_ST_INVERT_LOG2) != 0;
     const int np = G >> 1;
-    const double2 *lo2 = reinterpret_cast<const double2 *>(b2), *hi2 = reinterpret_cast<const double2 *>(b2 + G);
+    const dv2 *lo2 = reinterpret_cast<const dv2 *>(b2), *hi2 = reinterpret_cast<const dv2 *>(b2 + G);
+    auto value = [&](double x, double lo, double hi) -> double {
+        if (sub) x = x - fmin(fmax(x, lo), hi);   // .subtract_expr, R/inferCNV_ops.R:1764-1768 (lo <= hi)
+        if (inv) {   // R/inferCNV_ops.R:2818; the library function on a rare wave-uniform branch (|x| >= 1022, NaN, Inf)
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(__builtin_fabs(x) < 1022.0)) != 0, 0)) {
+                asm volatile("; exp2 outside the lean range" ::: "memory");
+                x = exp2(x);
+            } else {
+                x = exp2_lean_cs(x);
+            }
+        }
+        return x;
+    };
     for (int c = blockIdx.x; c < n_cells; c += gridDim.x) {
-        const double2 *col = reinterpret_cast<const double2 *>(cache + (int64_t)c * G);
-        double2 v[CS_NS];
-#pragma unroll
-        for (int k = 0; k < CS_NS; ++k) {
-            const int q = t + k * CS_NT;
-            v[k] = (q < np) ? col[q] : make_double2(0.0, 0.0);
+        const double *colp = cache + (int64_t)c * G;
+        const dv2 *col = reinterpret_cast<const dv2 *>(colp);
+        const double shift = value(colp[0], sub ? b2[0] : 0.0, sub ? b2[G] : 0.0);   // the cell's first value (every thread computes it)
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
+        for (int q = t; q < np; q += CS_NT) {
+            const dv2 x = __builtin_nontemporal_load(col + q);
+            dv2 lo = {0.0, 0.0}, hi = {0.0, 0.0};
+            if (sub) { lo = lo2[q]; hi = hi2[q]; }
+            const double d0 = value(x.x, lo.x, hi.x) - shift, d1 = value(x.y, lo.y, hi.y) - shift;
+            s1 += d0;
+            s1 += d1;
+            s2 = __builtin_fma(d0, d0, s2);
+            s2 = __builtin_fma(d1, d1, s2);
         }
-        double s = 0.0;
-#pragma unroll
-        for (int g0 = 0; g0 < CS_NS; g0 += CS_GRP) {   // the bound vectors (L2) a group of slots at a time: registers
-            double2 lo[CS_GRP], hi[CS_GRP];
-#pragma unroll
-            for (int k = 0; k < CS_GRP; ++k) {
-                const int q = t + (g0 + k) * CS_NT;
-                lo[k] = make_double2(0.0, 0.0);
-                hi[k] = lo[k];
-                if (sub && q < np) { lo[k] = lo2[q]; hi[k] = hi2[q]; }
-            }
-#pragma unroll
-            for (int k = 0; k < CS_GRP; ++k) {
-                const int q = t + (g0 + k) * CS_NT;
-                double x0 = v[g0 + k].x, x1 = v[g0 + k].y;
-                if (sub) {   // .subtract_expr, R/inferCNV_ops.R:1764-1768 (lo <= hi)
-                    x0 = x0 - fmin(fmax(x0, lo[k].x), hi[k].x);
-                    x1 = x1 - fmin(fmax(x1, lo[k].y), hi[k].y);
-                }
-                if (inv) {   // R/inferCNV_ops.R:2818
-                    const bool wide = !(__builtin_fabs(x0) < 1022.0) || !(__builtin_fabs(x1) < 1022.0);
-                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(wide) != 0, 0)) {
-                        asm volatile("; exp2 outside the lean range" ::: "memory");
-                        x0 = exp2(x0);
-                        x1 = exp2(x1);
-                    } else {
-                        x0 = exp2_lean_cs(x0);
-                        x1 = exp2_lean_cs(x1);
-                    }
-                }
-                if (q < np) { s += x0; s += x1; }
-                v[g0 + k] = make_double2(x0, x1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const double tot = block_sum(s);
-        const double mean = tot / (double)G;
-        double ss = 0.0;
-#pragma unroll
-        for (int k = 0; k < CS_NS; ++k) {
-            const int q = t + k * CS_NT;
-            if (q < np) {
-                const double d0 = v[k].x - mean, d1 = v[k].y - mean;
-                ss += d0 * d0;
-                ss += d1 * d1;
-            }
-        }
-        const double sst = block_sum(ss);
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if ((t & 63) == 0) { red[0][t >> 6] = s1; red[1][t >> 6] = s2; }
+        __syncthreads();
         if (t == 0) {
-            cell_stats[2 * (int64_t)c] = tot;
-            cell_stats[2 * (int64_t)c + 1] = sqrt(sst / (double)(G - 1));   // sample sd, two passes like R's sd()
+            double a1 = red[0][0], a2 = red[1][0];
+#pragma unroll
+            for (int w = 1; w < CS_NT / 64; ++w) { a1 += red[0][w]; a2 += red[1][w]; }
+            const double n = (double)G;
+            cell_stats[2 * (int64_t)c] = __builtin_fma(n, shift, a1);
+            cell_stats[2 * (int64_t)c + 1] = sqrt(fmax(a2 - a1 * a1 / n, 0.0) / (n - 1.0));   // sample sd (R's sd()), from the shifted moments
         }
+        __syncthreads();
     }
 }
 
@@ -554,12 +529,12 @@ int launch_reduce_cell_stats(const double *cell_stats, int32_t n_cells, int32_t 
     return ICNV_OK;
 }
 
-bool cache_cell_stats_covers(int32_t G) { return (G & 1) == 0 && G <= CS_NT * CS_NS * 2; }
+bool cache_cell_stats_covers(int32_t G) { return (G & 1) == 0 && G >= 2; }
 int launch_cache_cell_stats(const double *cache, int32_t G, int32_t n_cells, uint32_t mask, const double *b2, double *cell_stats,
                             hipStream_t stream) {
     if (n_cells <= 0) return ICNV_OK;
     KernelTimer kt("chain_cell_stats", stream);
-    hipLaunchKernelGGL(cache_cell_stats_kernel, dim3((unsigned)std::min(n_cells, num_cus() * 16)), dim3(CS_NT), 0, stream, cache, (int)G,
+    hipLaunchKernelGGL(cache_cell_stats_kernel, dim3((unsigned)std::min(n_cells, num_cus() * 32)), dim3(CS_NT), 0, stream, cache, (int)G,
                        (int)n_cells, mask, b2, cell_stats);
     ICNV_HIP(hipGetLastError());
     return ICNV_OK;

@@ -114,6 +114,7 @@ struct ChainArgs {
     int32_t in_by_pos;      // 1: `in` holds one column per list position (a cache written through cache_out)
     double *cell_stats;     // MODE_CELL_STATS: [n_cells * 2] {sum, sd}
     int32_t out_by_pos;     // 1: `out` receives one column per list position (the reference-cell cache written by round B)
+    int32_t pre_ld;         // doubles between the columns of pre_out (G unless the caller asked for padded columns)
     int32_t ld;             // 0, or (strided view, launch_chain_strided): doubles between the columns of in / out / pre_out, and between b1 / b2's lower and upper vectors
 };
 
@@ -171,7 +172,7 @@ int launch_group_gene_sums(const double *x, int32_t G, const int32_t *cells_dev,
 // (nan_flag, nullable: set to 1 when a stored bound is NaN -- NA-aware chains in the no-bounds mode look at it)
 int launch_bounds_from_sums(const double *sums_counts, int32_t G, int32_t n_grp, int32_t use_bounds, int32_t inv_log,
                             double *bounds, int32_t *nan_flag, hipStream_t stream);
-bool cache_cell_stats_covers(int32_t G);   // even G <= 10 240: the cell fits the streaming kernel's registers
+bool cache_cell_stats_covers(int32_t G);   // even G: the streaming kernel reads gene pairs
 int launch_cache_cell_stats(const double *cache, int32_t G, int32_t n_cells, uint32_t mask /* steps 12 / 14 still to run */, const double *b2,
                             double *cell_stats, hipStream_t stream);
 int launch_reduce_cell_stats(const double *cell_stats, int32_t n_cells, int32_t G, double *out4,
@@ -206,7 +207,8 @@ struct HmmParams {
 int launch_viterbi(const double *x, uint8_t *states, int32_t G, int64_t n_seq_cols, const int32_t *chr_start_dev,
                    const int32_t *chr_order_dev, int32_t n_chr, int32_t max_chr_len, const HmmParams &p,
                    const double *sd_per_col_dev, double sd_shared, uint32_t *bp_scratch, int32_t *n_underflow,
-                   const int32_t *gate_dev, int32_t gate_limit, hipStream_t stream);   // gate_dev: run only if *gate_dev > gate_limit
+                   const int32_t *gate_dev, int32_t gate_limit, hipStream_t stream,   // gate_dev: run only if *gate_dev > gate_limit
+                   int64_t ld_x = 0, int64_t ld_st = 0);   // elements between the columns of x / states (0: G, contiguous columns)
 size_t viterbi_scratch_bytes(int32_t G, int64_t n_cols);
 
 // certified fast path (viterbi_fast.hip): table-driven scores + decision-margin test, flagged sequences redone exactly
@@ -234,6 +236,11 @@ struct FastViterbiArgs {
     int32_t *flag_list;         // [2 * n_chr * ncols] (chromosome, column) pairs
     const int32_t *gate_count;  // null, or: the flag count of a first attempt on this batch -- the kernel runs only if it
     int32_t gate_limit;         // exceeds gate_limit, and hands it on as its own count otherwise
+    // Round 6: the columns of x / states may lie further apart than G elements (icnv_viterbi_cells_ld_dev): with a leading dimension
+    // that is a multiple of 16 every column starts on a cache line and every state column on a 16-byte word, whatever G is -- the
+    // staged kernel's chunks are whole lines again and the traceback's blocks aligned stores (a gene count that is not a multiple of
+    // 16 cost +27 % before).  The host-buffer entry points upload into such a layout by themselves.
+    int64_t ld_x, ld_st;
 };
 size_t viterbi_fast_scratch_bytes(int32_t G, int32_t n_chr, int64_t n_cols);
 size_t viterbi_fast_lds_bytes(int K, int n_int, int n_grid, bool staged);
@@ -246,7 +253,7 @@ int launch_viterbi_redo(const double *x, uint8_t *states, int32_t G, const int32
                         const double *sd_per_col_dev, double sd_shared, const int32_t *flag_count_dev,
                         const int32_t *flag_list_dev, int32_t max_count /* lists longer than this are left alone */,
                         uint32_t *bp_redo, int32_t *n_underflow, int32_t max_chr_len, const char *timer_name,
-                        hipStream_t stream);
+                        hipStream_t stream, int64_t ld_x = 0, int64_t ld_st = 0);
 int group_means_nsplit(int32_t G, int32_t n_grp);
 int launch_group_means_ws(const double *x, int32_t G, const int32_t *grp_idx_dev, const int32_t *grp_off_dev,
                           int32_t n_grp, int nsplit, double *part, double *out, hipStream_t stream);

@@ -217,8 +217,8 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
         if (!STAGE && col >= A.ncols) continue;
         const int s0 = A.chr_start[chr];
         const int n = A.chr_start[chr + 1] - s0;
-        const double *xc = A.x + col * (int64_t)A.G + s0;
-        uint8_t *st = A.states + col * (int64_t)A.G + s0;
+        const double *xc = A.x + col * A.ld_x + s0;
+        uint8_t *st = A.states + col * A.ld_st + s0;
         if (n < 2) {  // R/inferCNV_HMM.R:1104-1107
             if (n == 1) st[0] = 3;
             continue;
@@ -444,10 +444,10 @@ __global__ void __launch_bounds__(FAST_NT) viterbi_fast_kernel(const FastViterbi
                 const char *rb = reinterpret_cast<const char *>(wbuf) + rq * 1024u + rr * 128u;
                 // what this lane fetches in request q: 16 bytes (pair fp ^ f) of the column 8 q + (lane >> 3)
                 const uint32_t fr = (uint32_t)lane >> 3, fp = (uint32_t)lane & 7u;
-                const uint32_t voff_e = (fr * (uint32_t)A.G + 2u * (fp ^ (fr >> 1))) * 8u;
-                const uint32_t voff_o = (fr * (uint32_t)A.G + 2u * (fp ^ ((fr >> 1) | 4u))) * 8u;
-                const double *xt = A.x + col0 * (int64_t)A.G + s0;   // (wave-uniform) gene 0 of the task's first column
-                const int64_t qstride = 8 * (int64_t)A.G;
+                const uint32_t voff_e = (fr * (uint32_t)A.ld_x + 2u * (fp ^ (fr >> 1))) * 8u;
+                const uint32_t voff_o = (fr * (uint32_t)A.ld_x + 2u * (fp ^ ((fr >> 1) | 4u))) * 8u;
+                const double *xt = A.x + col0 * A.ld_x + s0;   // (wave-uniform) gene 0 of the task's first column
+                const int64_t qstride = 8 * A.ld_x;
                 auto request = [&](int gi) {
                     const double *tb = xt + gi;
 #pragma unroll
@@ -601,7 +601,8 @@ int launch_viterbi_fast(const FastViterbiArgs &a, int K, bool staged, hipStream_
     const size_t lds = (viterbi_fast_lds_bytes(K, a.n_int, a.n_grid, staged) + 15) & ~(size_t)15;
     if (lds > 160 * 1024) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "emission table does not fit the LDS");
     if (staged && a.ncols < 64) ICNV_FAIL(ICNV_ERR_ARG, "the staged fast Viterbi needs at least 64 columns");
-    if (staged && (int64_t)a.G * 8 * 8 >= ((int64_t)1 << 32)) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "too many genes for the staged fast Viterbi");
+    if (a.ld_x < a.G || a.ld_st < a.G) ICNV_FAIL(ICNV_ERR_ARG, "fast Viterbi: leading dimension below the gene count");
+    if (staged && a.ld_x * 8 * 8 >= ((int64_t)1 << 32)) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "too many genes for the staged fast Viterbi");
     const int64_t ncg = (a.ncols + 63) / 64;
     const int64_t tasks = ncg * a.n_chr;
     if (tasks > 0x7fffff00) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "too many Viterbi tasks for one launch");

@@ -35,6 +35,24 @@ def _check_matrix(x, dtype=torch.float64):
     return x.shape[0], x.shape[1]
 
 
+def _check_matrix_ld(x, dtype=torch.float64):
+    """(C, G, ld) of a CUDA matrix whose rows -- the cells -- are contiguous and lie `ld` elements apart: a contiguous
+    (cells, genes) tensor (ld = G) or the [:, :G] view of a wider one (padded_matrix)."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == dtype and x.dim() == 2 and (x.shape[1] <= 1 or x.stride(1) == 1)
+            and (x.shape[0] <= 1 or x.stride(0) >= x.shape[1])):
+        raise TypeError(f"expected a CUDA {dtype} tensor of shape (cells, genes) with contiguous rows")
+    return x.shape[0], x.shape[1], (x.stride(0) if x.shape[0] > 1 else x.shape[1])
+
+
+def padded_matrix(C, G, dtype=torch.float64, device="cuda", multiple=16):
+    """A (C, G) matrix whose rows start `ld = G rounded up to a multiple of 16` elements apart -- every cell on a cache line
+    (float64) / a 16-byte word (uint8) of its own, whatever G is.  The per-cell Viterbi reads and writes such matrices at the
+    speed of a gene count that is a multiple of 16 (icnv_viterbi_cells_ld_dev); ChainPlan.apply / smooth_chain write their
+    HMM input into one when it is passed as `pre` (icnv_chain_apply_ld_dev).  The padding columns are never read or written."""
+    ld = (int(G) + multiple - 1) // multiple * multiple
+    return torch.empty((int(C), ld), dtype=dtype, device=device)[:, :int(G)]
+
+
 def init(device=None):
     """Bind the calling thread to `device` (defaults to torch's current device)."""
     L = _lib.load()
@@ -98,11 +116,17 @@ class ChainPlan:
         check(self.L.icnv_chain_round_finish_dev(self.h, r, _stream()))
 
     def apply(self, x, out=None, want_pre_denoise=False, pre=None):
-        """`pre`: a preallocated tensor for the matrix before step 22 (implies want_pre_denoise)."""
+        """`pre`: a preallocated tensor for the matrix before step 22 (implies want_pre_denoise); a padded_matrix() is
+        written with its leading dimension (icnv_chain_apply_ld_dev)."""
         if out is None:
             out = torch.empty_like(x)
         if pre is None and want_pre_denoise:
             pre = torch.empty_like(x)
+        if pre is not None and not pre.is_contiguous():
+            _, G, ld = _check_matrix_ld(pre)
+            assert G == self.G and pre.shape[0] == self.C
+            check(self.L.icnv_chain_apply_ld_dev(self.h, _ptr(x), _ptr(out), _ptr(pre), int(ld), _stream()))
+            return out, pre
         check(self.L.icnv_chain_apply_dev(self.h, _ptr(x), _ptr(out), _ptr(pre), _stream()))
         return out, pre
 
@@ -191,16 +215,23 @@ def viterbi_cells(x, chr_start, means, sd_shared, logPi, logDelta, states=None):
     """predict_CNV_via_HMM_on_indiv_cells (R/inferCNV_HMM.R:284-324) / i3 variant
     (R/inferCNV_i3HMM.R:180-225).  Returns (states uint8 (C, G), n_underflow int32[1] tensor)."""
     L = _lib.load()
-    C, G = _check_matrix(x)
+    C, G, ld_x = _check_matrix_ld(x)
     cs, cp = i32(chr_start)
     m, mp = f64(means)
     lp = np.asfortranarray(logPi, dtype=np.float64)
     ld, ldp = f64(logDelta)
     if states is None:
-        states = torch.empty((C, G), dtype=torch.uint8, device=x.device)
+        # (a padded input gets padded states: the traceback then writes aligned 16-byte words for every cell)
+        states = torch.empty((C, G), dtype=torch.uint8, device=x.device) if ld_x == G else padded_matrix(C, G, torch.uint8, x.device)
+    _, Gs, ld_st = _check_matrix_ld(states, torch.uint8)
+    assert Gs == G and states.shape[0] == C
     bad = torch.zeros(1, dtype=torch.int32, device=x.device)
-    check(L.icnv_viterbi_cells_dev(_ptr(x), _ptr(states), G, C, cp, cs.size - 1, m.size, mp, float(sd_shared),
-                                   lp.ctypes.data_as(ct.POINTER(ct.c_double)), ldp, _ptr(bad), _stream()))
+    if ld_x == G and ld_st == G:
+        check(L.icnv_viterbi_cells_dev(_ptr(x), _ptr(states), G, C, cp, cs.size - 1, m.size, mp, float(sd_shared),
+                                       lp.ctypes.data_as(ct.POINTER(ct.c_double)), ldp, _ptr(bad), _stream()))
+    else:
+        check(L.icnv_viterbi_cells_ld_dev(_ptr(x), int(ld_x), _ptr(states), int(ld_st), G, C, cp, cs.size - 1, m.size, mp,
+                                          float(sd_shared), lp.ctypes.data_as(ct.POINTER(ct.c_double)), ldp, _ptr(bad), _stream()))
     return states, bad
 
 

@@ -61,6 +61,21 @@ for G in [int(a) for a in (sys.argv[1].split(",") if len(sys.argv) > 1 else "600
                          "viterbi_ms": t_vit * 1e3, "viterbi_cells_per_s": C / t_vit, "viterbi_GBps_algorithmic_9B": 9.0 * G * C / t_vit / 1e9,
                          "viterbi_path": st["path"], "viterbi_flagged": st["flagged"],
                          "step_gene_cells_per_s": G * C / (t_chain + t_vit)})
+    if G % 16:
+        # the same step with the HMM input and the states in a padded layout (leading dimension = G rounded up to 16: every cell on
+        # a cache line / a 16-byte word of its own; icnv_chain_apply_ld_dev + icnv_viterbi_cells_ld_dev)
+        pre_p = device.padded_matrix(C, G)
+        st_p = device.padded_matrix(C, G, torch.uint8)
+        def chain_step_p():
+            for r in range(plan.num_rounds):
+                plan.round_partial(r, x); plan.round_finish(r)
+            plan.apply(x, out=out, pre=pre_p)
+        t_chain_p = timed(chain_step_p)
+        t_vit_p = timed(lambda: device.viterbi_cells(pre_p, cs, means, sd, logPi, logDelta, states=st_p))
+        assert torch.equal(st_p, states) and torch.equal(pre_p, pre)
+        res["genes"][-1].update({"padded_ld": int(pre_p.stride(0)), "chain_ms_padded_hmm_input": t_chain_p * 1e3, "viterbi_ms_padded": t_vit_p * 1e3,
+                                 "step_gene_cells_per_s_padded": G * C / (t_chain_p + t_vit_p)})
+        del pre_p, st_p
     plan.close()
     del x, out, pre, states, plan
 

@@ -1571,3 +1571,56 @@ def test_viterbi_unaligned_matrix_views_bit_exact(dev, G):
         st, bad = dev.viterbi_cells(xv, cs, means, sd, logPi, logDelta, states=sv)
         np.testing.assert_array_equal(to_host(st), want)
         assert int(bufs[:off_s].sum()) == 0 and int(bufs[off_s + C * G:].sum()) == 0     # nothing written outside the view
+
+
+@pytest.mark.parametrize("G,C", [(9939, 700), (1003, 130), (4613, 64), (10000, 200)])
+def test_padded_leading_dimension_chain_and_viterbi(dev, G, C):
+    """Round 6: matrices with a leading dimension (device.padded_matrix: every cell's column starts on a cache line / a 16-byte word
+    of its own).  The fused chain writes its HMM input into one (icnv_chain_apply_ld_dev) -- bit for bit the contiguous one --, the
+    per-cell Viterbi reads it and writes padded states (icnv_viterbi_cells_ld_dev): the very states of the contiguous call and of
+    the oracle, for gene counts that are not multiples of 16 (9 939 = example/run.R's, 4 613 = the golden object's) and one that
+    is; the certified fast path serves both layouts; the padding columns are never touched."""
+    from infercnv_amd import synth
+    x, cs = synth.make_matrix_np(G, C)
+    refs, _ = synth.groups(C)
+    xd = to_dev(x)
+    out_c, pre_c = dev.smooth_chain(xd, cs, refs, want_pre_denoise=True)
+    plan = dev.ChainPlan(G, C, cs, refs)
+    for r in range(plan.num_rounds):
+        plan.round_partial(r, xd); plan.round_finish(r)
+    pre_p = dev.padded_matrix(C, G)
+    ld = pre_p.stride(0)
+    assert ld % 16 == 0 and ld >= G and (ld > G) == (G % 16 != 0)
+    base = pre_p.as_strided((C, ld), (ld, 1)) if ld > G else None       # the whole allocation, padding included
+    if base is not None:
+        base.fill_(-777.0)
+    out_p, pre_p2 = plan.apply(xd, pre=pre_p)
+    torch.cuda.synchronize()
+    assert pre_p2.data_ptr() == pre_p.data_ptr()
+    assert torch.equal(pre_p, pre_c) and torch.equal(out_p, out_c)
+    if base is not None:
+        assert bool((base[:, G:] == -777.0).all())                       # the padding columns are not written
+    means, sd, logPi, logDelta = synth.hmm_params_i6()
+    st_c, bad_c = dev.viterbi_cells(pre_c, cs, means, sd, logPi, logDelta)
+    path_c = dev.viterbi_last_stats()
+    st_p, bad_p = dev.viterbi_cells(pre_p, cs, means, sd, logPi, logDelta)
+    path_p = dev.viterbi_last_stats()
+    torch.cuda.synchronize()
+    assert int(bad_c.item()) == 0 and int(bad_p.item()) == 0
+    assert st_p.stride(0) == ld and st_p.shape == (C, G)
+    assert torch.equal(st_p, st_c)
+    assert path_c["path"] == path_p["path"] == "fast"
+    want, _ = oc.viterbi_cells(to_host(pre_c), cs, means, sd, logPi, logDelta)
+    np.testing.assert_array_equal(to_host(st_p.contiguous()), want)
+    # i3 on the padded layout, and an error for a leading dimension below G
+    mu, sigma, delta = onp.i3_params(to_host(pre_c), np.concatenate(refs), 0.05)
+    Pi3, d3 = onp.get_HMM_i3(1e-6)
+    m3 = np.array([mu - delta, mu, mu + delta])
+    s3p, _ = dev.viterbi_cells(pre_p, cs, m3, sigma, np.log(Pi3), np.log(d3))
+    s3c, _ = dev.viterbi_cells(pre_c, cs, m3, sigma, np.log(Pi3), np.log(d3))
+    assert torch.equal(s3p, s3c)
+    import ctypes as ct
+    from infercnv_amd import _lib
+    L = _lib.load()
+    assert L.icnv_viterbi_cells_ld_dev(ct.c_void_p(pre_c.data_ptr()), G - 1, ct.c_void_p(st_c.data_ptr()), G, G, C, None, 0, 6, None, 0.1, None, None,
+                                       None, None) == 1
