@@ -67,7 +67,10 @@ extern "C" {
                                          NA semantics (csrc/chain_na.hip: step 8 / 12 with bounds turn an NA into 0, the smoothing strips
                                          and re-inserts NAs per chromosome, the centre is taken over the values present,
                                          R/inferCNV_ops.R:1757-1768, 2098, 2487-2489, 2529); costs one extra pass over the input.  Without
-                                         it a NaN is not looked for (run()'s chain input, log2(x + 1) of counts, has none) */
+                                         it a NaN is not looked for (run()'s chain input, log2(x + 1) of counts, has none).  Any gene count
+                                         (fused, two-pass and three-pass chain); a call that runs in place keeps the flagged cells'
+                                         input columns aside first (fused chain; ICNV_ERR_UNSUPPORTED in place beyond the LDS-resident
+                                         limit); ICNV_ERR_UNSUPPORTED together with inv_log or noise_logistic (no silent default) */
 
 /* ---- library state ------------------------------------------------------ */
 int icnv_version(void);

@@ -395,9 +395,11 @@ int icnv_chain_begin(icnv_chain_t **out, const icnv_chain_cfg *cfg) {
             delete ch;
             ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "inv_log is not available for gene sets that need the three-pass chain");
         }
-        if (ch->na_aware && (ch->large || cfg->inv_log || cfg->noise_logistic)) {
+        if (ch->na_aware && (cfg->inv_log || cfg->noise_logistic)) {
+            // (explicit, not silent: the stand-alone subtract with inv_log = TRUE sums 2^x - 1 over the reference cells and
+            // noise_logistic rewrites every value -- neither has an NA pass here)
             delete ch;
-            ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "ICNV_ST_NA_AWARE is built for the fused chain (not the three-pass chain, inv_log or noise_logistic)");
+            ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "ICNV_ST_NA_AWARE is not available with inv_log or noise_logistic");
         }
         if (ch->large && chain_large_lds_bytes(ch->max_chr_len, ch->T) > 152 * 1024) {
             delete ch;
@@ -601,6 +603,17 @@ static int large_round_partial(icnv_chain *ch, uint32_t bit, uint32_t m, const d
     if (any_sm && nref > 0 && !staged) {
         ch->cache_in = nullptr;
         if ((rc = large_smooth_center(ch, m, expr_in, ch->d_ref.as<int32_t>(), tmp, nullptr, nref, s))) return rc;
+        if (ch->na_aware) {
+            // (round 6) reference cells that hold a NaN: their staged rows redone with the reference's NA semantics (chain_na.hip works
+            // on any gene count: one chromosome at a time through the LDS)
+            ChainArgs na = chain_args(ch, expr_in);
+            na.mask = m & sm_bits;
+            na.cells = ch->d_ref.as<int32_t>();
+            na.n_cells = nref;
+            na.out = tmp;
+            na.out_by_pos = 1;
+            if ((rc = launch_chain_na_fixup(na, ch->max_chr_len, ch->d_naflags.as<uint8_t>(), ch->d_nanbound.as<int32_t>(), s))) return rc;
+        }
         ch->cache_in = expr_in;
         ch->cache_mask = m & sm_bits;
     }
@@ -772,10 +785,21 @@ static int chain_apply_masked(icnv_chain_t *ch, uint32_t amask, const double *ex
     }
     if (ch->large) {
         ch->cache_in = nullptr;   // (the rounds' staged rows are not used by the apply)
+        if (ch->na_aware && (expr_in == expr_out || expr_in == pre_denoise))
+            ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "ICNV_ST_NA_AWARE with the two- / three-pass chain cannot run in place (the NA pass reads the input again)");
         const uint32_t keep = ch->mask;
         ch->mask = amask;
         rc = large_apply(ch, expr_in, expr_out, (amask & ICNV_ST_DENOISE) ? pre_denoise : nullptr, s);
         ch->mask = keep;
+        if (!rc && ch->na_aware) {   // the cells that hold a NaN again, stage by stage, the reference's way
+            ChainArgs na = chain_args(ch, expr_in);
+            na.mask = amask;
+            na.out = expr_out;
+            na.pre_out = (amask & ICNV_ST_DENOISE) ? pre_denoise : nullptr;
+            na.cells = nullptr;
+            na.n_cells = (int32_t)ch->cfg.C;
+            rc = launch_chain_na_fixup(na, ch->max_chr_len, ch->d_naflags.as<uint8_t>(), ch->d_nanbound.as<int32_t>(), s);
+        }
         if (!rc && pre_denoise && !(amask & ICNV_ST_DENOISE))
             ICNV_HIP(hipMemcpyAsync(pre_denoise, expr_out, (size_t)ch->cfg.G * ch->cfg.C * sizeof(double), hipMemcpyDeviceToDevice, s));
         return rc;

@@ -1385,14 +1385,22 @@ def test_chain_missing_values_policy_against_the_reference_semantics(dev):
 
 @pytest.mark.parametrize("case", ["full_chain", "no_bounds", "smooth_only", "centre_median", "centre_mean", "nan_in_reference_cell",
                                   "full_chain_in_place", "no_bounds_in_place", "no_bounds_nan_in_reference_cell",
-                                  "from_step_9_nan_in_reference_cell"])
-def test_chain_na_aware_reference_semantics(dev, case):
+                                  "from_step_9_nan_in_reference_cell",
+                                  "full_chain:two_pass", "nan_in_reference_cell:two_pass", "no_bounds:three_pass_taps"])
+def test_chain_na_aware_reference_semantics(dev, case, monkeypatch):
     """ICNV_ST_NA_AWARE (round 5): the cells that hold a NaN come out the way the reference's step functions treat an NA
     (oracle_np.run_chain_na: R/inferCNV_ops.R:1757-1768 which() never selects an NA -> 0 with bounds; :2974-2975 the clamp
     leaves it alone; :2487-2489, 2529 the smoothing strips and re-inserts NAs per chromosome; :2098 median(na.rm = TRUE);
     2^NA = NA; :2335 step 22 never selects it), every other cell as always.  NaNs at chromosome starts and ends, runs of them,
     a whole chromosome of one cell, a cell with a single value left on a chromosome, in observation and in reference cells."""
     from infercnv_amd import synth, _lib
+    if ":" in case:
+        # round 6: the NA pass behind the chain for gene sets beyond the LDS-resident limit (forced on this size): two-pass form
+        # (strided views + centre / finish) and the (2T + 1)-tap three-pass chain
+        case, form = case.split(":")
+        monkeypatch.setenv("ICNV_CHAIN_LARGE", "1")
+        if form == "three_pass_taps":
+            monkeypatch.setenv("ICNV_CHAIN_LARGE_TAPS", "1")
     G, C = 1500, 40
     x, cs = synth.make_matrix_np(G, C)
     x = x - 1.5
