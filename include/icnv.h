@@ -419,6 +419,30 @@ int icnv_cells_mean_sd(const double *expr, int64_t G, int64_t C, const int32_t *
 int icnv_cells_moments_partial_dev(const double *expr, int64_t G, int64_t C, const int32_t *cell_idx, int64_t n_cells,
                                    int32_t phase, double mean, double *out3_host, void *stream);
 
+/* The i3 HMM at group level as a PLAN with device-resident parameters (round 6).  i3HMM_predict_CNV_via_HMM_on_tumor_subclusters /
+ * _whole_tumor_samples (R/inferCNV_i3HMM.R:249-389) compute mean(ref) and sd(ref) of the reference cells' values
+ * (.i3HMM_get_sd_trend_by_num_cells_fit, :38-52), place the three state means at mu and mu +- delta (:435-445) and run the
+ * Viterbi on every group's mean profile.  The plan uploads the group structure ONCE; a step is
+ *   icnv_group_hmm_i3_partial_dev(): group means + the reference cells' shifted moments {sum (x - 1), sum (x - 1)^2, n} in ONE pass
+ *       over the matrix; *moments_dev points at the three doubles on the device -- all-reduce(sum) them in a cell-sharded run;
+ *   icnv_group_hmm_i3_finish_dev(): mu, sigma, delta from the moments ON THE DEVICE (delta = delta_abs when it is a number -- the
+ *       KS-based value of use_KS = TRUE, computed by the caller from sigma --, sigma * z_abs otherwise: |qnorm(p, 0, sigma)| =
+ *       sigma |qnorm(p)|), Viterbi per group with its parameters read from device memory, broadcast to the cells.
+ * No upload, download or stream synchronisation inside a step.  Every cell in at most one group, every reference cell in exactly
+ * one, at most 8192 (group, chromosome) sequences (ICNV_ERR_UNSUPPORTED otherwise: icnv_viterbi_groups_dev serves those).  The
+ * moments are shifted around 1, the level the chain's output is centred at: mu and sigma agree with the two-pass long-double values
+ * of icnv_cells_moments_partial_dev to ~1e-15 relative. */
+typedef struct icnv_group_hmm icnv_group_hmm_t;
+int icnv_group_hmm_begin(icnv_group_hmm_t **plan, int64_t G, int64_t C, const int32_t *chr_start, int32_t n_chr,
+                         const int32_t *grp_idx, const int32_t *grp_off, int32_t n_grp, const int32_t *ref_idx, int64_t n_ref);
+int icnv_group_hmm_i3_partial_dev(icnv_group_hmm_t *plan, const double *expr, double **moments_dev, void *stream);
+int icnv_group_hmm_i3_finish_dev(icnv_group_hmm_t *plan, uint8_t *states, const double *logPi /* 3 x 3, column-major */,
+                                 const double *logDelta /* [3] */, double z_abs, double delta_abs,
+                                 int32_t *n_underflow_dev, void *stream);
+/* {mu, sigma, delta} of the last finish (synchronises the stream). */
+int icnv_group_hmm_get_i3_params(icnv_group_hmm_t *plan, double *mu_sigma_delta, void *stream);
+void icnv_group_hmm_end(icnv_group_hmm_t *plan);
+
 /* Values of the matrix at element offsets g + G c (host list in, host values out): the draws of
  * sample(expr_vals, size = ncells, replace = TRUE) in get_hspike_cnv_mean_sd_trend_by_num_cells_fit
  * (R/inferCNV_HMM.R:164) taken from the resident hidden-spike matrix; the index stream itself is R's RNG, restated on the

@@ -95,6 +95,11 @@ PROTOTYPES = {
     "icnv_normalize_log2": (ct.c_int, [_vp, _vp, _i64, _i64, _dbl, _i32, _i32, _dp]),
     "icnv_viterbi_cells": (ct.c_int, [_vp, _vp, _i64, _i64, _ip, _i32, _i32, _dp, _dbl, _dp, _dp]),
     "icnv_viterbi_cells_dev": (ct.c_int, [_vp, _vp, _i64, _i64, _ip, _i32, _i32, _dp, _dbl, _dp, _dp, _vp, _vp]),
+    "icnv_group_hmm_begin": (ct.c_int, [_vp, _i64, _i64, _ip, _i32, _ip, _ip, _i32, _ip, _i64]),
+    "icnv_group_hmm_i3_partial_dev": (ct.c_int, [_vp, _vp, _vp, _vp]),
+    "icnv_group_hmm_i3_finish_dev": (ct.c_int, [_vp, _vp, _dp, _dp, _dbl, _dbl, _vp, _vp]),
+    "icnv_group_hmm_get_i3_params": (ct.c_int, [_vp, _dp, _vp]),
+    "icnv_group_hmm_end": (None, [_vp]),
     "icnv_viterbi_cells_ld_dev": (ct.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _ip, _i32, _i32, _dp, _dbl, _dp, _dp, _vp, _vp]),
     "icnv_viterbi_groups": (ct.c_int, [_vp, _vp, _i64, _i64, _ip, _i32, _ip, _ip, _i32, _i32, _dp, _dp, _dp, _dp]),
     "icnv_viterbi_groups_dev": (ct.c_int, [_vp, _vp, _i64, _i64, _ip, _i32, _ip, _ip, _i32, _i32, _dp, _dp, _dp, _dp,

@@ -1769,6 +1769,128 @@ int icnv_viterbi_groups_dev(const double *expr, uint8_t *states, int64_t G, int6
     return launch_broadcast_states(d_gs.as<uint8_t>(), (int32_t)G, C, d_map.as<int32_t>(), states, s);
 }
 
+// ------------------------------------------------------------------ i3 HMM at group level, device-resident parameters (round 6)
+// predict via i3HMM_predict_CNV_via_HMM_on_tumor_subclusters / _whole_tumor_samples (R/inferCNV_i3HMM.R:249-389) as a PLAN: the
+// group structure goes to the device once; a step is  group means + the reference cells' moments (ONE pass over the matrix)
+// -> [all-reduce of 3 doubles in a cell-sharded run] -> mu, sigma, delta on the device -> Viterbi per group with its parameters
+// read from device memory -> broadcast.  No upload, no download and no stream synchronisation inside a step (round 5's step
+// spent 0.29 of its 1.43 ms on them: two host round trips for the moments, five uploads of the group structure).
+struct icnv_group_hmm {
+    int64_t G = 0, C = 0;
+    int32_t n_chr = 0, n_grp = 0, max_len = 0, ns = 1;
+    int64_t n_ref = 0;
+    std::vector<int32_t> chr_start;
+    DevBuf d_chr, d_idx, d_off, d_map, d_ref, d_list, d_gm, d_gs, d_part, d_mom, d_m3, d_params, d_scr, d_bad;
+    int32_t count = 0;
+};
+
+int icnv_group_hmm_begin(icnv_group_hmm_t **out, int64_t G, int64_t C, const int32_t *chr_start, int32_t n_chr,
+                         const int32_t *grp_idx, const int32_t *grp_off, int32_t n_grp, const int32_t *ref_idx, int64_t n_ref) {
+    if (!out) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (G < 1 || C < 0 || G > 0x7fffffff || C > 0x7fffffff || n_grp < 0 || n_ref < 0) ICNV_FAIL(ICNV_ERR_ARG, "bad dimensions");
+    int rc = validate_chr(chr_start, n_chr, G);
+    if (rc) return rc;
+    if ((rc = validate_groups(grp_idx, grp_off, n_grp, C, "groups"))) return rc;
+    if (n_ref > 0 && (rc = validate_index_list(ref_idx, n_ref, C, "reference cell"))) return rc;
+    for (int q = 0; q < n_grp; ++q)
+        if (grp_off[q + 1] == grp_off[q]) ICNV_FAIL(ICNV_ERR_ARG, "empty group");
+    if ((int64_t)n_grp * n_chr > 8192)
+        ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "group HMM plan: more than 8192 (group, chromosome) sequences -- use icnv_viterbi_groups_dev");
+    // every cell in at most one group, every reference cell in exactly one: the moments are gathered while the groups' cells stream by
+    std::vector<int32_t> cell_to_grp((size_t)std::max<int64_t>(C, 1), -1);
+    for (int q = 0; q < n_grp; ++q)
+        for (int i = grp_off[q]; i < grp_off[q + 1]; ++i) {
+            if (cell_to_grp[grp_idx[i]] >= 0) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "group HMM plan: a cell in two groups -- use icnv_viterbi_groups_dev");
+            cell_to_grp[grp_idx[i]] = q;
+        }
+    std::vector<uint8_t> flag((size_t)std::max<int64_t>(C, 1), 0);
+    for (int64_t i = 0; i < n_ref; ++i) {
+        if (cell_to_grp[ref_idx[i]] < 0) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "group HMM plan: a reference cell in no group");
+        if (flag[ref_idx[i]]) ICNV_FAIL(ICNV_ERR_ARG, "reference cell listed twice");
+        flag[ref_idx[i]] = 1;
+    }
+    auto *h = new icnv_group_hmm();
+    h->G = G; h->C = C; h->n_chr = n_chr; h->n_grp = n_grp; h->n_ref = n_ref;
+    h->chr_start.assign(chr_start, chr_start + n_chr + 1);
+    for (int k = 0; k < n_chr; ++k) h->max_len = std::max(h->max_len, chr_start[k + 1] - chr_start[k]);
+    std::vector<int32_t> order;
+    chr_order_longest_first(chr_start, n_chr, order);
+    std::vector<int32_t> list;
+    for (int32_t c : order)
+        for (int32_t q = 0; q < n_grp; ++q) { list.push_back(c); list.push_back(q); }
+    h->count = (int32_t)(list.size() / 2);
+    list.push_back(h->count);   // the count rides behind the list
+    h->ns = group_means_nsplit((int32_t)G, std::max(n_grp, 1));
+    hipStream_t s = nullptr;
+    auto fail = [&](int code) { delete h; return code; };
+    if ((rc = upload(h->d_chr, h->chr_start.data(), h->chr_start.size(), s))) return fail(rc);
+    if ((rc = upload(h->d_idx, grp_idx, n_grp ? (size_t)grp_off[n_grp] : 0, s))) return fail(rc);
+    if ((rc = upload(h->d_off, grp_off, (size_t)n_grp + 1, s))) return fail(rc);
+    if ((rc = upload(h->d_map, cell_to_grp.data(), cell_to_grp.size(), s))) return fail(rc);
+    if ((rc = upload(h->d_ref, flag.data(), flag.size(), s))) return fail(rc);
+    if ((rc = upload(h->d_list, list.data(), list.size(), s))) return fail(rc);
+    const size_t ng = (size_t)std::max(n_grp, 1);
+    if ((rc = h->d_gm.alloc((size_t)G * ng * sizeof(double))) || (rc = h->d_gs.alloc((size_t)G * ng)) ||
+        (rc = h->d_part.alloc(ng * h->ns * 3 * (size_t)G * sizeof(double))) ||
+        (rc = h->d_mom.alloc((size_t)std::max<int64_t>(group_means_moment_blocks((int32_t)G, (int32_t)ng, h->ns), 1) * 2 * sizeof(double))) ||
+        (rc = h->d_m3.alloc(4 * sizeof(double))) || (rc = h->d_params.alloc(8 * sizeof(double))) ||
+        (rc = h->d_scr.alloc(viterbi_redo_scratch_bytes(h->max_len))) || (rc = h->d_bad.alloc(sizeof(int32_t))))
+        return fail(rc);
+    if (hipStreamSynchronize(s) != hipSuccess) { delete h; ICNV_FAIL(ICNV_ERR_HIP, "upload of the group structure failed"); }   // (the host vectors go out of scope)
+    *out = h;
+    return ICNV_OK;
+}
+
+int icnv_group_hmm_i3_partial_dev(icnv_group_hmm_t *h, const double *expr, double **moments_dev, void *stream) {
+    if (!h || (!expr && h->C > 0)) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    const int64_t nb = group_means_moment_blocks((int32_t)h->G, h->n_grp, h->ns);
+    if (h->n_grp > 0) {
+        if ((rc = launch_group_means_ws(expr, (int32_t)h->G, h->d_idx.as<int32_t>(), h->d_off.as<int32_t>(), h->n_grp, h->ns, h->d_part.as<double>(),
+                                        h->d_gm.as<double>(), s, h->d_ref.as<uint8_t>(), h->d_mom.as<double>())))
+            return rc;
+    }
+    // {S1, S2, n}: this rank's share (zeros from a rank without groups); all-reduce(sum) them in a cell-sharded run
+    if ((rc = launch_reduce_moments(h->d_mom.as<double>(), h->n_grp > 0 ? nb : 0, (double)h->n_ref * (double)h->G, h->d_m3.as<double>(), s))) return rc;
+    if (moments_dev) *moments_dev = h->d_m3.as<double>();
+    return ICNV_OK;
+}
+
+int icnv_group_hmm_i3_finish_dev(icnv_group_hmm_t *h, uint8_t *states, const double *logPi, const double *logDelta, double z_abs,
+                                 double delta_abs, int32_t *n_underflow_dev, void *stream) {
+    if (!h || (!states && h->C > 0)) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
+    if (!(delta_abs == delta_abs) && !(z_abs > 0.0)) ICNV_FAIL(ICNV_ERR_ARG, "z_abs must be positive when no delta is given");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = launch_i3_params(h->d_m3.as<double>(), z_abs, delta_abs, h->d_params.as<double>(), s))) return rc;
+    // logPi / logDelta: log of .i3HMM_get_HMM's matrices (R/inferCNV_i3HMM.R:99-156), prepared by the caller as for icnv_viterbi_groups_dev
+    const double mean0[3] = {0.0, 0.0, 0.0};   // (the means come from the device)
+    HmmParams p;
+    if ((rc = fill_hmm(p, 3, mean0, logPi, logDelta))) return rc;
+    int32_t *bad = n_underflow_dev ? n_underflow_dev : h->d_bad.as<int32_t>();
+    if (h->n_grp > 0) {
+        if ((rc = launch_viterbi_redo(h->d_gm.as<double>(), h->d_gs.as<uint8_t>(), (int32_t)h->G, h->d_chr.as<int32_t>(), p, nullptr, 1.0,
+                                      h->d_list.as<int32_t>() + 2 * (size_t)h->count, h->d_list.as<int32_t>(), 0x7fffffff, h->d_scr.as<uint32_t>(),
+                                      bad, h->max_len, "viterbi", s, 0, 0, h->d_params.as<double>())))
+            return rc;
+    }
+    return launch_broadcast_states(h->d_gs.as<uint8_t>(), (int32_t)h->G, h->C, h->d_map.as<int32_t>(), states, s);
+}
+
+int icnv_group_hmm_get_i3_params(icnv_group_hmm_t *h, double *mu_sigma_delta, void *stream) {
+    if (!h || !mu_sigma_delta) ICNV_FAIL(ICNV_ERR_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    double buf[6];
+    ICNV_HIP(hipMemcpyAsync(buf, h->d_params.p, sizeof(buf), hipMemcpyDeviceToHost, s));
+    ICNV_HIP(hipStreamSynchronize(s));
+    mu_sigma_delta[0] = buf[4]; mu_sigma_delta[1] = buf[3]; mu_sigma_delta[2] = buf[5];
+    return ICNV_OK;
+}
+
+void icnv_group_hmm_end(icnv_group_hmm_t *h) { delete h; }
+
 }  // extern "C"
 // single-device forms of the host-buffer group entry points (the extern "C" ones live in host_path.hip: they deal whole
 // groups / tiles to the devices of icnv_set_devices)

@@ -253,10 +253,15 @@ int launch_viterbi_redo(const double *x, uint8_t *states, int32_t G, const int32
                         const double *sd_per_col_dev, double sd_shared, const int32_t *flag_count_dev,
                         const int32_t *flag_list_dev, int32_t max_count /* lists longer than this are left alone */,
                         uint32_t *bp_redo, int32_t *n_underflow, int32_t max_chr_len, const char *timer_name,
-                        hipStream_t stream, int64_t ld_x = 0, int64_t ld_st = 0);
+                        hipStream_t stream, int64_t ld_x = 0, int64_t ld_st = 0,
+                        const double *params_dev = nullptr /* [mean_0 .. mean_{K-1}, sd] on the device instead of p.mean / sd_shared */);
 int group_means_nsplit(int32_t G, int32_t n_grp);
 int launch_group_means_ws(const double *x, int32_t G, const int32_t *grp_idx_dev, const int32_t *grp_off_dev,
-                          int32_t n_grp, int nsplit, double *part, double *out, hipStream_t stream);
+                          int32_t n_grp, int nsplit, double *part, double *out, hipStream_t stream,
+                          const uint8_t *ref_flag_dev = nullptr, double *mom = nullptr);   // (+ the shifted moments of the flagged cells' values, two doubles per workgroup)
+int64_t group_means_moment_blocks(int32_t G, int32_t n_grp, int nsplit);
+int launch_reduce_moments(const double *mom, int64_t n_blocks, double n_values, double *out3, hipStream_t stream);
+int launch_i3_params(const double *m3, double z, double delta_abs, double *params6, hipStream_t stream);
 int launch_broadcast_states(const uint8_t *grp_states, int32_t G, int64_t C, const int32_t *cell_to_grp_dev,
                             uint8_t *states, hipStream_t stream);
 int launch_state_consensus(const uint8_t *states, int32_t G, const int32_t *grp_idx_dev, const int32_t *grp_off_dev,

@@ -275,6 +275,58 @@ def viterbi_groups(x, chr_start, groups, means, sd_shared_per_group, logPi, logD
     return states, bad
 
 
+class GroupHMMPlan:
+    """The i3 HMM at group level with device-resident parameters (icnv_group_hmm_* in include/icnv.h): the group structure is
+    uploaded once; `i3_partial(x)` returns the three shifted moments as a CUDA tensor view (all-reduce it in place in a
+    cell-sharded run), `i3_finish(states, ...)` derives mu / sigma / delta on the device and runs the Viterbi + broadcast.
+    No host round trip inside a step."""
+
+    def __init__(self, G, C, chr_start, groups, ref_cells):
+        self.L = _lib.load()
+        self.G, self.C = int(G), int(C)
+        self.cs, cp = i32(chr_start)
+        idx, off = pack_groups(groups)
+        self.idx, ip = i32(idx)
+        self.off, op = i32(off)
+        self.ref, rp = i32(ref_cells)
+        h = ct.c_void_p()
+        check(self.L.icnv_group_hmm_begin(ct.byref(h), self.G, self.C, cp, self.cs.size - 1, ip, op, len(groups), rp, self.ref.size))
+        self.h = h
+
+    def i3_partial(self, x):
+        C, G = _check_matrix(x)
+        assert (C, G) == (self.C, self.G)
+        p = ct.c_void_p()
+        check(self.L.icnv_group_hmm_i3_partial_dev(self.h, _ptr(x), ct.byref(p), _stream()))
+        return _wrap_f64(p.value, 3, x.device)
+
+    def i3_finish(self, logPi, logDelta, z_abs, delta_abs=None, states=None, device=None):
+        if states is None:
+            states = torch.empty((self.C, self.G), dtype=torch.uint8, device=device or "cuda")
+        lp = np.asfortranarray(logPi, dtype=np.float64)
+        ld, ldp = f64(logDelta)
+        check(self.L.icnv_group_hmm_i3_finish_dev(self.h, _ptr(states), lp.ctypes.data_as(ct.POINTER(ct.c_double)), ldp, float(z_abs),
+                                                  float("nan") if delta_abs is None else float(delta_abs), None, _stream()))
+        return states
+
+    def i3_params(self):
+        """(mu, sigma, delta) of the last finish (synchronises)."""
+        buf = (ct.c_double * 3)()
+        check(self.L.icnv_group_hmm_get_i3_params(self.h, buf, _stream()))
+        return buf[0], buf[1], buf[2]
+
+    def close(self):
+        if self.h:
+            self.L.icnv_group_hmm_end(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def group_means(x, groups):
     """rowMeans(expr.data[, group]) per group -> (n_groups, G) tensor."""
     L = _lib.load()

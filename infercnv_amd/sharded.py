@@ -190,17 +190,47 @@ class ShardedGroupHMM:
         mu, sigma = sharded_mean_sd(lambda ph, m: self.engine.moments_partial(x_local, ref_local, ph, m), self.pg, self.device)
         return mu, sigma, abs(statistics.NormalDist(0.0, sigma).inv_cdf(i3_p_val))
 
+    def _plan_for(self, x_local, chr_start, groups_local, ref_local):
+        """The device plan of this (matrix shape, layout, groups, reference cells), built on first use and kept: the group
+        structure is uploaded once, not per step.  None when the engine is not the device engine or the plan does not take
+        the groups (a cell in two groups, more than 8192 sequences): run_i3 then takes the call-by-call path."""
+        if not isinstance(self.engine, DeviceGroupEngine):
+            return None
+        key = (tuple(x_local.shape), np.asarray(chr_start).tobytes(), tuple(np.asarray(g).tobytes() for g in groups_local),
+               np.asarray(ref_local).tobytes())
+        if getattr(self, "_plan_key", None) != key:
+            from . import device
+            self._plan, self._plan_key = None, key
+            try:
+                self._plan = device.GroupHMMPlan(x_local.shape[1], x_local.shape[0], chr_start, groups_local, ref_local)
+            except RuntimeError as e:                # ICNV_ERR_UNSUPPORTED (3): the call-by-call path serves these groups
+                if getattr(e, "code", None) != 3:
+                    raise
+                self._plan = None
+        return self._plan
+
     def run_i3(self, x_local, chr_start, groups_local, ref_local, t=1e-6, i3_p_val=0.05, ks_delta=None):
         """i3HMM_predict_CNV_via_HMM_on_tumor_subclusters (R/inferCNV_i3HMM.R:249-308): states of this rank's cells.
         The state means sit at mu +- delta: the Z-based delta of use_KS = FALSE, or `ks_delta` -- the KS-based one of the
         reference's default use_KS = TRUE, a function of (sigma, p, number of reference cells, RNG state) alone
         (hmm.get_HoneyBADGER_setGexpDev), so every rank computes the same value from the all-reduced sigma."""
-        mu, sigma, delta = self.i3_params(x_local, ref_local, i3_p_val)
-        if ks_delta is not None:
-            delta = float(ks_delta(sigma)) if callable(ks_delta) else float(ks_delta)
         Pi = np.full((3, 3), t)
         np.fill_diagonal(Pi, 1.0 - 5.0 * t)               # the reference's 1 - 5t diagonal with three states (:108-112)
         d0 = np.array([t, 1.0 - 5.0 * t, t])
+        plan = None if callable(ks_delta) else self._plan_for(x_local, chr_start, groups_local, ref_local)
+        if plan is not None:
+            # device-resident parameters (round 6): one pass for the group means AND the reference moments, the all-reduce of three
+            # doubles on the library's own buffer, mu / sigma / delta derived on the device -- no host round trip in the step
+            import statistics
+            import torch.distributed as dist
+            m3 = plan.i3_partial(x_local)
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1:
+                dist.all_reduce(m3, op=dist.ReduceOp.SUM, group=self.pg)
+            z = abs(statistics.NormalDist().inv_cdf(i3_p_val))
+            return plan.i3_finish(np.log(Pi), np.log(d0), z, None if ks_delta is None else float(ks_delta), device=x_local.device)
+        mu, sigma, delta = self.i3_params(x_local, ref_local, i3_p_val)
+        if ks_delta is not None:
+            delta = float(ks_delta(sigma)) if callable(ks_delta) else float(ks_delta)
         means = np.array([mu - delta, mu, mu + delta])
         return self.engine.viterbi_groups(x_local, chr_start, groups_local, means, [sigma] * len(groups_local),
                                           np.log(Pi), np.log(d0))

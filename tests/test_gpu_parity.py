@@ -1632,3 +1632,52 @@ def test_padded_leading_dimension_chain_and_viterbi(dev, G, C):
     L = _lib.load()
     assert L.icnv_viterbi_cells_ld_dev(ct.c_void_p(pre_c.data_ptr()), G - 1, ct.c_void_p(st_c.data_ptr()), G, G, C, None, 0, 6, None, 0.1, None, None,
                                        None, None) == 1
+
+
+def test_group_hmm_plan_i3_device_resident_parameters(dev):
+    """Round 6: the i3 HMM at group level as a plan (icnv_group_hmm_*): group means and the reference cells' shifted moments in ONE
+    pass, mu / sigma / delta derived on the device, the Viterbi reading them from device memory.  Against the call-by-call path
+    (two-pass long-double moments on the host, icnv_viterbi_groups_dev) and the oracle: mu and sigma to 1e-13 relative, every
+    state call identical; a second step on the same plan (nothing is uploaded again) and a KS-style explicit delta; groups the
+    plan does not take (a cell in two groups) are refused with ICNV_ERR_UNSUPPORTED -- sharded.ShardedGroupHMM falls back."""
+    import statistics
+    from infercnv_amd import synth, sharded, _lib
+    G, C = 3000, 900
+    x, cs = synth.make_matrix_np(G, C)
+    refs, _ = synth.groups(C)
+    _, pre, _ = oc.smooth_chain(x, cs, refs, want_pre_denoise=True)
+    subs, is_ref, _ = synth.subclusters(C)
+    groups = [np.asarray(g, dtype=np.int32) for g in subs]
+    ref_cells = np.concatenate([g for g, r in zip(groups, is_ref) if r])
+    pd = to_dev(pre)
+    mu0, sigma0 = dev.cells_mean_sd(pd, ref_cells)
+    z = abs(statistics.NormalDist().inv_cdf(0.05))
+    Pi3, d3 = onp.get_HMM_i3(1e-6)
+    plan = dev.GroupHMMPlan(G, C, cs, groups, ref_cells)
+    for step in range(2):
+        m3 = plan.i3_partial(pd)
+        st = plan.i3_finish(np.log(Pi3), np.log(d3), z, device=pd.device)
+        mu, sigma, delta = plan.i3_params()
+        assert abs(mu - mu0) <= 1e-13 * abs(mu0) and abs(sigma - sigma0) <= 1e-13 * sigma0, (mu, mu0, sigma, sigma0)
+        assert abs(delta - sigma * z) <= 1e-15
+        assert float(m3[2]) == ref_cells.size * G
+        want, _ = dev.viterbi_groups(pd, cs, groups, np.array([mu0 - sigma0 * z, mu0, mu0 + sigma0 * z]), [sigma0] * len(groups), np.log(Pi3), np.log(d3))
+        assert torch.equal(st, want), int((st != want).sum())
+    ref_states, _ = oc.viterbi_groups(pre, cs, groups, np.array([mu0 - sigma0 * z, mu0, mu0 + sigma0 * z]), [sigma0] * len(groups), np.log(Pi3), np.log(d3))
+    np.testing.assert_array_equal(to_host(st), ref_states)
+    assert len(np.unique(ref_states)) >= 2
+    # an explicit delta (the KS-based one of use_KS = TRUE is computed by the caller from sigma)
+    st_k = plan.i3_finish(np.log(Pi3), np.log(d3), z, delta_abs=0.07, device=pd.device)
+    want_k, _ = dev.viterbi_groups(pd, cs, groups, np.array([mu0 - 0.07, mu0, mu0 + 0.07]), [sigma0] * len(groups), np.log(Pi3), np.log(d3))
+    assert torch.equal(st_k, want_k)
+    plan.close()
+    # the sharded driver takes the plan by itself and gives the call-by-call result
+    hmm = sharded.ShardedGroupHMM()
+    got = hmm.run_i3(pd, cs, groups, ref_cells)
+    assert hmm._plan is not None and torch.equal(got, want)
+    with pytest.raises(_lib.IcnvError) as e:
+        dev.GroupHMMPlan(G, C, cs, groups + [groups[0][:3]], ref_cells)
+    assert e.value.code == 3
+    hmm2 = sharded.ShardedGroupHMM()
+    got2 = hmm2.run_i3(pd, cs, groups + [groups[0][:3]], ref_cells)       # falls back to the call-by-call path
+    assert hmm2._plan is None and got2.shape == got.shape
