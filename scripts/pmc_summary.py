@@ -31,7 +31,7 @@ for t in ("copy", "bench"):
             out["calibration_copy_4e9_read_4e9_write"] = {"fetch_bytes_corrected": fb, "write_bytes": wb}
 # configs 4 / 5: bytes per STEP of the step's own kernels (the run is 1 warm-up + 2 steps; the chain that prepares the
 # inputs runs once and is left out)
-STEP_KERNELS = {"cfg4": ("block_cell_reduce_kernel", "group_partial_sums_kernel", "group_means_finish_kernel", "viterbi_redo_kernel",
+STEP_KERNELS = {"cfg4": ("block_cell_reduce_kernel", "group_partial_sums_kernel", "group_means_finish_kernel", "reduce_moments_kernel", "i3_params_kernel", "viterbi_redo_kernel",
                          "viterbi_kernel", "viterbi_fast_kernel", "broadcast_states_kernel"),
                 "cfg5": ("median9_classify_kernel", "median_filter9_kernel", "median9_sparse_kernel", "median_filter_kernel")}
 def load_all(path):

@@ -22,6 +22,7 @@ cd /tmp
 timeout 300 python $R/bench.py > $O/bench_full.json 2> $O/bench_full.err
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o $TAG -- python $R/bench.py --no-cpu-baseline > $O/prof/bench_under_rocprof.json 2> $O/prof/log.txt   # the default command without its CPU / host-buffer legs (they launch the same kernels on other matrices and would mix into the averages)
 python $R/scripts/rocprof_summary.py $O/prof/${TAG}_results.db > $O/${TAG}_kernel_stats.txt 2>&1
+python $R/scripts/step_gaps.py $O/prof/${TAG}_results.db > $O/${TAG}_step_timeline.txt 2>&1   # the same trace as a timeline: kernel time vs time between kernels, per step
 rm -f $O/prof/*.db      # (gpurun merges at most 64 MiB back: the summaries travel, the raw traces do not)
 for c in 4 5; do
   timeout 300 python $R/bench.py --config $c --no-cpu-baseline > $O/bench_config$c.json 2> $O/bench_config$c.err
