@@ -99,7 +99,7 @@ def measure_ceilings():
 
 STREAM_1R2W_GBS, STREAM_1R2W_SOURCE = _stream_ceiling_from_file()     # replaced by measure_ceilings() in main()
 FP64_VECTOR_PEAK_TF = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
-VITERBI_VALU_PER_GENE = 92.1   # SQ_INSTS_VALU / (genes x cells / 64) of the staged kernel, profiles/r05_pmc_viterbi_fast.txt (traceback included)
+VITERBI_VALU_PER_GENE = 92.1   # SQ_INSTS_VALU / (genes x cells / 64) of the staged kernel, profiles/r06_pmc_viterbi_fast.txt: 7.1976e8 / 7.8125e6 (traceback included; round 5 measured the same)
 COLUMN_WALK_GBS, COLUMN_WALK_SOURCE = 3660.0, "profiles/r04_ubench_column_walk.txt"   # replaced by measure_ceilings() in main()
 ROW_REQUESTS_GBS, ROW_REQUESTS_SOURCE = None, None                                     # set by measure_ceilings() in main()
 
@@ -796,7 +796,7 @@ def main():
                                        "the launch is now paced by vector issue.  No MFMA-shaped work")
         if "viterbi" in roof:
             # second ceiling of the Viterbi (SURVEY.md 8d asks for HBM GB/s *and* the fp64 rate): vector instructions per gene and
-            # wavefront (SQ_INSTS_VALU of the launch / gene steps, profiles/r05_pmc_viterbi_fast.txt; 84 of them in the forward pass
+            # wavefront (SQ_INSTS_VALU of the launch / gene steps, profiles/r06_pmc_viterbi_fast.txt; 84 of them in the forward pass
             # by static count, scripts/vf_asm_stats.py), every one of them 4 cycles of a 16-lane SIMD; 256 CUs x 4 SIMDs at the 2.4 GHz peak clock
             instr = VITERBI_VALU_PER_GENE
             ceil_ms = (G * C_local / 64.0) * instr * 4.0 / (256 * 4) / 2.4e9 * 1e3
