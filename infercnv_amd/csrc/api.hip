@@ -1780,7 +1780,7 @@ struct icnv_group_hmm {
     int32_t n_chr = 0, n_grp = 0, max_len = 0, ns = 1;
     int64_t n_ref = 0;
     std::vector<int32_t> chr_start;
-    DevBuf d_chr, d_idx, d_off, d_map, d_ref, d_list, d_gm, d_gs, d_part, d_mom, d_m3, d_params, d_scr, d_bad;
+    DevBuf d_chr, d_idx, d_off, d_map, d_ref, d_kind, d_list, d_gm, d_gs, d_part, d_mom, d_m3, d_params, d_scr, d_bad;
     int32_t count = 0;
 };
 
@@ -1829,6 +1829,13 @@ int icnv_group_hmm_begin(icnv_group_hmm_t **out, int64_t G, int64_t C, const int
     if ((rc = upload(h->d_off, grp_off, (size_t)n_grp + 1, s))) return fail(rc);
     if ((rc = upload(h->d_map, cell_to_grp.data(), cell_to_grp.size(), s))) return fail(rc);
     if ((rc = upload(h->d_ref, flag.data(), flag.size(), s))) return fail(rc);
+    std::vector<uint8_t> kind((size_t)std::max(n_grp, 1), 0);   // per group: 0 no reference cell, 1 reference cells only, 2 mixed
+    for (int q = 0; q < n_grp; ++q) {
+        int nr = 0;
+        for (int i = grp_off[q]; i < grp_off[q + 1]; ++i) nr += flag[grp_idx[i]];
+        kind[(size_t)q] = nr == 0 ? 0 : (nr == grp_off[q + 1] - grp_off[q] ? 1 : 2);
+    }
+    if ((rc = upload(h->d_kind, kind.data(), kind.size(), s))) return fail(rc);
     if ((rc = upload(h->d_list, list.data(), list.size(), s))) return fail(rc);
     const size_t ng = (size_t)std::max(n_grp, 1);
     if ((rc = h->d_gm.alloc((size_t)G * ng * sizeof(double))) || (rc = h->d_gs.alloc((size_t)G * ng)) ||
@@ -1849,7 +1856,7 @@ int icnv_group_hmm_i3_partial_dev(icnv_group_hmm_t *h, const double *expr, doubl
     const int64_t nb = group_means_moment_blocks((int32_t)h->G, h->n_grp, h->ns);
     if (h->n_grp > 0) {
         if ((rc = launch_group_means_ws(expr, (int32_t)h->G, h->d_idx.as<int32_t>(), h->d_off.as<int32_t>(), h->n_grp, h->ns, h->d_part.as<double>(),
-                                        h->d_gm.as<double>(), s, h->d_ref.as<uint8_t>(), h->d_mom.as<double>())))
+                                        h->d_gm.as<double>(), s, h->d_ref.as<uint8_t>(), h->d_mom.as<double>(), h->d_kind.as<uint8_t>())))
             return rc;
     }
     // {S1, S2, n}: this rank's share (zeros from a rank without groups); all-reduce(sum) them in a cell-sharded run

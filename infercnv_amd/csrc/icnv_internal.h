@@ -258,7 +258,8 @@ int launch_viterbi_redo(const double *x, uint8_t *states, int32_t G, const int32
 int group_means_nsplit(int32_t G, int32_t n_grp);
 int launch_group_means_ws(const double *x, int32_t G, const int32_t *grp_idx_dev, const int32_t *grp_off_dev,
                           int32_t n_grp, int nsplit, double *part, double *out, hipStream_t stream,
-                          const uint8_t *ref_flag_dev = nullptr, double *mom = nullptr);   // (+ the shifted moments of the flagged cells' values, two doubles per workgroup)
+                          const uint8_t *ref_flag_dev = nullptr, double *mom = nullptr,   // (+ the shifted moments of the flagged cells' values, two doubles per workgroup;
+                          const uint8_t *grp_kind_dev = nullptr);                         //  grp_kind[q]: 0 no flagged cell in group q, 1 only flagged cells, 2 mixed / unknown)
 int64_t group_means_moment_blocks(int32_t G, int32_t n_grp, int nsplit);
 int launch_reduce_moments(const double *mom, int64_t n_blocks, double n_values, double *out3, hipStream_t stream);
 int launch_i3_params(const double *m3, double z, double delta_abs, double *params6, hipStream_t stream);
