@@ -667,12 +667,21 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
             // the slow list as a whole, so the size is a performance knob, not a limit)
             const int64_t outs_per_wg = n_tiles9 * (K1G * K1C) / grid1 + 1;
             L.qcap = (int)std::min<int64_t>(std::max<int64_t>(outs_per_wg * 5 / 100, 2 * K1G * K1C), 1 << 24);
+            // ... and never more than 1 GiB over all segments (ADVICE, round 5: 5 % of the outputs at 16 bytes is ~10 % of the matrix bytes --
+            // 8 GB for 10 000 x 1 000 000 on a GPU that holds 270 GB of matrices)
+            L.qcap = (int)std::min<int64_t>(L.qcap, std::max<int64_t>(((int64_t)1 << 30) / ((int64_t)grid1 * (int64_t)sizeof(uint4)), 2 * K1G * K1C));
             if (const char *e = std::getenv("ICNV_MF9_QCAP")) L.qcap = std::max(1, std::atoi(e));   // developer / test switch: a tiny queue sends tiles to the slow list
-            const size_t b_queue = (size_t)grid1 * L.qcap * sizeof(uint4);
             const size_t b_list = ((size_t)grid1 * L.lcap * sizeof(int32_t) + 15) & ~(size_t)15;
             const size_t b_cnt = ((size_t)grid1 * sizeof(int32_t) + 15) & ~(size_t)15;
             const size_t b_flag = ((size_t)n_tiles2 + 15) & ~(size_t)15;
-            if (int rc = plan9.queue->alloc(b_queue + b_list + 2 * b_cnt + b_flag)) return rc;
+            size_t b_queue = 0;
+            for (;;) {   // a pool that cannot give the queue gets a shorter one: more tiles take the slow list, nothing fails
+                b_queue = (size_t)grid1 * L.qcap * sizeof(uint4);
+                const int rc = plan9.queue->alloc(b_queue + b_list + 2 * b_cnt + b_flag);
+                if (!rc) break;
+                if (L.qcap <= 64) return rc;
+                L.qcap = std::max(64, L.qcap / 4);
+            }
             char *base = plan9.queue->as<char>();
             L.queue = reinterpret_cast<uint4 *>(base); base += b_queue;
             L.slow = reinterpret_cast<int32_t *>(base); base += b_list;
