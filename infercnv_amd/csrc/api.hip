@@ -2076,11 +2076,15 @@ int icnv_median_filter_dev(const double *expr_in, double *expr_out, int64_t G, i
     // Kernel 1 cuts every (cell tile, chromosome) block into tiles of 56 genes x 32 cells from its first gene / cell, borders
     // included; the dense pass has its own grid of 32 genes x 16 cells over the same blocks (a tile of kernel 1 covers two of
     // its cell blocks exactly and two or three of its gene blocks).
-    std::vector<int32_t> gdesc, cdesc, g1desc, c1desc;
+    std::vector<int32_t> gdesc, cdesc, g1desc, c1desc, sdesc, segdesc;
     if (median_is_9x9(window_size)) {
         for (int k = 0; k < n_chr; ++k) {
             const int32_t cs = chr_start[k], xdim = chr_start[k + 1] - chr_start[k];
             const int32_t kb2 = (int32_t)(gdesc.size() / 4);   // the chromosome's first dense-pass gene block
+            for (int g0 = 0; g0 < xdim; g0 += MEDIAN9_STRIP_GENES) {   // strip kernel: 64 output genes = two dense-pass gene blocks
+                const int32_t r[4] = {cs, xdim, g0, kb2 + g0 / MEDIAN_GENES_PER_PATCH};
+                sdesc.insert(sdesc.end(), r, r + 4);
+            }
             for (int g0 = 0; g0 < xdim; g0 += MEDIAN_GENES_PER_PATCH) {   // dense pass: {cs, xdim, first gene, end of its interior outputs}
                 const int32_t r[4] = {cs, xdim, g0, std::min(g0 + MEDIAN_GENES_PER_PATCH, xdim - 4)};
                 gdesc.insert(gdesc.end(), r, r + 4);
@@ -2092,6 +2096,10 @@ int icnv_median_filter_dev(const double *expr_in, double *expr_out, int64_t G, i
         }
         for (int t = 0; t < n_tiles; ++t) {
             const int32_t ydim = tile_off[t + 1] - tile_off[t];
+            for (int c0 = 0; c0 < ydim; c0 += MEDIAN9_SEG_BLOCKS * MEDIAN9_CELLS_PER_PATCH) {   // strip kernel: segments of eight dense-pass cell blocks
+                const int32_t r[4] = {tile_off[t], ydim, c0, (int32_t)(cdesc.size() / 4) + c0 / MEDIAN9_CELLS_PER_PATCH};
+                segdesc.insert(segdesc.end(), r, r + 4);
+            }
             for (int c0 = 0; c0 < ydim; c0 += MEDIAN9_K1_CELLS) {
                 const int32_t r1[4] = {tile_off[t], ydim, c0, (int32_t)(cdesc.size() / 4)};
                 c1desc.insert(c1desc.end(), r1, r1 + 4);
@@ -2102,7 +2110,9 @@ int icnv_median_filter_dev(const double *expr_in, double *expr_out, int64_t G, i
             }
         }
     }
-    DevBuf d_chr, d_idx, d_off, d_blk, d_gd, d_cd, d_g1, d_c1;
+    DevBuf d_chr, d_idx, d_off, d_blk, d_gd, d_cd, d_g1, d_c1, d_sd, d_seg;
+    if (!sdesc.empty() && (rc = upload(d_sd, sdesc.data(), sdesc.size(), s))) return rc;
+    if (!segdesc.empty() && (rc = upload(d_seg, segdesc.data(), segdesc.size(), s))) return rc;
     if (!gdesc.empty() && (rc = upload(d_gd, gdesc.data(), gdesc.size(), s))) return rc;
     if (!cdesc.empty() && (rc = upload(d_cd, cdesc.data(), cdesc.size(), s))) return rc;
     if (!g1desc.empty() && (rc = upload(d_g1, g1desc.data(), g1desc.size(), s))) return rc;
@@ -2122,6 +2132,11 @@ int icnv_median_filter_dev(const double *expr_in, double *expr_out, int64_t G, i
     plan9.cell1_desc = d_c1.as<int32_t>();
     plan9.n_gene_blocks1 = (int32_t)(g1desc.size() / 4);
     plan9.n_cell_patches1 = (int32_t)(c1desc.size() / 4);
+    plan9.strip_desc = d_sd.as<int32_t>();
+    plan9.seg_desc = d_seg.as<int32_t>();
+    plan9.n_strips = (int32_t)(sdesc.size() / 4);
+    plan9.n_segs = (int32_t)(segdesc.size() / 4);
+    plan9.n_list = tile_off[n_tiles];
     return launch_median_filter(expr_in, expr_out, (int32_t)G, C, d_chr.as<int32_t>(), n_chr, d_idx.as<int32_t>(),
                                 d_off.as<int32_t>(), n_tiles, d_blk.as<int32_t>(), chr_start, blk_off[n_tiles],
                                 window_size, plan9, s);

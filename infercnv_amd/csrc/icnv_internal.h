@@ -284,6 +284,11 @@ struct Median9Plan {
     const int32_t *gene1_desc = nullptr;        // kernel 1, 4 ints: {chromosome's first gene, its length, tile's first gene, index of its first dense-pass gene block}
     const int32_t *cell1_desc = nullptr;        // kernel 1, 4 ints: {offset of the tile's cells, tile length, tile's first cell, index of its first dense-pass cell block}
     int32_t n_gene_blocks = 0, n_cell_patches = 0, n_gene_blocks1 = 0, n_cell_patches1 = 0;
+    // the strip form of the dense pass (round 6): 64-gene strips of the chromosomes x segments of eight 16-cell blocks of the cell tiles
+    const int32_t *strip_desc = nullptr;        // 4 ints: {chromosome's first gene, its length, strip's first gene, index of that gene's dense-pass gene block}
+    const int32_t *seg_desc = nullptr;          // 4 ints: {offset of the tile's cells, tile length, segment's first cell, index of that cell's dense-pass cell block}
+    int32_t n_strips = 0, n_segs = 0;
+    int32_t n_list = 0;                         // entries of the tiles' cell lists (the probe samples them)
     DevBuf *queue = nullptr;                    // workspace of the three-kernel scheme's lists (allocated by the launch, owned by the caller)
 };
 int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, const int32_t *chr_start_dev,
@@ -295,5 +300,6 @@ constexpr int MEDIAN9_CELLS_PER_PATCH = 16;
 constexpr int MEDIAN9_K1_GENES = 56, MEDIAN9_K1_CELLS = 32;   // kernel 1's tile: with the halo one tile row is the 64 lanes of a wavefront
 inline bool median_is_9x9(int32_t window_size) { return (window_size - 1) / 2 + 1 == 4; }
 constexpr int MEDIAN_CELLS_PER_PATCH = 8;   // generic kernel
+constexpr int MEDIAN9_STRIP_GENES = 64, MEDIAN9_SEG_BLOCKS = 8;   // strip kernel: output genes per wavefront, 16-cell blocks per segment
 
 }  // namespace icnv

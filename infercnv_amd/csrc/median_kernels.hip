@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 #include "icnv_internal.h"
 
@@ -34,6 +35,7 @@ __device__ static inline double icnv_mf_max(double x, double y) {
 #define ICNV_FMAX(a, b) icnv_mf_max(a, b)
 #endif
 #include "median9x9_net.h"
+#include "median9_strip_net.h"
 
 namespace icnv {
 
@@ -240,6 +242,9 @@ __device__ __forceinline__ void median9_general_output(const double *__restrict_
 constexpr int MF9_SPARSE_T = 128;   // more undecided interior outputs than this in a tile (of up to 512): the tile goes to the dense list
 constexpr int MF9_NT = MF_TG * MF_TC;
 
+struct StripParams;         // what the probe kernel found (defined with the strip kernel)
+__device__ inline bool median9_has_dominant_value(const StripParams *P);
+
 struct Median9Lists {       // per-workgroup segments of kernel 1's grid
     uint4 *queue;           // [n_seg][qcap] {p, a, clamp, 0}
     int32_t *qcount;        // [n_seg]
@@ -267,7 +272,8 @@ __global__ void __launch_bounds__(256, 4) median9_classify_kernel(
     const double *__restrict__ in, double *__restrict__ out, int G, const int32_t *__restrict__ tile_idx,
     const int4 *__restrict__ gene1_desc /* {chromosome's first gene, its length, tile's first gene, index of the CHROMOSOME's first dense-pass gene block} */,
     const int4 *__restrict__ cell1_desc /* {offset of the cell tile's list, its length, tile's first cell, index of its first dense-pass cell block} */,
-    int gene_blocks1, int64_t n_tiles, int gene_blocks2, Median9Lists L, int dev_mode /* developer switch: 1 no test, 2 no queue for interior outputs */) {
+    int gene_blocks1, int64_t n_tiles, int gene_blocks2, Median9Lists L, int dev_mode /* developer switch: 1 no test, 2 no queue for interior outputs */,
+    const StripParams *__restrict__ probe_result /* nullable */) {
     constexpr int NW = 4;
     __shared__ unsigned long long lessmask[2][K1ROWS], grtmask[2][K1ROWS];   // per tile row: bit l = the value at gene g0 - 4 + l lies below / above the candidate
     __shared__ unsigned int wcnt[2][NW];
@@ -276,7 +282,7 @@ __global__ void __launch_bounds__(256, 4) median9_classify_kernel(
     uint4 *queue = L.queue + (int64_t)blockIdx.x * L.qcap;
     int32_t *slist = L.slow + (int64_t)blockIdx.x * L.lcap;
     int qn = 0, sn = 0;                  // entries of this workgroup's segments (the same numbers in every thread)
-    const int64_t step = gridDim.x;
+    const int64_t step = gridDim.x, pend = n_tiles;
     int64_t pid = blockIdx.x;
     struct Where { int cs, xdim, g0, kb2, ydim, c0, idx_off, kc2; };
     auto where = [&](int64_t p) {
@@ -306,20 +312,21 @@ __global__ void __launch_bounds__(256, 4) median9_classify_kernel(
         }
     };
     double vguess = 0.0;
-    int miss = 0, cold = (dev_mode & 1) ? 0x7fffffff : 0;
+    // (round 6) a matrix in which the probe found no dominant value is not read at all: every tile goes to the dense pass, every border output to the queue
+    int miss = 0, cold = ((dev_mode & 1) || (probe_result && !median9_has_dominant_value(probe_result))) ? 0x7fffffff : 0;
     bool loaded = false;                 // the current tile's values are in `stage`
-    if (pid >= n_tiles) {
+    if (pid >= pend) {
         if (threadIdx.x == 0) { L.qcount[blockIdx.x] = 0; L.scount[blockIdx.x] = 0; }
         return;
     }
     Where D0 = where(pid), D1 = D0, D2 = D0;
-    if (pid + step < n_tiles) D1 = where(pid + step);
-    if (pid + 2 * step < n_tiles) D2 = where(pid + 2 * step);
+    if (pid + step < pend) D1 = where(pid + step);
+    if (pid + 2 * step < pend) D2 = where(pid + 2 * step);
     int32_t R0 = load_ridx(D0), R1 = load_ridx(D1);
     // first candidate: an element of the first tile (wave-uniform address); re-seeded below when it decides nothing
     vguess = in[(int64_t)tile_idx[D0.idx_off + (D0.c0 + 8 < D0.ydim ? D0.c0 + 8 : D0.c0)] * G + D0.cs + D0.g0];
     if (cold == 0) { gather(D0, R0); loaded = true; }
-    for (int it = 0; pid < n_tiles; pid += step, ++it) {
+    for (int it = 0; pid < pend; pid += step, ++it) {
         const Where w = D0;
         // (workgroup-uniform; a NaN candidate -- a probe can pick one up from the data -- decides nothing: tested on the bits)
         const bool test = loaded && !(((unsigned long long)__double_as_longlong(vguess) & 0x7fffffffffffffffull) > 0x7ff0000000000000ull);
@@ -349,12 +356,12 @@ __global__ void __launch_bounds__(256, 4) median9_classify_kernel(
         // before this tile's decisions are taken
         const bool had_values = loaded;
         loaded = false;
-        if (pid + step < n_tiles) {
+        if (pid + step < pend) {
             if (cold > 0) --cold;
             else { gather(D1, R1); loaded = true; }
         }
-        const int32_t R2 = pid + 2 * step < n_tiles ? load_ridx(D2) : -1;
-        const Where D3 = pid + 3 * step < n_tiles ? where(pid + 3 * step) : D2;
+        const int32_t R2 = pid + 2 * step < pend ? load_ridx(D2) : -1;
+        const Where D3 = pid + 3 * step < pend ? where(pid + 3 * step) : D2;
         // this lane's gene column: outputs of cells c0 + 8 wave + i, i = 0 .. 7
         const bool g_act = lane >= 4 && lane < 4 + K1G && gx < w.xdim;
         const bool g_int = g_act && gx >= 4 && gx < w.xdim - 4;
@@ -496,7 +503,9 @@ __global__ void __launch_bounds__(256, 4) median9_classify_kernel(
 __global__ void __launch_bounds__(MF_TG *MF_TC, 2) median_filter9_kernel(
     const double *__restrict__ in, double *__restrict__ out, int G, const int32_t *__restrict__ tile_idx,
     const int4 *__restrict__ gene_block_desc, const int4 *__restrict__ cell_patch_desc, int gene_blocks,
-    const uint8_t *__restrict__ dflag, int64_t n_tiles2) {
+    const uint8_t *__restrict__ dflag, int64_t n_tiles2, const int32_t *__restrict__ gate, int gate_cap) {
+    // (round 6) behind the strip kernel this launch is a fallback: it runs only if the strip kernel's queue overflowed
+    if (gate && *gate <= gate_cap) return;
     constexpr int h = 4;
     constexpr int PW = MF_TG + 2 * h;    // patch width (genes)
     constexpr int PH = MF9_TC + 2 * h;   // patch height (cells)
@@ -610,10 +619,394 @@ __global__ void __launch_bounds__(MF_TG *MF_TC, 2) median_filter9_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Kernel 2s (round 6): the STRIP form of the dense pass.  One wavefront slides down the cells of a (cell tile, chromosome)
+// block with one gene column per lane (64 output genes, the 4-gene halo on either side through a 72-wide row in LDS) and keeps
+// everything that neighbouring windows share in REGISTERS: every matrix row is sorted once (the lane's nine genes), rows are
+// merged in pairs once (used by four pair-windows), pairs in quads once (used by two), and a pair of outputs takes positions
+// 30..41 of its eight shared rows from two quads and finishes with its own ninth row -- 254 min/max per output instead of 427,
+// no barrier, no sorted columns in LDS.  Registers hold this only because the values are 32 bits wide: every element is a
+// COMPOUND KEY  (code << 8) | id:
+//   code  a monotone (non-decreasing) 24-bit code of the value: 2 q + 1 with q = the value's bucket of 2^23 - 1 linear buckets
+//         over the range the probe kernel sampled (saturating: anything outside, +-Inf and NaN land in the end buckets); the
+//         dominant value of the matrix, if there is one, has a code of its own (2 q_d + 1, its bucket's other values 2 q_d and
+//         2 q_d + 2), so that ties at that value -- 70 % of a denoised matrix -- are never ambiguous;
+//   id    (ring slot of the row, gene column mod 16): unique among the elements of a window; it makes the keys of a window
+//         distinct and says where the median's 64-bit value lies (rows are kept as doubles in a 16-row ring in LDS).
+// Exactness: the element at rank 40 of the window's sorted keys has 40 elements in front of it and 40 behind it.  If no other
+// element of the window carries its code, the 40 in front have smaller codes, hence strictly smaller values, the 40 behind
+// strictly greater ones: its value IS the median.  Equal codes are neighbours in the sorted order, so the test is
+// code(39) != code(40) != code(41) (that is why the networks deliver three ranks); the dominant value's own code passes by
+// construction (every element with that code has the same value); the end buckets never pass.  An output that fails the test
+// is queued for kernel 3 (a record like kernel 1's, one atomic each: ~1e-5 of the outputs on continuous data).  Data with many
+// repeated values that are not the dominant one would flood that queue: when it overflows, the fp64 dense pass
+// (median_filter9_kernel) runs over the same tiles behind this kernel and rewrites them -- a gated launch that otherwise
+// returns at once.  Only the choice of path depends on the data, never the result.
+constexpr int MS_SEG = 8;                         // dense-pass cell blocks (16 cells) per segment: a run is at most 128 output rows
+constexpr int MS_W = 72;                          // ring row: 64 genes + 2 x 4 halo
+constexpr int MS_RING = 12;                       // rows kept as doubles (a window and the rows in flight: 10)
+#ifndef MS_WAVES_PER_SIMD
+#define MS_WAVES_PER_SIMD 2
+#endif
+constexpr uint32_t MS_QMAX = (1u << 23) - 2u;     // last bucket; codes 0 .. 2 QMAX + 2 < 2^24
+
+constexpr int MS_NSP = 3;
+struct StripParams {        // written by median9_probe_kernel
+    double scale, lo_scaled;   // bucket q = sat_u32(fma(x, scale, lo_scaled))
+    double sp[MS_NSP];         // values that repeat (>= 1 % of the sample each, most frequent first): each gets a code of its own; sp[0] is the dominant value if has_dom
+    uint32_t has_dom, n_sp;
+};
+
+__device__ inline bool median9_has_dominant_value(const StripParams *P) { return P->has_dom != 0u; }
+
+__device__ __forceinline__ uint32_t ms_bucket(double x, double scale, double lo_scaled) {
+    const double t = __builtin_fma(x, scale, lo_scaled);
+    uint32_t q;
+    asm("v_cvt_u32_f64 %0, %1" : "=v"(q) : "v"(t));    // saturating; NaN -> 0
+    return q < MS_QMAX ? q : MS_QMAX;
+}
+
+// The probe (two small launches): 4 096 pseudo-random elements of the tiles' cells.
+//  (1) which values REPEAT: the first 512 samples are candidates; workgroup b of the first launch counts every sample against its
+//      sixteen candidates.  The second launch takes the three most frequent repeated values (a value that makes up 0.7 % of the
+//      matrix is among 512 candidates with probability 0.97; a miss costs time, never exactness) -- each gets a code of its own in
+//      the strip kernel; one that makes up a quarter of the sample is the DOMINANT value.  Without a dominant value the
+//      classification pass decides nothing and is told not to read the matrix at all (every tile goes to the dense pass, every border
+//      output to the queue).  More repeated values than three (discrete data): the strip kernel is told to leave the tiles to the
+//      fp64 dense pass (strip_ok = 0).
+//  (2) the range of the finite samples, for the linear buckets.
+constexpr int MP_SAMPLES = 4096, MP_CAND = 512, MP_WG = 32;     // candidates per workgroup: 16
+__device__ __forceinline__ double median9_probe_sample(const double *__restrict__ in, int G, const int32_t *__restrict__ tile_idx, int n_list, int i) {
+    // (two 32-bit hashes scaled into range by a high multiply: no division; 64 samples share a cell -- 64 x 64 elements: a random element
+    // of a 4 GB matrix is a page-table walk, 4 096 of them took 20-50 us)
+    uint32_t h1 = (uint32_t)(i >> 6) * 0x9E3779B9u + 0x7F4A7C15u, h2 = (uint32_t)i * 0x85EBCA6Bu + 0xC2B2AE35u;
+    h1 ^= h1 >> 15; h1 *= 0x2C1B3C6Du; h1 ^= h1 >> 12; h2 ^= h2 >> 13; h2 *= 0x297A2D39u; h2 ^= h2 >> 15;
+    const int e = (int)__umulhi(h1, (uint32_t)n_list), g = (int)__umulhi(h2, (uint32_t)G);
+    return in[(int64_t)tile_idx[e] * G + g];
+}
+struct ProbeScratch { int32_t count[MP_CAND]; double mn[MP_WG], mx[MP_WG]; };
+
+__global__ void __launch_bounds__(256) median9_probe_count_kernel(const double *__restrict__ in, int G, const int32_t *__restrict__ tile_idx,
+                                                                   int n_list, ProbeScratch *__restrict__ S) {
+    constexpr int CPW = MP_CAND / MP_WG, SPT = MP_SAMPLES / 256;
+    __shared__ unsigned long long cand[CPW];
+    __shared__ int cnt[CPW];
+    __shared__ double smin[4], smax[4];
+    const int tid = threadIdx.x;
+    unsigned long long v[SPT];
+    double mn = __builtin_inf(), mx = -__builtin_inf();
+#pragma unroll
+    for (int k = 0; k < SPT; ++k) {
+        const double x = median9_probe_sample(in, G, tile_idx, n_list, tid + 256 * k);
+        v[k] = (unsigned long long)__double_as_longlong(x);
+        const bool finite = (v[k] & 0x7ff0000000000000ull) != 0x7ff0000000000000ull;
+        if (finite) { mn = x < mn ? x : mn; mx = x > mx ? x : mx; }
+    }
+    if (tid < CPW) {
+        cand[tid] = (unsigned long long)__double_as_longlong(median9_probe_sample(in, G, tile_idx, n_list, (int)blockIdx.x * CPW + tid));
+        cnt[tid] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) {
+        const unsigned long long cj = cand[j];
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < SPT; ++k) n += v[k] == cj ? 1 : 0;
+        if (n) atomicAdd(&cnt[j], n);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double a = __shfl_xor(mn, o, 64), b = __shfl_xor(mx, o, 64);
+        mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+    }
+    if ((tid & 63) == 0) { smin[tid >> 6] = mn; smax[tid >> 6] = mx; }
+    __syncthreads();
+    if (tid < CPW) S->count[blockIdx.x * CPW + tid] = cnt[tid];
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) { mn = smin[w] < mn ? smin[w] : mn; mx = smax[w] > mx ? smax[w] : mx; }
+        S->mn[blockIdx.x] = mn; S->mx[blockIdx.x] = mx;      // (every workgroup saw all samples: the same numbers)
+    }
+}
+
+__global__ void __launch_bounds__(MP_CAND) median9_probe_finish_kernel(const double *__restrict__ in, int G, const int32_t *__restrict__ tile_idx,
+                                                                        int n_list, const ProbeScratch *__restrict__ S, StripParams *__restrict__ P) {
+    __shared__ unsigned long long key[MP_CAND];      // block arg-max of (count << 32 | candidate index)
+    __shared__ unsigned long long picked[MS_NSP];
+    __shared__ int picked_cnt[MS_NSP], others;
+    const int tid = threadIdx.x;
+    const unsigned long long mine = (unsigned long long)__double_as_longlong(median9_probe_sample(in, G, tile_idx, n_list, tid));
+    const int my_cnt = S->count[tid];
+    const bool is_nan = (mine & 0x7fffffffffffffffull) > 0x7ff0000000000000ull;
+    if (tid == 0) others = 0;
+    int n_sp = 0;
+    for (int k = 0; k < MS_NSP; ++k) {
+        bool taken = is_nan || my_cnt < 3;       // (a value seen three times in 4 096 samples repeats: continuous data does not)
+        for (int i = 0; i < n_sp; ++i) taken = taken || picked[i] == mine;
+        key[tid] = taken ? 0ull : (((unsigned long long)my_cnt << 32) | (unsigned long long)(MP_CAND - tid));
+        __syncthreads();
+        for (int o = MP_CAND / 2; o > 0; o >>= 1) {
+            if (tid < o) key[tid] = key[tid] > key[tid + o] ? key[tid] : key[tid + o];
+            __syncthreads();
+        }
+        const unsigned long long best = key[0];
+        __syncthreads();
+        if (best == 0ull) break;
+        if (tid == MP_CAND - (int)(best & 0xffffffffull)) { picked[k] = mine; picked_cnt[k] = my_cnt; }
+        ++n_sp;
+        __syncthreads();
+    }
+    // candidates that repeat and are none of the picked values: samples of the matrix's share of OTHER repeated values
+    {
+        bool other = !is_nan && my_cnt >= 3;
+        for (int i = 0; i < n_sp; ++i) other = other && picked[i] != mine;
+        if (other) atomicAdd(&others, 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double mn = S->mn[0], mx = S->mx[0];
+        double lo = mn, hi = mx;
+        if (!(lo <= hi)) { lo = 0.0; hi = 1.0; }                  // no finite sample
+        double range = hi - lo;
+        if (!(range > 0.0) || range > 1e300) range = 1.0;          // constant sample / overflow: any positive scale is correct
+        const double scale = (double)MS_QMAX / (range * 1.0625);   // 1/32 of the range spare on either side
+        StripParams p;
+        p.scale = scale;
+        p.lo_scaled = -(lo - range * 0.03125) * scale;
+        for (int k = 0; k < MS_NSP; ++k) p.sp[k] = k < n_sp ? __longlong_as_double((long long)picked[k]) : 0.0;
+        p.n_sp = (uint32_t)n_sp | (others * 50 > MP_CAND ? 0x100u : 0u);      // bit 8: more than 2 % of the matrix are further repeated values -- not the strip kernel's data
+        p.has_dom = (n_sp > 0 && picked_cnt[0] >= MP_SAMPLES / 4) ? 1u : 0u;
+        *P = p;
+    }
+}
+
+struct StripArgs {
+    const double *in;
+    double *out;
+    int G;
+    const int32_t *tile_idx;
+    const int4 *strip_desc;     // {chromosome's first gene, its length, strip's first gene (in the chromosome), dflag gene block of that gene}
+    const int4 *seg_desc;       // {offset of the cell tile's list, its length, segment's first cell, dflag cell block of that cell}
+    int n_strips;
+    int64_t n_units;            // n_strips x segments
+    const uint8_t *dflag;
+    int gene_blocks2;
+    const StripParams *P;
+    uint4 *fq;                  // outputs this kernel could not certify: {position in the tile list, absolute gene, clamp bits, 0}
+    int32_t *fq_count;
+    int fq_cap;
+    int32_t *unit_counter;      // zeroed before the launch
+};
+
+__global__ void __launch_bounds__(256, MS_WAVES_PER_SIMD) median9_strip_kernel(const StripArgs A) {
+    __shared__ double ring_all[4][MS_RING][MS_W];
+    __shared__ uint32_t keys_all[4][2][MS_W + 8];
+    __shared__ int32_t rcol_all[4][16];
+    __shared__ uint32_t park_all[4][5][9][64];     // the sorted second rows of the last five steps (each is an output's ninth row four steps later)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t (*park)[9][64] = park_all[wave];
+    double (*ring)[MS_W] = ring_all[wave];
+    uint32_t (*keys)[MS_W + 8] = keys_all[wave];
+    int32_t *rcol = rcol_all[wave];
+    const double scale = A.P->scale, lo_scaled = A.P->lo_scaled;
+    // the repeated values' buckets (0xffffffff: none -- also a second value in a bucket that is taken) and their own codes
+    // (scalars, not arrays: an array the compiler indexes at run time would live in scratch memory)
+    const uint32_t n_sp = A.P->n_sp & 0xffu;
+    if (A.P->n_sp & 0x100u) {       // discrete data (the probe): the gated fp64 dense pass takes the tiles
+        if (threadIdx.x == 0 && blockIdx.x == 0) *A.fq_count = 0x7fffffff;
+        return;
+    }
+    const double sv0 = A.P->sp[0], sv1 = A.P->sp[1], sv2 = A.P->sp[2];
+    const uint32_t sq0 = n_sp > 0u ? ms_bucket(sv0, scale, lo_scaled) : 0xffffffffu;
+    uint32_t sq1 = n_sp > 1u ? ms_bucket(sv1, scale, lo_scaled) : 0xffffffffu;
+    uint32_t sq2 = n_sp > 2u ? ms_bucket(sv2, scale, lo_scaled) : 0xffffffffu;
+    if (sq1 == sq0) sq1 = 0xffffffffu;
+    if (sq2 == sq0 || sq2 == sq1) sq2 = 0xffffffffu;
+    const uint32_t sc0 = 2u * sq0 + 1u, sc1 = 2u * sq1 + 1u, sc2 = 2u * sq2 + 1u;      // (none: 0xffffffff, never a 24-bit code)
+    auto make_key = [&](double x, int slot, int col) -> uint32_t {
+        const uint32_t q = ms_bucket(x, scale, lo_scaled);
+        uint32_t code = 2u * q + 1u;
+        if (q == sq0) code = x < sv0 ? 2u * q : (x == sv0 ? code : 2u * q + 2u);
+        if (q == sq1) code = x < sv1 ? 2u * q : (x == sv1 ? code : 2u * q + 2u);
+        if (q == sq2) code = x < sv2 ? 2u * q : (x == sv2 ? code : 2u * q + 2u);
+        return (code << 8) | ((uint32_t)slot << 4) | ((uint32_t)col & 15u);
+    };
+    // Units are handed out by a counter (the marked tiles cluster in a few chromosomes: dealt round-robin, 5 +- 2 of a wavefront's 32 units
+    // carried work and the launch waited for the unluckiest wavefront); the next unit's number is requested before this one is processed
+    auto next_unit = [&]() -> int64_t {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(A.unit_counter, 1);
+        return (int64_t)__builtin_amdgcn_readfirstlane(v);
+    };
+    int64_t u_next = next_unit();
+    for (;;) {
+        const int64_t u = u_next;
+        if (u >= A.n_units) break;
+        u_next = next_unit();
+        const int4 sd = A.strip_desc[u % A.n_strips], cd = A.seg_desc[u / A.n_strips];
+        const int cs = sd.x, xdim = sd.y, g0 = sd.z, kb = sd.w;
+        const int idx_off = cd.x, ydim = cd.y, c0 = cd.z, kc = cd.w;
+        // the marks of this unit's 8 cell blocks x 2 gene blocks (kernel 1 wrote them): bit 2 j + b
+        uint32_t fm;
+        {
+            const int j = lane >> 1, b = lane & 1;
+            const bool have = lane < 2 * MS_SEG && c0 + MEDIAN9_CELLS_PER_PATCH * j < ydim && g0 + MF_TG * b < xdim;
+            const uint8_t f = have ? A.dflag[(int64_t)(kc + j) * A.gene_blocks2 + kb + b] : (uint8_t)0;
+            fm = (uint32_t)__ballot(f != 0);
+        }
+        uint32_t pm = 0;     // bit j: cell block j has a marked tile
+#pragma unroll
+        for (int j = 0; j < MS_SEG; ++j) pm |= ((fm >> (2 * j)) & 3u) ? (1u << j) : 0u;
+        const int go = g0 + lane;                              // this lane's output gene (in the chromosome)
+        const bool lane_ok = go >= 4 && go < xdim - 4;         // interior outputs only (kernel 1 / 3 own the borders)
+        const int gl = g0 - 4 + lane, ge = g0 + 60 + lane;     // the genes this lane loads per row: column `lane`, and column 64 + lane (lanes 0 .. 7)
+        // (a row's address is a wave-uniform base -- the scalar unit's -- plus these 32-bit lane offsets)
+        const int off_l = cs + (gl < 0 ? 0 : (gl < xdim ? gl : xdim - 1));
+        const int off_e = cs + (ge < xdim ? ge : xdim - 1);
+        while (pm) {
+            const int j0 = __builtin_ctz(pm);
+            const int run = __builtin_ctz(~(pm >> j0));
+            pm &= ~(((1u << run) - 1u) << j0);
+            const int c_lo = c0 + MEDIAN9_CELLS_PER_PATCH * j0;
+            const int c_hi = c0 + MEDIAN9_CELLS_PER_PATCH * (j0 + run) < ydim ? c0 + MEDIAN9_CELLS_PER_PATCH * (j0 + run) : ydim;
+            const int o_lo = c_lo > 4 ? c_lo : 4, o_hi = c_hi < ydim - 4 ? c_hi : ydim - 4;     // output rows [o_lo, o_hi)
+            if (o_lo >= o_hi) continue;
+            const int r_first = o_lo - 4;                       // stream row j is the tile's cell r_first + j
+            const int n_stream = o_hi - o_lo + 8;               // <= 136
+            const int j_last = n_stream - 5;                    // last centre
+            int32_t rc0, rc1, rc2;                              // matrix column of stream row lane, 64 + lane, 128 + lane
+            {
+                const int a0 = r_first + lane, a1 = a0 + 64, a2 = a0 + 128;
+                rc0 = A.tile_idx[idx_off + (a0 < ydim ? a0 : ydim - 1)];
+                rc1 = A.tile_idx[idx_off + (a1 < ydim ? a1 : ydim - 1)];
+                rc2 = A.tile_idx[idx_off + (a2 < ydim ? a2 : ydim - 1)];
+            }
+            // (by-value captures: a closure of references turns the selection below into a selection of addresses in scratch memory)
+            auto row_col = [rc0, rc1, rc2, n_stream](int j) -> int32_t {              // (wave-uniform j)
+                const int jj = j < n_stream ? j : n_stream - 1;
+                const int32_t a = __builtin_amdgcn_readlane(rc0, jj & 63), b = __builtin_amdgcn_readlane(rc1, jj & 63), c = __builtin_amdgcn_readlane(rc2, jj & 63);
+                return jj < 64 ? a : (jj < 128 ? b : c);
+            };
+            // state carried from step to step (32-bit keys): the newest pair, two quads, the window, four second rows
+            uint32_t M1h[18], Q2[2][36], W[12];
+#pragma unroll
+            for (int i = 0; i < 18; ++i) M1h[i] = 0u;
+#pragma unroll
+            for (int i = 0; i < 36; ++i) { Q2[0][i] = 0u; Q2[1][i] = 0u; }
+#pragma unroll
+            for (int i = 0; i < 12; ++i) W[i] = 0u;
+            // rows of the first step
+            int32_t col_a = row_col(0), col_b = row_col(1);
+            const double *row_a = A.in + (int64_t)col_a * A.G, *row_b = A.in + (int64_t)col_b * A.G;
+            double xa = row_a[off_l], xb = row_b[off_l];
+            double ea = 0.0, eb = 0.0;
+            if (lane < 8) { ea = row_a[off_e]; eb = row_b[off_e]; }
+            int ring_slot = 0, park_slot = 0;
+            auto emit = [&](const uint32_t (&r)[3], int jc) {
+                if (jc < 4 || jc > j_last) return;              // (wave-uniform)
+                const int cy = r_first + jc;
+                const uint32_t bits = (fm >> (2 * ((cy - c0) >> 4))) & 3u;
+                if (!(lane_ok && ((bits >> (lane >> 5)) & 1u))) return;
+                const uint32_t code = r[1] >> 8;
+                const bool own_code = code == sc0 || code == sc1 || code == sc2;      // a repeated value's code: every element that carries it has that value
+                const bool amb = (((r[0] >> 8) == code || (r[2] >> 8) == code) && !own_code) || code < 3u || code >= 2u * MS_QMAX;
+                const int slot = (int)((r[1] >> 4) & 15u), col = lane + (int)(((r[1] & 15u) - (uint32_t)lane) & 15u);
+                const double v = ring[slot][col];
+                const int32_t ccol = rcol[jc & 15];
+                if (!amb) {
+                    A.out[(int64_t)ccol * A.G + cs + go] = v;
+                } else {
+                    // (one atomic per wavefront: the lanes' records lie behind each other)
+                    const unsigned long long m = __ballot(1);
+                    const int first = __builtin_ctzll(m);
+                    int at = 0;
+                    if (lane == first) at = atomicAdd(A.fq_count, __builtin_popcountll(m));
+                    at = __builtin_amdgcn_readlane(at, first) + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    if (at < A.fq_cap) A.fq[at] = make_uint4((unsigned int)(idx_off + cy), (unsigned int)(cs + go), 0x4444u, 0u);
+                }
+            };
+            auto step = [&](auto PHC, int p) {
+                constexpr int PH = decltype(PHC)::value;
+                const int ja = 2 * p, jb = 2 * p + 1;
+                const int sa = ring_slot, sb = ring_slot + 1;      // (stream row j lives in ring slot j mod 12)
+                ring_slot = ring_slot + 2 == MS_RING ? 0 : ring_slot + 2;
+                ring[sa][lane] = xa;
+                ring[sb][lane] = xb;
+                keys[0][lane] = make_key(xa, sa, lane);
+                keys[1][lane] = make_key(xb, sb, lane);
+                if (lane < 8) {
+                    ring[sa][64 + lane] = ea;
+                    ring[sb][64 + lane] = eb;
+                    keys[0][64 + lane] = make_key(ea, sa, 64 + lane);
+                    keys[1][64 + lane] = make_key(eb, sb, 64 + lane);
+                }
+                if (lane == 0) { rcol[ja & 15] = col_a; rcol[jb & 15] = col_b; }
+                // the next step's rows are requested now and land behind this step's networks
+                col_a = row_col(ja + 2);
+                col_b = row_col(jb + 2);
+                row_a = A.in + (int64_t)col_a * A.G;
+                row_b = A.in + (int64_t)col_b * A.G;
+                xa = row_a[off_l];
+                xb = row_b[off_l];
+                if (lane < 8) { ea = row_a[off_e]; eb = row_b[off_e]; }
+                __builtin_amdgcn_wave_barrier();
+                uint32_t Ta[9], Tn[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { Ta[k] = keys[0][lane + k]; Tn[k] = keys[1][lane + k]; }
+                __builtin_amdgcn_wave_barrier();
+                MS_SORT9(Ta);
+                MS_SORT9(Tn);
+                uint32_t r[3];
+                ms_finish(W, Ta, r);                 // the previous step's second output: centre 2 p - 4, its ninth row is this step's first
+                emit(r, 2 * p - 4);
+                uint32_t M1n[18], Qn[36];
+                __builtin_amdgcn_sched_barrier(0);
+                ms_merge9(Ta, Tn, M1n);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) park[park_slot][i][lane] = Tn[i];
+                park_slot = park_slot == 4 ? 0 : park_slot + 1;       // (now the slot of step p - 4)
+                __builtin_amdgcn_sched_barrier(0);
+                ms_merge18(M1h, M1n, Qn);            // rows 2 p - 2 .. 2 p + 1
+#pragma unroll
+                for (int i = 0; i < 18; ++i) M1h[i] = M1n[i];
+                __builtin_amdgcn_sched_barrier(0);
+                ms_window(Q2[PH & 1], Qn, W);        // rows 2 p - 6 .. 2 p + 1
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 36; ++i) Q2[PH & 1][i] = Qn[i];
+                uint32_t To[9];                       // the sorted row 2 p - 7 (second row of step p - 4): ninth row of this step's first output
+#pragma unroll
+                for (int i = 0; i < 9; ++i) To[i] = park[park_slot][i][lane];
+                ms_finish(W, To, r);                 // first output: centre 2 p - 3
+                emit(r, 2 * p - 3);
+            };
+            for (int p = 0;;) {
+                if (2 * p - 4 > j_last) break;
+                step(std::integral_constant<int, 0>{}, p); ++p;
+                if (2 * p - 4 > j_last) break;
+                step(std::integral_constant<int, 1>{}, p); ++p;
+                if (2 * p - 4 > j_last) break;
+                step(std::integral_constant<int, 2>{}, p); ++p;
+                if (2 * p - 4 > j_last) break;
+                step(std::integral_constant<int, 3>{}, p); ++p;
+            }
+        }
+    }
+}
+
 // Kernel 3: the queued outputs (one segment per workgroup of kernel 1), one per lane; then every output of the slow list's tiles.
 __global__ void __launch_bounds__(256, 2) median9_sparse_kernel(const double *__restrict__ in, double *__restrict__ out, int G,
                                                                  const int32_t *__restrict__ tile_idx, const int4 *__restrict__ gene1_desc,
-                                                                 const int4 *__restrict__ cell1_desc, int gene_blocks1, Median9Lists L) {
+                                                                 const int4 *__restrict__ cell1_desc, int gene_blocks1, Median9Lists L,
+                                                                 const uint4 *__restrict__ fq, const int32_t *__restrict__ fq_count, int fq_cap) {
+    if (fq) {   // the outputs the strip kernel could not certify (beyond the capacity: the gated dense pass has rewritten every tile)
+        const int nq = *fq_count == 0x7fffffff ? 0 : (*fq_count < fq_cap ? *fq_count : fq_cap);      // (0x7fffffff: the strip kernel did not run)
+        for (int i = (int)(blockIdx.x * 256 + threadIdx.x); i < nq; i += (int)gridDim.x * 256) {
+            const uint4 e = fq[i];
+            median9_general_output(in, out, G, tile_idx, (int)e.x, (int)e.y, e.z);
+        }
+    }
     // (block b starts with segment b and walks on: the segments are about equally long)
     for (int sgm = blockIdx.x; sgm < L.n_seg; sgm += gridDim.x) {
         const int n = L.qcount[sgm];
@@ -674,10 +1067,16 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
             const size_t b_list = ((size_t)grid1 * L.lcap * sizeof(int32_t) + 15) & ~(size_t)15;
             const size_t b_cnt = ((size_t)grid1 * sizeof(int32_t) + 15) & ~(size_t)15;
             const size_t b_flag = ((size_t)n_tiles2 + 15) & ~(size_t)15;
+            // (round 6) the strip form of the dense pass: the probe's result, the counter and the queue of its uncertified outputs
+            static const int strip_mode = std::getenv("ICNV_MF9_STRIP") ? std::atoi(std::getenv("ICNV_MF9_STRIP")) : 1;   // developer switch: 0 = the fp64 dense pass of rounds 2-5
+            const bool strip = strip_mode != 0 && plan9.n_strips > 0 && plan9.n_segs > 0;
+            int fq_cap = (int)std::min<int64_t>(std::max<int64_t>(n_tiles2 * (MF_TG * MF9_TC) / 64, 1 << 16), 1 << 22);
+            if (const char *e = std::getenv("ICNV_MF9_FQCAP")) fq_cap = std::max(0, std::atoi(e));   // developer / test switch: 0 sends every uncertified output's tile to the gated fp64 pass
+            const size_t b_probe = 64 + ((sizeof(ProbeScratch) + 63) & ~(size_t)63), b_fq = strip ? (size_t)fq_cap * sizeof(uint4) : 0;
             size_t b_queue = 0;
             for (;;) {   // a pool that cannot give the queue gets a shorter one: more tiles take the slow list, nothing fails
                 b_queue = (size_t)grid1 * L.qcap * sizeof(uint4);
-                const int rc = plan9.queue->alloc(b_queue + b_list + 2 * b_cnt + b_flag);
+                const int rc = plan9.queue->alloc(b_queue + b_list + 2 * b_cnt + b_flag + b_probe + b_fq);
                 if (!rc) break;
                 if (L.qcap <= 64) return rc;
                 L.qcap = std::max(64, L.qcap / 4);
@@ -687,23 +1086,54 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
             L.slow = reinterpret_cast<int32_t *>(base); base += b_list;
             L.qcount = reinterpret_cast<int32_t *>(base); base += b_cnt;
             L.scount = reinterpret_cast<int32_t *>(base); base += b_cnt;
-            L.dflag = reinterpret_cast<uint8_t *>(base);
-            ICNV_HIP(hipMemsetAsync(L.dflag, 0, b_flag, stream));
+            L.dflag = reinterpret_cast<uint8_t *>(base); base += b_flag;
+            StripParams *probe = reinterpret_cast<StripParams *>(base);
+            int32_t *fq_count = reinterpret_cast<int32_t *>(base + 48);
+            ProbeScratch *pscratch = reinterpret_cast<ProbeScratch *>(base + 64); base += b_probe;
+            uint4 *fq = strip ? reinterpret_cast<uint4 *>(base) : nullptr;
+            static_assert(sizeof(StripParams) <= 48 && MS_NSP == 3, "workspace layout");
+            ICNV_HIP(hipMemsetAsync(L.dflag, 0, b_flag + b_probe, stream));       // the marks and the strip kernel's counter
             const int4 *gd = reinterpret_cast<const int4 *>(plan9.gene_block_desc), *cd = reinterpret_cast<const int4 *>(plan9.cell_patch_desc);
             const int4 *g1 = reinterpret_cast<const int4 *>(plan9.gene1_desc), *c1 = reinterpret_cast<const int4 *>(plan9.cell1_desc);
+            static const int probe_mode = std::getenv("ICNV_MF9_PROBE") ? std::atoi(std::getenv("ICNV_MF9_PROBE")) : 1;           // developer switch: 0 = kernel 1 looks for a dominant value by itself, as in round 5
+            const bool probed = plan9.n_list > 0 && (strip || probe_mode != 0);
+            if (probed) {
+                hipLaunchKernelGGL(median9_probe_count_kernel, dim3(MP_WG), dim3(256), 0, stream, in, G, tile_idx_dev, plan9.n_list, pscratch);
+                hipLaunchKernelGGL(median9_probe_finish_kernel, dim3(1), dim3(MP_CAND), 0, stream, in, G, tile_idx_dev, plan9.n_list,
+                                   (const ProbeScratch *)pscratch, probe);
+            }
             hipLaunchKernelGGL(median9_classify_kernel, dim3((unsigned)grid1), dim3(256), 0, stream, in, out, G, tile_idx_dev, g1, c1,
-                               plan9.n_gene_blocks1, n_tiles9, plan9.n_gene_blocks, L, dev_mode);
+                               plan9.n_gene_blocks1, n_tiles9, plan9.n_gene_blocks, L, dev_mode,
+                               (probed && probe_mode != 0) ? (const StripParams *)probe : (const StripParams *)nullptr);
             const size_t lds = ((size_t)2 * (MF_TG + 8) * (MF9_TC + 8) + (size_t)(MF9_TC + 8) * MF_TG * 9) * sizeof(double) +
                                3 * (MF9_TC + 8) * sizeof(int32_t);
             static DeviceOnce once;
             if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(median_filter9_kernel), 80 * 1024, once)) return rc;
             int64_t grid2 = (int64_t)num_cus() * 2;   // two resident workgroups per CU (70 KB of LDS, 256 registers)
             if (grid2 > n_tiles2) grid2 = n_tiles2;
-            hipLaunchKernelGGL(median_filter9_kernel, dim3((unsigned)grid2), dim3(MF_TG * MF_TC), lds, stream, in, out, G, tile_idx_dev, gd, cd,
-                               plan9.n_gene_blocks, L.dflag, n_tiles2);
+            if (strip) {
+                StripArgs A;
+                A.in = in; A.out = out; A.G = G; A.tile_idx = tile_idx_dev;
+                A.strip_desc = reinterpret_cast<const int4 *>(plan9.strip_desc);
+                A.seg_desc = reinterpret_cast<const int4 *>(plan9.seg_desc);
+                A.n_strips = plan9.n_strips;
+                A.n_units = (int64_t)plan9.n_strips * plan9.n_segs;
+                A.dflag = L.dflag; A.gene_blocks2 = plan9.n_gene_blocks;
+                A.P = probe; A.fq = fq; A.fq_count = fq_count; A.fq_cap = fq_cap;
+                A.unit_counter = fq_count + 1;
+                int64_t grid2s = (int64_t)num_cus() * MS_WAVES_PER_SIMD;       // resident workgroups of four independent wavefronts
+                if (grid2s * 4 > A.n_units) grid2s = (A.n_units + 3) / 4;
+                hipLaunchKernelGGL(median9_strip_kernel, dim3((unsigned)grid2s), dim3(256), 0, stream, A);
+                // ... and the fp64 dense pass behind it, gated: it returns at once unless the strip kernel's queue overflowed
+                hipLaunchKernelGGL(median_filter9_kernel, dim3((unsigned)grid2), dim3(MF_TG * MF_TC), lds, stream, in, out, G, tile_idx_dev, gd, cd,
+                                   plan9.n_gene_blocks, L.dflag, n_tiles2, (const int32_t *)fq_count, fq_cap);
+            } else {
+                hipLaunchKernelGGL(median_filter9_kernel, dim3((unsigned)grid2), dim3(MF_TG * MF_TC), lds, stream, in, out, G, tile_idx_dev, gd, cd,
+                                   plan9.n_gene_blocks, L.dflag, n_tiles2, (const int32_t *)nullptr, 0);
+            }
             int64_t grid3 = std::min<int64_t>((int64_t)num_cus() * 4, grid1);
             hipLaunchKernelGGL(median9_sparse_kernel, dim3((unsigned)grid3), dim3(256), 0, stream, in, out, G, tile_idx_dev, g1, c1,
-                               plan9.n_gene_blocks1, L);
+                               plan9.n_gene_blocks1, L, (const uint4 *)fq, (const int32_t *)fq_count, fq_cap);
             if (std::getenv("ICNV_MF9_DEBUG")) {   // developer switch: how the tiles were split (synchronises)
                 std::vector<int32_t> cnt(2 * (b_cnt / sizeof(int32_t)));
                 std::vector<uint8_t> fl((size_t)n_tiles2);
@@ -714,8 +1144,15 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
                 const size_t stride = b_cnt / sizeof(int32_t);
                 for (int64_t i = 0; i < grid1; ++i) { q += cnt[i]; sl += cnt[stride + i]; }
                 for (uint8_t f : fl) d += f;
-                fprintf(stderr, "[median9] %lld tiles (56 x 32): %lld of %lld dense-pass tiles (32 x 16) marked, %lld slow, %lld queued outputs (qcap %d per segment, %lld segments)\n",
-                        (long long)n_tiles9, (long long)d, (long long)n_tiles2, (long long)sl, (long long)q, L.qcap, (long long)grid1);
+                int32_t nfq = 0;
+                StripParams hp;
+                (void)hipMemcpy(&nfq, fq_count, sizeof(nfq), hipMemcpyDeviceToHost);
+                (void)hipMemcpy(&hp, probe, sizeof(hp), hipMemcpyDeviceToHost);
+                fprintf(stderr, "[median9] %lld tiles (56 x 32): %lld of %lld dense-pass tiles (32 x 16) marked, %lld slow, %lld queued outputs (qcap %d per segment, %lld segments); "
+                        "strip %d: %d uncertified outputs (capacity %d), probe: dominant value %s (%.17g), scale %.6g\n",
+                        (long long)n_tiles9, (long long)d, (long long)n_tiles2, (long long)sl, (long long)q, L.qcap, (long long)grid1,
+                        (int)strip, (int)nfq, fq_cap, hp.has_dom ? "yes" : "no", hp.sp[0], hp.scale);
+                fprintf(stderr, "[median9] probe: %u repeated values (%s): %.17g %.17g %.17g\n", hp.n_sp & 0xffu, (hp.n_sp & 0x100u) ? "and many more: fp64 dense pass" : "strip kernel", hp.sp[0], hp.sp[1], hp.sp[2]);
             }
         }
     } else {
