@@ -807,6 +807,7 @@ __global__ void __launch_bounds__(256, MS_WAVES_PER_SIMD) median9_strip_kernel(c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t (*park)[9][64] = park_all[wave];
     double (*ring)[MS_W] = ring_all[wave];
+    const double *ring_flat = &ring_all[wave][0][0];
     uint32_t (*keys)[MS_W + 8] = keys_all[wave];
     int32_t *rcol = rcol_all[wave];
     const double scale = A.P->scale, lo_scaled = A.P->lo_scaled;
@@ -824,13 +825,14 @@ __global__ void __launch_bounds__(256, MS_WAVES_PER_SIMD) median9_strip_kernel(c
     if (sq1 == sq0) sq1 = 0xffffffffu;
     if (sq2 == sq0 || sq2 == sq1) sq2 = 0xffffffffu;
     const uint32_t sc0 = 2u * sq0 + 1u, sc1 = 2u * sq1 + 1u, sc2 = 2u * sq2 + 1u;      // (none: 0xffffffff, never a 24-bit code)
-    auto make_key = [&](double x, int slot, int col) -> uint32_t {
+    // (branch-free per lane; the number of repeated values is wave-uniform: data without any pays for none)
+    auto make_key = [&](double x, uint32_t id) -> uint32_t {
         const uint32_t q = ms_bucket(x, scale, lo_scaled);
         uint32_t code = 2u * q + 1u;
-        if (q == sq0) code = x < sv0 ? 2u * q : (x == sv0 ? code : 2u * q + 2u);
-        if (q == sq1) code = x < sv1 ? 2u * q : (x == sv1 ? code : 2u * q + 2u);
-        if (q == sq2) code = x < sv2 ? 2u * q : (x == sv2 ? code : 2u * q + 2u);
-        return (code << 8) | ((uint32_t)slot << 4) | ((uint32_t)col & 15u);
+        if (n_sp > 0u) code += (q == sq0) ? (uint32_t)((int)(x > sv0) - (int)(x < sv0)) : 0u;
+        if (n_sp > 1u) code += (q == sq1) ? (uint32_t)((int)(x > sv1) - (int)(x < sv1)) : 0u;
+        if (n_sp > 2u) code += (q == sq2) ? (uint32_t)((int)(x > sv2) - (int)(x < sv2)) : 0u;
+        return (code << 8) | id;
     };
     // Units are handed out by a counter (the marked tiles cluster in a few chromosomes: dealt round-robin, 5 +- 2 of a wavefront's 32 units
     // carried work and the launch waited for the unluckiest wavefront); the next unit's number is requested before this one is processed
@@ -863,7 +865,10 @@ __global__ void __launch_bounds__(256, MS_WAVES_PER_SIMD) median9_strip_kernel(c
         const int gl = g0 - 4 + lane, ge = g0 + 60 + lane;     // the genes this lane loads per row: column `lane`, and column 64 + lane (lanes 0 .. 7)
         // (a row's address is a wave-uniform base -- the scalar unit's -- plus these 32-bit lane offsets)
         const int off_l = cs + (gl < 0 ? 0 : (gl < xdim ? gl : xdim - 1));
-        const int off_e = cs + (ge < xdim ? ge : xdim - 1);
+        const int ge2 = g0 + 60 + (lane & 7);                  // (lanes 0 .. 7 and 8 .. 15: the genes of columns 64 .. 71)
+        const int off_e = cs + (ge2 < xdim ? ge2 : xdim - 1);
+        const int off_o = cs + go;
+        const uint32_t id_l = (uint32_t)lane & 15u;
         while (pm) {
             const int j0 = __builtin_ctz(pm);
             const int run = __builtin_ctz(~(pm >> j0));
@@ -900,30 +905,32 @@ __global__ void __launch_bounds__(256, MS_WAVES_PER_SIMD) median9_strip_kernel(c
             int32_t col_a = row_col(0), col_b = row_col(1);
             const double *row_a = A.in + (int64_t)col_a * A.G, *row_b = A.in + (int64_t)col_b * A.G;
             double xa = row_a[off_l], xb = row_b[off_l];
-            double ea = 0.0, eb = 0.0;
-            if (lane < 8) { ea = row_a[off_e]; eb = row_b[off_e]; }
+            double xe = 0.0;
+            if (lane < 16) xe = (lane < 8 ? row_a : row_b)[off_e];
             int ring_slot = 0, park_slot = 0;
             auto emit = [&](const uint32_t (&r)[3], int jc) {
                 if (jc < 4 || jc > j_last) return;              // (wave-uniform)
                 const int cy = r_first + jc;
-                const uint32_t bits = (fm >> (2 * ((cy - c0) >> 4))) & 3u;
-                if (!(lane_ok && ((bits >> (lane >> 5)) & 1u))) return;
+                const uint32_t bits = (fm >> (2 * ((cy - c0) >> 4))) & 3u;      // (wave-uniform: the marks of this row's two tiles)
+                const bool mine = lane_ok && ((bits >> (lane >> 5)) & 1u);
                 const uint32_t code = r[1] >> 8;
                 const bool own_code = code == sc0 || code == sc1 || code == sc2;      // a repeated value's code: every element that carries it has that value
                 const bool amb = (((r[0] >> 8) == code || (r[2] >> 8) == code) && !own_code) || code < 3u || code >= 2u * MS_QMAX;
-                const int slot = (int)((r[1] >> 4) & 15u), col = lane + (int)(((r[1] & 15u) - (uint32_t)lane) & 15u);
-                const double v = ring[slot][col];
-                const int32_t ccol = rcol[jc & 15];
-                if (!amb) {
-                    A.out[(int64_t)ccol * A.G + cs + go] = v;
-                } else {
-                    // (one atomic per wavefront: the lanes' records lie behind each other)
-                    const unsigned long long m = __ballot(1);
-                    const int first = __builtin_ctzll(m);
-                    int at = 0;
-                    if (lane == first) at = atomicAdd(A.fq_count, __builtin_popcountll(m));
-                    at = __builtin_amdgcn_readlane(at, first) + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-                    if (at < A.fq_cap) A.fq[at] = make_uint4((unsigned int)(idx_off + cy), (unsigned int)(cs + go), 0x4444u, 0u);
+                // the median's 64-bit value: ring slot and column of its id (the column is the one of lane .. lane + 8 with these low four bits)
+                const uint32_t col = (uint32_t)lane + ((r[1] - (uint32_t)lane) & 15u);
+                const double v = ring_flat[((r[1] >> 4) & 15u) * MS_W + col];
+                double *orow = A.out + (int64_t)rcol[jc & 15] * A.G;            // (wave-uniform)
+                if (mine && !amb) orow[off_o] = v;
+                if (__ballot(mine && amb)) {
+                    if (mine && amb) {
+                        // (one atomic per wavefront: the lanes' records lie behind each other)
+                        const unsigned long long m = __ballot(1);
+                        const int first = __builtin_ctzll(m);
+                        int at = 0;
+                        if (lane == first) at = atomicAdd(A.fq_count, __builtin_popcountll(m));
+                        at = __builtin_amdgcn_readlane(at, first) + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                        if (at < A.fq_cap) A.fq[at] = make_uint4((unsigned int)(idx_off + cy), (unsigned int)(cs + go), 0x4444u, 0u);
+                    }
                 }
             };
             auto step = [&](auto PHC, int p) {
@@ -933,13 +940,12 @@ __global__ void __launch_bounds__(256, MS_WAVES_PER_SIMD) median9_strip_kernel(c
                 ring_slot = ring_slot + 2 == MS_RING ? 0 : ring_slot + 2;
                 ring[sa][lane] = xa;
                 ring[sb][lane] = xb;
-                keys[0][lane] = make_key(xa, sa, lane);
-                keys[1][lane] = make_key(xb, sb, lane);
-                if (lane < 8) {
-                    ring[sa][64 + lane] = ea;
-                    ring[sb][64 + lane] = eb;
-                    keys[0][64 + lane] = make_key(ea, sa, 64 + lane);
-                    keys[1][64 + lane] = make_key(eb, sb, 64 + lane);
+                keys[0][lane] = make_key(xa, ((uint32_t)sa << 4) | id_l);
+                keys[1][lane] = make_key(xb, ((uint32_t)sb << 4) | id_l);
+                if (lane < 16) {                    // columns 64 .. 71: lanes 0 .. 7 hold row a's, lanes 8 .. 15 row b's
+                    const int se = lane < 8 ? sa : sb;
+                    ring[se][64 + (lane & 7)] = xe;
+                    keys[lane >> 3][64 + (lane & 7)] = make_key(xe, ((uint32_t)se << 4) | (uint32_t)(lane & 7));
                 }
                 if (lane == 0) { rcol[ja & 15] = col_a; rcol[jb & 15] = col_b; }
                 // the next step's rows are requested now and land behind this step's networks
@@ -949,7 +955,7 @@ __global__ void __launch_bounds__(256, MS_WAVES_PER_SIMD) median9_strip_kernel(c
                 row_b = A.in + (int64_t)col_b * A.G;
                 xa = row_a[off_l];
                 xb = row_b[off_l];
-                if (lane < 8) { ea = row_a[off_e]; eb = row_b[off_e]; }
+                if (lane < 16) xe = (lane < 8 ? row_a : row_b)[off_e];
                 __builtin_amdgcn_wave_barrier();
                 uint32_t Ta[9], Tn[9];
 #pragma unroll

@@ -317,6 +317,17 @@ def test_median_network_header_is_generated_and_verified():
     assert "up to date" in r.stdout
 
 
+def test_median_strip_network_header_is_generated_and_verified():
+    """median9_strip_net.h (round 6: the 32-bit min/max networks of the strip kernel -- sort9, 9 + 9, 18 + 18, the pruned 36 + 36 window and the
+    three-rank finish) is exactly what gen_median_strip_net.py writes; the generator checks every network on thousands of random inputs
+    with ties and the whole sliding schedule (rows -> pairs -> quads -> window -> ranks 39, 40, 41) against sorted windows."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "infercnv_amd", "csrc", "gen_median_strip_net.py"), "--check"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "up to date" in r.stdout
+
+
 def _build_shim_driver():
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
