@@ -2110,6 +2110,10 @@ int icnv_median_filter_dev(const double *expr_in, double *expr_out, int64_t G, i
             }
         }
     }
+    while (!c1desc.empty() && (c1desc.size() / 4) % MEDIAN9_K1_RUN != 0) {   // kernel 1 walks runs of MEDIAN9_K1_RUN cell blocks: pad with empty ones
+        const int32_t r1[4] = {0, 0, 0, 0};
+        c1desc.insert(c1desc.end(), r1, r1 + 4);
+    }
     DevBuf d_chr, d_idx, d_off, d_blk, d_gd, d_cd, d_g1, d_c1, d_sd, d_seg;
     if (!sdesc.empty() && (rc = upload(d_sd, sdesc.data(), sdesc.size(), s))) return rc;
     if (!segdesc.empty() && (rc = upload(d_seg, segdesc.data(), segdesc.size(), s))) return rc;

@@ -297,6 +297,7 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
                          int32_t window_size, const Median9Plan &plan9, hipStream_t stream);
 constexpr int MEDIAN_GENES_PER_PATCH = 32;
 constexpr int MEDIAN9_CELLS_PER_PATCH = 16;
+constexpr int MEDIAN9_K1_RUN = 1;            // kernel 1 walks runs of this many tiles down the cells: the host pads its cell blocks to a multiple
 constexpr int MEDIAN9_K1_GENES = 56, MEDIAN9_K1_CELLS = 32;   // kernel 1's tile: with the halo one tile row is the 64 lanes of a wavefront
 inline bool median_is_9x9(int32_t window_size) { return (window_size - 1) / 2 + 1 == 4; }
 constexpr int MEDIAN_CELLS_PER_PATCH = 8;   // generic kernel

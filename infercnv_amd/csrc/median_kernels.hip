@@ -244,6 +244,7 @@ constexpr int MF9_NT = MF_TG * MF_TC;
 
 struct StripParams;         // what the probe kernel found (defined with the strip kernel)
 __device__ inline bool median9_has_dominant_value(const StripParams *P);
+__device__ inline double median9_dominant_value(const StripParams *P);
 
 struct Median9Lists {       // per-workgroup segments of kernel 1's grid
     uint4 *queue;           // [n_seg][qcap] {p, a, clamp, 0}
@@ -266,7 +267,7 @@ __device__ inline unsigned int median9_clamp_bits(int gx, int xdim, int cy, int 
 // shifting.  Wavefront w reads rows 10 w .. 10 w + 9 of the tile's 40 and decides the outputs of cells 8 w .. 8 w + 7 (eight
 // per lane, one gene column: the counts of the window rows are computed once per row and slide down the column).
 // A tile covers 2 x 2 tiles of the dense pass (32 genes x 16 cells each): each of the four is classified on its own.
-constexpr int K1G = 56, K1C = 32, K1ROWS = K1C + 8, K1RPW = K1ROWS / 4, K1OPW = K1C / 4;
+constexpr int K1G = 56, K1C = 32, K1ROWS = K1C + 8, K1RPW = K1ROWS / 4, K1OPW = K1C / 4, K1RUN = MEDIAN9_K1_RUN;
 
 __global__ void __launch_bounds__(256, 4) median9_classify_kernel(
     const double *__restrict__ in, double *__restrict__ out, int G, const int32_t *__restrict__ tile_idx,
@@ -282,8 +283,16 @@ __global__ void __launch_bounds__(256, 4) median9_classify_kernel(
     uint4 *queue = L.queue + (int64_t)blockIdx.x * L.qcap;
     int32_t *slist = L.slow + (int64_t)blockIdx.x * L.lcap;
     int qn = 0, sn = 0;                  // entries of this workgroup's segments (the same numbers in every thread)
-    const int64_t step = gridDim.x, pend = n_tiles;
-    int64_t pid = blockIdx.x;
+    // Order of the tiles (round 6): a workgroup walks RUNS of K1RUN tiles down the cells of one gene block (run r = blockIdx + k gridDim: gene
+    // block r mod gene_blocks1, cell blocks K1RUN (r / gene_blocks1) ...), so that the eight halo rows it shares with the tile above are
+    // lines IT asked for one tile earlier -- L2 hits instead of a second trip to HBM (1.25 x the rows otherwise).  The host pads the
+    // cell blocks to a multiple of K1RUN with empty ones.  A tile's number stays cell block x gene_blocks1 + gene block.
+    const int64_t n_runs = (int64_t)gene_blocks1 * ((n_tiles / gene_blocks1) / K1RUN);
+    auto tile_at = [&](int s) -> int64_t {      // the s-th tile of this workgroup, -1: none
+        const int64_t r = (int64_t)blockIdx.x + (int64_t)(s / K1RUN) * gridDim.x;
+        if (r >= n_runs) return -1;
+        return ((r / gene_blocks1) * K1RUN + (s % K1RUN)) * gene_blocks1 + r % gene_blocks1;
+    };
     struct Where { int cs, xdim, g0, kb2, ydim, c0, idx_off, kc2; };
     auto where = [&](int64_t p) {
         const int4 gd = gene1_desc[p % gene_blocks1], cd = cell1_desc[p / gene_blocks1];
@@ -315,18 +324,25 @@ __global__ void __launch_bounds__(256, 4) median9_classify_kernel(
     // (round 6) a matrix in which the probe found no dominant value is not read at all: every tile goes to the dense pass, every border output to the queue
     int miss = 0, cold = ((dev_mode & 1) || (probe_result && !median9_has_dominant_value(probe_result))) ? 0x7fffffff : 0;
     bool loaded = false;                 // the current tile's values are in `stage`
-    if (pid >= pend) {
+    if (tile_at(0) < 0) {
         if (threadIdx.x == 0) { L.qcount[blockIdx.x] = 0; L.scount[blockIdx.x] = 0; }
         return;
     }
-    Where D0 = where(pid), D1 = D0, D2 = D0;
-    if (pid + step < pend) D1 = where(pid + step);
-    if (pid + 2 * step < pend) D2 = where(pid + 2 * step);
+    Where D0 = where(tile_at(0)), D1 = D0, D2 = D0;
+    if (tile_at(1) >= 0) D1 = where(tile_at(1));
+    if (tile_at(2) >= 0) D2 = where(tile_at(2));
     int32_t R0 = load_ridx(D0), R1 = load_ridx(D1);
     // first candidate: an element of the first tile (wave-uniform address); re-seeded below when it decides nothing
     vguess = in[(int64_t)tile_idx[D0.idx_off + (D0.c0 + 8 < D0.ydim ? D0.c0 + 8 : D0.c0)] * G + D0.cs + D0.g0];
+    // (round 6) with the probe's dominant value the candidate is that value for good: a run of tiles down an altered region decides nothing
+    // for many tiles in a row, which must neither re-seed the candidate nor stop the loads
+    const bool fixed_candidate = probe_result && median9_has_dominant_value(probe_result);
+    if (fixed_candidate) vguess = median9_dominant_value(probe_result);
     if (cold == 0) { gather(D0, R0); loaded = true; }
-    for (int it = 0; pid < pend; pid += step, ++it) {
+    for (int it = 0;; ++it) {
+        const int64_t pid = tile_at(it);
+        if (pid < 0) break;
+        const bool more1 = tile_at(it + 1) >= 0, more2 = tile_at(it + 2) >= 0;
         const Where w = D0;
         // (workgroup-uniform; a NaN candidate -- a probe can pick one up from the data -- decides nothing: tested on the bits)
         const bool test = loaded && !(((unsigned long long)__double_as_longlong(vguess) & 0x7fffffffffffffffull) > 0x7ff0000000000000ull);
@@ -356,12 +372,12 @@ __global__ void __launch_bounds__(256, 4) median9_classify_kernel(
         // before this tile's decisions are taken
         const bool had_values = loaded;
         loaded = false;
-        if (pid + step < pend) {
+        if (more1) {
             if (cold > 0) --cold;
             else { gather(D1, R1); loaded = true; }
         }
-        const int32_t R2 = pid + 2 * step < pend ? load_ridx(D2) : -1;
-        const Where D3 = pid + 3 * step < pend ? where(pid + 3 * step) : D2;
+        const int32_t R2 = more2 ? load_ridx(D2) : -1;
+        const Where D3 = tile_at(it + 3) >= 0 ? where(tile_at(it + 3)) : D2;
         // this lane's gene column: outputs of cells c0 + 8 wave + i, i = 0 .. 7
         const bool g_act = lane >= 4 && lane < 4 + K1G && gx < w.xdim;
         const bool g_int = g_act && gx >= 4 && gx < w.xdim - 4;
@@ -476,7 +492,7 @@ __global__ void __launch_bounds__(256, 4) median9_classify_kernel(
                 }
             }
         }
-        if (had_values) {
+        if (had_values && w.ydim > 0 && !fixed_candidate) {       // (an empty tile -- the padding of the runs -- says nothing about the candidate)
             if (any_maj) {
                 miss = 0;
             } else {
@@ -659,6 +675,7 @@ struct StripParams {        // written by median9_probe_kernel
 };
 
 __device__ inline bool median9_has_dominant_value(const StripParams *P) { return P->has_dom != 0u; }
+__device__ inline double median9_dominant_value(const StripParams *P) { return P->sp[0]; }
 
 __device__ __forceinline__ uint32_t ms_bucket(double x, double scale, double lo_scaled) {
     const double t = __builtin_fma(x, scale, lo_scaled);
@@ -1056,11 +1073,12 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
             if (n_tiles2 > 0x7fffffff) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "median filter: more than 2^31 tiles in one call");
             static const int dev_mode = std::getenv("ICNV_MF9_MODE") ? std::atoi(std::getenv("ICNV_MF9_MODE")) : 0;   // developer switch
             // kernel 1: four workgroups per CU (<= 128 registers; ten 8-byte loads in flight per lane), persistent; their list segments
+            const int64_t n_runs1 = n_tiles9 / K1RUN;      // (the host pads kernel 1's cell blocks to a multiple of K1RUN)
             int64_t grid1 = (int64_t)num_cus() * 4;
-            if (grid1 > n_tiles9) grid1 = n_tiles9;
+            if (grid1 > n_runs1) grid1 = n_runs1;
             Median9Lists L;
             L.n_seg = (int)grid1;
-            L.lcap = (int)(n_tiles9 / grid1 + 2);
+            L.lcap = (int)((n_runs1 / grid1 + 1) * K1RUN + 2);
             // queue of single outputs: sized for 5 % of a workgroup's outputs, at least two tiles' worth (a neutral region leaves
             // next to nothing undecided, the border outputs of undecided regions are ~3 % of those; a tile that does not fit goes to
             // the slow list as a whole, so the size is a performance knob, not a limit)
