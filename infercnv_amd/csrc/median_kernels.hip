@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256, 4) median9_classify_kernel(
     const int4 *__restrict__ gene1_desc /* {chromosome's first gene, its length, tile's first gene, index of the CHROMOSOME's first dense-pass gene block} */,
     const int4 *__restrict__ cell1_desc /* {offset of the cell tile's list, its length, tile's first cell, index of its first dense-pass cell block} */,
     int gene_blocks1, int64_t n_tiles, int gene_blocks2, Median9Lists L, int dev_mode /* developer switch: 1 no test, 2 no queue for interior outputs */,
-    const StripParams *__restrict__ probe_result /* nullable */) {
+    const StripParams *__restrict__ probe_result /* nullable */, int64_t n_flags /* entries of L.dflag; 0: no border kernel behind this launch */) {
     constexpr int NW = 4;
     __shared__ unsigned long long lessmask[2][K1ROWS], grtmask[2][K1ROWS];   // per tile row: bit l = the value at gene g0 - 4 + l lies below / above the candidate
     __shared__ unsigned int wcnt[2][NW];
@@ -324,6 +324,14 @@ __global__ void __launch_bounds__(256, 4) median9_classify_kernel(
     // (round 6) a matrix in which the probe found no dominant value is not read at all: every tile goes to the dense pass, every border output to the queue
     int miss = 0, cold = ((dev_mode & 1) || (probe_result && !median9_has_dominant_value(probe_result))) ? 0x7fffffff : 0;
     bool loaded = false;                 // the current tile's values are in `stage`
+    if (probe_result && !median9_has_dominant_value(probe_result) && n_flags > 0) {
+        // (round 6) no dominant value: nothing to classify.  Every tile of the dense pass is marked here and now (bytes of 1, this workgroup's share), the border
+        // outputs are computed by median9_border_kernel straight from the blocks' geometry: no queue, no walk over the tiles (0.9 -> 0.05 ms per 50 000 cells)
+        for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n_flags; i += (int64_t)gridDim.x * 1024)
+            *reinterpret_cast<uint32_t *>(L.dflag + i) = 0x01010101u;      // (the flag array is padded to 16 bytes)
+        if (threadIdx.x == 0) { L.qcount[blockIdx.x] = 0; L.scount[blockIdx.x] = 0; }
+        return;
+    }
     if (tile_at(0) < 0) {
         if (threadIdx.x == 0) { L.qcount[blockIdx.x] = 0; L.scount[blockIdx.x] = 0; }
         return;
@@ -1018,6 +1026,48 @@ __global__ void __launch_bounds__(256, MS_WAVES_PER_SIMD) median9_strip_kernel(c
     }
 }
 
+// Kernel 1b (round 6): the border outputs of EVERY (cell tile, chromosome) block, straight from the geometry -- the partner of kernel 1's early
+// exit when the probe finds no dominant value (gated: with a dominant value kernel 1 has queued the undecided border outputs and this launch
+// returns at once).  A cell within four rows of its tile's edge has all of its genes on the border (items of 256 genes: tile x 8 rows x
+// chunks), any other cell the first and last four genes of every chromosome (one item per cell); persistent workgroups stride over both lists.
+__global__ void __launch_bounds__(256, 2) median9_border_kernel(const double *__restrict__ in, double *__restrict__ out, int G, const int32_t *__restrict__ tile_idx,
+                                                                 const int32_t *__restrict__ tile_off, int n_tiles, const int32_t *__restrict__ chr_start, int n_chr,
+                                                                 const StripParams *__restrict__ probe_result) {
+    if (median9_has_dominant_value(probe_result)) return;
+    const int n_chunk = (G + 255) / 256;
+    const int64_t n_a = (int64_t)n_tiles * 8 * n_chunk;
+    for (int64_t i = blockIdx.x; i < n_a; i += gridDim.x) {
+        const int t = (int)(i / (8 * n_chunk)), r = (int)(i / n_chunk) % 8, a = (int)(i % n_chunk) * 256 + (int)threadIdx.x;
+        const int idx_off = tile_off[t], ydim = tile_off[t + 1] - idx_off;
+        const int cy = r < 4 ? r : ydim - 8 + r;         // rows 0 .. 3 and ydim - 4 .. ydim - 1, none twice
+        if (!(r < 4 ? cy < ydim : cy >= 4) || a >= G) continue;
+        int k = 0, kh = n_chr - 1;                       // the gene's chromosome
+        while (k < kh) {
+            const int mid = (k + kh + 1) >> 1;
+            if (chr_start[mid] <= a) k = mid; else kh = mid - 1;
+        }
+        const int cs = chr_start[k], xdim = chr_start[k + 1] - cs;
+        median9_general_output(in, out, G, tile_idx, idx_off + cy, a, median9_clamp_bits(a - cs, xdim, cy, ydim));
+    }
+    const int n_list = tile_off[n_tiles];
+    for (int e = blockIdx.x; e < n_list; e += gridDim.x) {
+        int lo = 0, hi = n_tiles - 1;                    // the cell's tile: the last one that starts at or before e
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tile_off[mid] <= e) lo = mid; else hi = mid - 1;
+        }
+        const int idx_off = tile_off[lo], ydim = tile_off[lo + 1] - idx_off, cy = e - idx_off;
+        if (cy < 4 || cy >= ydim - 4) continue;          // (a border row: done above)
+        for (int i = threadIdx.x; i < 8 * n_chr; i += 256) {
+            const int k = i >> 3, j = i & 7;
+            const int cs = chr_start[k], xdim = chr_start[k + 1] - cs;
+            const int gx = j < 4 ? j : xdim - 8 + j;     // genes 0 .. 3 and xdim - 4 .. xdim - 1, none twice
+            if (j < 4 ? gx < xdim : gx >= 4)
+                median9_general_output(in, out, G, tile_idx, e, cs + gx, median9_clamp_bits(gx, xdim, cy, ydim));
+        }
+    }
+}
+
 // Kernel 3: the queued outputs (one segment per workgroup of kernel 1), one per lane; then every output of the slow list's tiles.
 __global__ void __launch_bounds__(256, 2) median9_sparse_kernel(const double *__restrict__ in, double *__restrict__ out, int G,
                                                                  const int32_t *__restrict__ tile_idx, const int4 *__restrict__ gene1_desc,
@@ -1121,6 +1171,7 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
             const int4 *g1 = reinterpret_cast<const int4 *>(plan9.gene1_desc), *c1 = reinterpret_cast<const int4 *>(plan9.cell1_desc);
             static const int probe_mode = std::getenv("ICNV_MF9_PROBE") ? std::atoi(std::getenv("ICNV_MF9_PROBE")) : 1;           // developer switch: 0 = kernel 1 looks for a dominant value by itself, as in round 5
             const bool probed = plan9.n_list > 0 && (strip || probe_mode != 0);
+            static const int border_mode = std::getenv("ICNV_MF9_BORDER") ? std::atoi(std::getenv("ICNV_MF9_BORDER")) : 1;        // developer switch: 0 = without a dominant value kernel 1 still walks the tiles and queues the border outputs
             if (probed) {
                 hipLaunchKernelGGL(median9_probe_count_kernel, dim3(MP_WG), dim3(256), 0, stream, in, G, tile_idx_dev, plan9.n_list, pscratch);
                 hipLaunchKernelGGL(median9_probe_finish_kernel, dim3(1), dim3(MP_CAND), 0, stream, in, G, tile_idx_dev, plan9.n_list,
@@ -1128,7 +1179,11 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
             }
             hipLaunchKernelGGL(median9_classify_kernel, dim3((unsigned)grid1), dim3(256), 0, stream, in, out, G, tile_idx_dev, g1, c1,
                                plan9.n_gene_blocks1, n_tiles9, plan9.n_gene_blocks, L, dev_mode,
-                               (probed && probe_mode != 0) ? (const StripParams *)probe : (const StripParams *)nullptr);
+                               (probed && probe_mode != 0) ? (const StripParams *)probe : (const StripParams *)nullptr,
+                               (probed && probe_mode != 0 && border_mode != 0) ? (int64_t)b_flag : (int64_t)0);
+            if (probed && probe_mode != 0 && border_mode != 0)
+                hipLaunchKernelGGL(median9_border_kernel, dim3((unsigned)std::min<int64_t>((int64_t)num_cus() * 8, (int64_t)plan9.n_list)), dim3(256), 0, stream, in, out, G, tile_idx_dev, tile_off_dev, n_tiles,
+                                   chr_start_dev, n_chr, (const StripParams *)probe);
             const size_t lds = ((size_t)2 * (MF_TG + 8) * (MF9_TC + 8) + (size_t)(MF9_TC + 8) * MF_TG * 9) * sizeof(double) +
                                3 * (MF9_TC + 8) * sizeof(int32_t);
             static DeviceOnce once;

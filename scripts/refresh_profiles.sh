@@ -5,7 +5,7 @@
 # usage (on the GPU box):  ICNV_COMMIT=<short hash> bash scripts/refresh_profiles.sh r05
 #   (the box has no .git: the commit travels in the environment and is written into every summary)
 set -x
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
@@ -26,7 +26,7 @@ python $R/scripts/step_gaps.py $O/prof/${TAG}_results.db > $O/${TAG}_step_timeli
 rm -f $O/prof/*.db      # (gpurun merges at most 64 MiB back: the summaries travel, the raw traces do not)
 for c in 4 5; do
   timeout 300 python $R/bench.py --config $c --no-cpu-baseline > $O/bench_config$c.json 2> $O/bench_config$c.err
-  timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof -o ${TAG}_config$c -- python $R/bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-side-legs > /dev/null 2> $O/prof/log_config$c.txt
+  timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof -o ${TAG}_config$c -- python $R/bench.py --config $c --steps 20 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-side-legs > /dev/null 2> $O/prof/log_config$c.txt
   python $R/scripts/rocprof_summary.py $O/prof/${TAG}_config${c}_results.db > $O/${TAG}_kernel_stats_config$c.txt 2>&1
   rm -f $O/prof/*.db
 done
