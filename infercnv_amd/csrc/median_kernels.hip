@@ -1024,6 +1024,168 @@ __global__ void __launch_bounds__(256, MS_WAVES_PER_SIMD) median9_strip_kernel(c
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Kernel 1s (round 6): the classification pass as a SWEEP down the cells -- used whenever the probe ran (its dominant value is the
+// candidate; without one this launch marks every tile and returns, like kernel 1).  One wavefront, no workgroup: lane l holds gene
+// g0 - 4 + l of a 56-gene block (the same blocks as kernel 1's tiles) and walks down a segment of 128 cells.  Every matrix row is read
+// ONCE (kernel 1 reads 40 rows for 32: its tiles overlap by the halo), its two ballots are the row's masks, a lane's 9-bit popcounts of
+// the last nine rows live in registers and the window sums slide: no LDS, no barrier, ~45 vector instructions per row.  Decided
+// outputs are written at once; the undecided ones of a block of 16 cells are kept as bit masks until the block is complete -- then
+// its two 32-gene halves are counted (more than 128 undecided interior outputs: the dense pass takes the tile), the rest is queued
+// row by row in the wavefront's own segment (a block that does not fit puts its tile of kernel 1 on the slow list).  Same lists, same
+// meaning as kernel 1's: kernels 2 and 3 do not know which of the two ran.
+struct SweepArgs {
+    const double *in;
+    double *out;
+    int G;
+    const int32_t *tile_idx;
+    const int4 *gene1_desc;     // {chromosome's first gene, its length, block's first gene, index of the chromosome's first dense-pass gene block}
+    const int4 *seg_desc;       // {offset of the cell tile's list, its length, segment's first cell, dense-pass cell block of that cell}
+    int gene_blocks1, gene_blocks2;
+    int64_t n_units;            // gene_blocks1 x segments
+    Median9Lists L;             // segments per WAVEFRONT of this grid
+    int dev_mode;
+    const StripParams *P;
+    int64_t n_flags;
+};
+constexpr int SW_ROWS = MS_SEG * MF9_TC;      // cells per segment (the strip kernel's segments)
+
+__global__ void __launch_bounds__(256) median9_sweep_kernel(const SweepArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int sgm = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);      // this wavefront's segment of the lists
+    if (!median9_has_dominant_value(A.P)) {
+        for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < A.n_flags; i += (int64_t)gridDim.x * 1024)
+            *reinterpret_cast<uint32_t *>(A.L.dflag + i) = 0x01010101u;
+        if (lane == 0) { A.L.qcount[sgm] = 0; A.L.scount[sgm] = 0; }
+        return;
+    }
+    const double vg = median9_dominant_value(A.P);
+    uint4 *queue = A.L.queue + (int64_t)sgm * A.L.qcap;
+    int32_t *slist = A.L.slow + (int64_t)sgm * A.L.lcap;
+    int qn = 0, sn = 0;
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    constexpr unsigned long long HALF0 = 0x0000000FFFFFFFF0ull, HALF1 = 0x0FFFFFF000000000ull;      // lanes 4 .. 35 | 36 .. 59: the tile's two dense-pass gene blocks
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t u = sgm; u < A.n_units; u += n_waves) {
+        const int gb = (int)(u % A.gene_blocks1);
+        const int4 gd = A.gene1_desc[gb], sd = A.seg_desc[u / A.gene_blocks1];
+        const int cs = gd.x, xdim = gd.y, g0 = gd.z, kb2 = gd.w;
+        const int idx_off = sd.x, ydim = sd.y, c0 = sd.z, kc = sd.w;
+        const int n_out = (c0 + SW_ROWS < ydim ? c0 + SW_ROWS : ydim) - c0;       // outputs: cells c0 .. c0 + n_out - 1; stream row j is cell c0 - 4 + j
+        const int n_groups = (n_out + 8 + 8) / 9;                                 // groups of nine stream rows
+        const int gx = g0 - 4 + lane;
+        const bool gok = gx >= 0 && gx < xdim;
+        const bool g_act = lane >= 4 && lane < 4 + K1G && gx < xdim;
+        const bool g_int = g_act && gx >= 4 && gx < xdim - 4;
+        const int nx = (gx + 4 < xdim - 1 ? gx + 4 : xdim - 1) - (gx - 4 > 0 ? gx - 4 : 0) + 1;
+        const int sh = lane >= 4 ? lane - 4 : 0;
+        const int off = cs + (gx < 0 ? 0 : (gx < xdim ? gx : xdim - 1));
+        const int a_abs = cs + gx;
+        auto load_rc = [&](int g) -> int32_t {        // lane i < 9: the matrix column of stream row 9 g + i, -1 outside the tile
+            const int cy = c0 - 4 + 9 * g + lane;
+            return (lane < 9 && g < n_groups && cy >= 0 && cy < ydim) ? A.tile_idx[idx_off + cy] : -1;
+        };
+        double cur[9], nxt[9];
+        auto gather = [&](double (&v)[9], int32_t rc) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const int32_t row = __builtin_amdgcn_readlane(rc, i);
+                double x = 0.0;
+                if (row >= 0) x = (A.in + (int64_t)row * A.G)[off];
+                v[i] = x;
+            }
+        };
+        int32_t rc_prev = -1, rc_cur = load_rc(0), rc_nxt = load_rc(1);
+        gather(cur, rc_cur);
+        int hl[9], hg[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { hl[i] = 0; hg[i] = 0; }
+        int sl = 0, sg = 0;
+        // this lane's outputs of the current and the next block of 16 cells, undecided / interior (bit (c - c0) mod 32: a block is finished outside the
+        // unrolled rows, up to nine rows after its last one), and the undecided interior outputs of the two gene halves per block parity
+        uint32_t und32 = 0, inter32 = 0;
+        int n0e = 0, n1e = 0, n0o = 0, n1o = 0;
+        int next_blk = 0;
+        auto finish_block = [&](int kblk) {
+            const int par = kblk & 1;
+            const int n0 = par ? n0o : n0e, n1 = par ? n1o : n1e;
+            const uint32_t und16 = (und32 >> (16 * par)) & 0xFFFFu, inter16 = (inter32 >> (16 * par)) & 0xFFFFu;
+            const bool dense0 = n0 > MF9_SPARSE_T || ((A.dev_mode & 2) && n0 > 0), dense1 = n1 > MF9_SPARSE_T || ((A.dev_mode & 2) && n1 > 0);
+            const bool my_dense = lane >= 4 + MF_TG ? dense1 : dense0;
+            const uint32_t keep16 = und16 & ~(my_dense ? inter16 : 0u);      // a dense tile's interior outputs are all rewritten by the dense pass
+            int n_push = 0;
+#pragma unroll
+            for (int i = 0; i < MF9_TC; ++i) n_push += __builtin_popcountll(__ballot((keep16 >> i) & 1u));
+            if (n_push > 0) {
+                if (qn + n_push > A.L.qcap) {
+                    // the records do not fit this wavefront's segment: the tile of kernel 1 that holds the block is left to kernel 3 as a whole
+                    if (lane == 0 && sn < A.L.lcap) slist[sn] = (int32_t)((int64_t)((kc + kblk) >> 1) * A.gene_blocks1 + gb);
+                    ++sn;
+                } else {
+                    int at = qn;
+#pragma unroll
+                    for (int i = 0; i < MF9_TC; ++i) {
+                        const unsigned long long row = __ballot((keep16 >> i) & 1u);
+                        if ((keep16 >> i) & 1u) {
+                            const int cy = c0 + MF9_TC * kblk + i;
+                            queue[at + __builtin_popcountll(row & lower)] = make_uint4((unsigned int)(idx_off + cy), (unsigned int)a_abs, median9_clamp_bits(gx, xdim, cy, ydim), 0u);
+                        }
+                        at += __builtin_popcountll(row);
+                    }
+                    qn += n_push;
+                }
+            }
+            if (lane < 4 && (dense0 || dense1)) {
+                const int gh = lane >> 1, which = lane & 1;
+                const int lo = g0 + MF_TG * gh, hi = (lo + (gh ? K1G - MF_TG : MF_TG) < xdim ? lo + (gh ? K1G - MF_TG : MF_TG) : xdim) - 1;
+                if ((gh ? dense1 : dense0) && lo <= hi) A.L.dflag[(int64_t)(kc + kblk) * A.gene_blocks2 + (kb2 + (which ? hi / MF_TG : lo / MF_TG))] = 1;
+            }
+            und32 &= ~(0xFFFFu << (16 * par));
+            inter32 &= ~(0xFFFFu << (16 * par));
+            if (par) { n0o = 0; n1o = 0; } else { n0e = 0; n1e = 0; }
+        };
+        for (int g = 0; g < n_groups; ++g) {
+            const int32_t rc_nn = load_rc(g + 2);
+            if (g + 1 < n_groups) gather(nxt, rc_nxt);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const int j = 9 * g + i, cyr = c0 - 4 + j;
+                const bool ok = gok && cyr >= 0 && cyr < ydim && !(A.dev_mode & 1);
+                const double x = cur[i];
+                const bool is_nan = ((unsigned long long)__double_as_longlong(x) & 0x7fffffffffffffffull) > 0x7ff0000000000000ull;
+                const unsigned long long ml = __ballot(ok && (x < vg || is_nan)), mg = __ballot(ok && (x > vg || is_nan));
+                const int nl = __builtin_popcount((unsigned int)(ml >> sh) & 0x1FFu), ng = __builtin_popcount((unsigned int)(mg >> sh) & 0x1FFu);
+                sl += nl - hl[i]; hl[i] = nl;
+                sg += ng - hg[i]; hg[i] = ng;
+                const int c = cyr - 4;                       // the output whose window this row completes
+                if (j >= 8 && c < c0 + n_out) {              // (wave-uniform)
+                    const int ny = (c + 4 < ydim - 1 ? c + 4 : ydim - 1) - (c - 4 > 0 ? c - 4 : 0) + 1;
+                    const bool dec = !(A.dev_mode & 1) && 2 * sl < nx * ny && 2 * sg < nx * ny;
+                    const int32_t ccol = i >= 4 ? __builtin_amdgcn_readlane(rc_cur, i >= 4 ? i - 4 : 0) : __builtin_amdgcn_readlane(rc_prev, i < 4 ? i + 5 : 0);
+                    if (g_act && dec) (A.out + (int64_t)ccol * A.G)[a_abs] = vg;
+                    const bool und = g_act && !dec, inter = g_int && c >= 4 && c < ydim - 4;
+                    const int bi = (c - c0) & 31;
+                    und32 |= (und ? 1u : 0u) << bi;
+                    inter32 |= (inter ? 1u : 0u) << bi;
+                    const unsigned long long ub = __ballot(und && inter);
+                    const int u0 = __builtin_popcountll(ub & HALF0), u1 = __builtin_popcountll(ub & HALF1);
+                    if (bi & 16) { n0o += u0; n1o += u1; } else { n0e += u0; n1e += u1; }
+                }
+            }
+            // blocks whose last output lies behind us (one per group at most, two at the end of the unit)
+            {
+                const int done = 9 * g + 8 - 8 < n_out - 1 ? 9 * g + 8 - 8 : n_out - 1;      // outputs c0 .. c0 + done are complete (done < 0: none yet)
+                while (next_blk * MF9_TC <= done && (next_blk * MF9_TC + MF9_TC - 1 <= done || done == n_out - 1)) finish_block(next_blk++);
+            }
+            rc_prev = rc_cur; rc_cur = rc_nxt; rc_nxt = rc_nn;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) cur[i] = nxt[i];
+        }
+    }
+    if (lane == 0) { A.L.qcount[sgm] = qn; A.L.scount[sgm] = sn < A.L.lcap ? sn : A.L.lcap; }
+}
+
 // Kernel 1b (round 6): the border outputs of EVERY (cell tile, chromosome) block, straight from the geometry -- the partner of kernel 1's early
 // exit when the probe finds no dominant value (gated: with a dominant value kernel 1 has queued the undecided border outputs and this launch
 // returns at once).  A cell within four rows of its tile's edge has all of its genes on the border (items of 256 genes: tile x 8 rows x
@@ -1120,6 +1282,13 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
             static_assert(K1G == MEDIAN9_K1_GENES && K1C == MEDIAN9_K1_CELLS && K1G + 8 == 64 && K1C == 2 * MF9_TC && K1G <= 2 * MF_TG, "host tables");
             if (n_tiles2 > 0x7fffffff) ICNV_FAIL(ICNV_ERR_UNSUPPORTED, "median filter: more than 2^31 tiles in one call");
             static const int dev_mode = std::getenv("ICNV_MF9_MODE") ? std::atoi(std::getenv("ICNV_MF9_MODE")) : 0;   // developer switch
+            static const int strip_mode = std::getenv("ICNV_MF9_STRIP") ? std::atoi(std::getenv("ICNV_MF9_STRIP")) : 1;   // developer switch: 0 = the fp64 dense pass of rounds 2-5
+            static const int probe_mode = std::getenv("ICNV_MF9_PROBE") ? std::atoi(std::getenv("ICNV_MF9_PROBE")) : 1;   // developer switch: 0 = kernel 1 looks for a dominant value by itself, as in round 5
+            static const int sweep_mode = std::getenv("ICNV_MF9_SWEEP") ? std::atoi(std::getenv("ICNV_MF9_SWEEP")) : 1;   // developer switch: 0 = kernel 1 (tiles of 56 x 32, four wavefronts each) also when the probe ran
+            const bool strip = strip_mode != 0 && plan9.n_strips > 0 && plan9.n_segs > 0;
+            const bool probed = plan9.n_list > 0 && (strip || probe_mode != 0);
+            static const int border_mode = std::getenv("ICNV_MF9_BORDER") ? std::atoi(std::getenv("ICNV_MF9_BORDER")) : 1;   // developer switch: 0 = without a dominant value kernel 1 still walks the tiles and queues the border outputs
+            const bool sweep = probed && probe_mode != 0 && sweep_mode != 0 && border_mode != 0 && plan9.n_segs > 0;
             // kernel 1: four workgroups per CU (<= 128 registers; ten 8-byte loads in flight per lane), persistent; their list segments
             const int64_t n_runs1 = n_tiles9 / K1RUN;      // (the host pads kernel 1's cell blocks to a multiple of K1RUN)
             int64_t grid1 = (int64_t)num_cus() * 4;
@@ -1127,6 +1296,15 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
             Median9Lists L;
             L.n_seg = (int)grid1;
             L.lcap = (int)((n_runs1 / grid1 + 1) * K1RUN + 2);
+            // kernel 1s (the sweep): one list segment per WAVEFRONT, units (56 genes x 128 cells) dealt round-robin -- a wavefront's slow list can hold every block it may meet
+            const int64_t n_units_s = (int64_t)plan9.n_gene_blocks1 * plan9.n_segs;
+            int64_t grid_s = (int64_t)num_cus() * 6;
+            if (grid_s * 4 > n_units_s) grid_s = (n_units_s + 3) / 4;
+            if (sweep) {
+                L.n_seg = (int)(grid_s * 4);
+                L.lcap = (int)((n_units_s / L.n_seg + 1) * MS_SEG + 2);
+                grid1 = L.n_seg;      // (the sizes below are per segment)
+            }
             // queue of single outputs: sized for 5 % of a workgroup's outputs, at least two tiles' worth (a neutral region leaves
             // next to nothing undecided, the border outputs of undecided regions are ~3 % of those; a tile that does not fit goes to
             // the slow list as a whole, so the size is a performance knob, not a limit)
@@ -1140,8 +1318,6 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
             const size_t b_cnt = ((size_t)grid1 * sizeof(int32_t) + 15) & ~(size_t)15;
             const size_t b_flag = ((size_t)n_tiles2 + 15) & ~(size_t)15;
             // (round 6) the strip form of the dense pass: the probe's result, the counter and the queue of its uncertified outputs
-            static const int strip_mode = std::getenv("ICNV_MF9_STRIP") ? std::atoi(std::getenv("ICNV_MF9_STRIP")) : 1;   // developer switch: 0 = the fp64 dense pass of rounds 2-5
-            const bool strip = strip_mode != 0 && plan9.n_strips > 0 && plan9.n_segs > 0;
             int fq_cap = (int)std::min<int64_t>(std::max<int64_t>(n_tiles2 * (MF_TG * MF9_TC) / 64, 1 << 16), 1 << 22);
             if (const char *e = std::getenv("ICNV_MF9_FQCAP")) fq_cap = std::max(0, std::atoi(e));   // developer / test switch: 0 sends every uncertified output's tile to the gated fp64 pass
             const size_t b_probe = 64 + ((sizeof(ProbeScratch) + 63) & ~(size_t)63), b_fq = strip ? (size_t)fq_cap * sizeof(uint4) : 0;
@@ -1167,18 +1343,25 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
             ICNV_HIP(hipMemsetAsync(L.dflag, 0, b_flag + b_probe, stream));       // the marks and the strip kernel's counter
             const int4 *gd = reinterpret_cast<const int4 *>(plan9.gene_block_desc), *cd = reinterpret_cast<const int4 *>(plan9.cell_patch_desc);
             const int4 *g1 = reinterpret_cast<const int4 *>(plan9.gene1_desc), *c1 = reinterpret_cast<const int4 *>(plan9.cell1_desc);
-            static const int probe_mode = std::getenv("ICNV_MF9_PROBE") ? std::atoi(std::getenv("ICNV_MF9_PROBE")) : 1;           // developer switch: 0 = kernel 1 looks for a dominant value by itself, as in round 5
-            const bool probed = plan9.n_list > 0 && (strip || probe_mode != 0);
-            static const int border_mode = std::getenv("ICNV_MF9_BORDER") ? std::atoi(std::getenv("ICNV_MF9_BORDER")) : 1;        // developer switch: 0 = without a dominant value kernel 1 still walks the tiles and queues the border outputs
             if (probed) {
                 hipLaunchKernelGGL(median9_probe_count_kernel, dim3(MP_WG), dim3(256), 0, stream, in, G, tile_idx_dev, plan9.n_list, pscratch);
                 hipLaunchKernelGGL(median9_probe_finish_kernel, dim3(1), dim3(MP_CAND), 0, stream, in, G, tile_idx_dev, plan9.n_list,
                                    (const ProbeScratch *)pscratch, probe);
             }
-            hipLaunchKernelGGL(median9_classify_kernel, dim3((unsigned)grid1), dim3(256), 0, stream, in, out, G, tile_idx_dev, g1, c1,
-                               plan9.n_gene_blocks1, n_tiles9, plan9.n_gene_blocks, L, dev_mode,
-                               (probed && probe_mode != 0) ? (const StripParams *)probe : (const StripParams *)nullptr,
-                               (probed && probe_mode != 0 && border_mode != 0) ? (int64_t)b_flag : (int64_t)0);
+            if (sweep) {
+                SweepArgs S;
+                S.in = in; S.out = out; S.G = G; S.tile_idx = tile_idx_dev;
+                S.gene1_desc = g1; S.seg_desc = reinterpret_cast<const int4 *>(plan9.seg_desc);
+                S.gene_blocks1 = plan9.n_gene_blocks1; S.gene_blocks2 = plan9.n_gene_blocks;
+                S.n_units = n_units_s; S.L = L; S.dev_mode = dev_mode; S.P = probe;
+                S.n_flags = (int64_t)b_flag;
+                hipLaunchKernelGGL(median9_sweep_kernel, dim3((unsigned)grid_s), dim3(256), 0, stream, S);
+            } else {
+                hipLaunchKernelGGL(median9_classify_kernel, dim3((unsigned)grid1), dim3(256), 0, stream, in, out, G, tile_idx_dev, g1, c1,
+                                   plan9.n_gene_blocks1, n_tiles9, plan9.n_gene_blocks, L, dev_mode,
+                                   (probed && probe_mode != 0) ? (const StripParams *)probe : (const StripParams *)nullptr,
+                                   (probed && probe_mode != 0 && border_mode != 0) ? (int64_t)b_flag : (int64_t)0);
+            }
             if (probed && probe_mode != 0 && border_mode != 0)
                 hipLaunchKernelGGL(median9_border_kernel, dim3((unsigned)std::min<int64_t>((int64_t)num_cus() * 8, (int64_t)plan9.n_list)), dim3(256), 0, stream, in, out, G, tile_idx_dev, tile_off_dev, n_tiles,
                                    chr_start_dev, n_chr, (const StripParams *)probe);
