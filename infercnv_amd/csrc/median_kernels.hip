@@ -943,7 +943,7 @@ __global__ void __launch_bounds__(256, MS_WAVES_PER_SIMD) median9_strip_kernel(c
                 const uint32_t col = (uint32_t)lane + ((r[1] - (uint32_t)lane) & 15u);
                 const double v = ring_flat[((r[1] >> 4) & 15u) * MS_W + col];
                 double *orow = A.out + (int64_t)rcol[jc & 15] * A.G;            // (wave-uniform)
-                if (mine && !amb) orow[off_o] = v;
+                if (mine && !amb) __builtin_nontemporal_store(v, orow + off_o);
                 if (__ballot(mine && amb)) {
                     if (mine && amb) {
                         // (one atomic per wavefront: the lanes' records lie behind each other)
@@ -1163,7 +1163,7 @@ __global__ void __launch_bounds__(256) median9_sweep_kernel(const SweepArgs A) {
                     const int ny = (c + 4 < ydim - 1 ? c + 4 : ydim - 1) - (c - 4 > 0 ? c - 4 : 0) + 1;
                     const bool dec = !(A.dev_mode & 1) && 2 * sl < nx * ny && 2 * sg < nx * ny;
                     const int32_t ccol = i >= 4 ? __builtin_amdgcn_readlane(rc_cur, i >= 4 ? i - 4 : 0) : __builtin_amdgcn_readlane(rc_prev, i < 4 ? i + 5 : 0);
-                    if (g_act && dec) (A.out + (int64_t)ccol * A.G)[a_abs] = vg;
+                    if (g_act && dec) __builtin_nontemporal_store(vg, (A.out + (int64_t)ccol * A.G) + a_abs);      // (written once, read by nobody in this call)
                     const bool und = g_act && !dec, inter = g_int && c >= 4 && c < ydim - 4;
                     const int bi = (c - c0) & 31;
                     und32 |= (und ? 1u : 0u) << bi;
