@@ -2076,7 +2076,7 @@ int icnv_median_filter_dev(const double *expr_in, double *expr_out, int64_t G, i
     // Kernel 1 cuts every (cell tile, chromosome) block into tiles of 56 genes x 32 cells from its first gene / cell, borders
     // included; the dense pass has its own grid of 32 genes x 16 cells over the same blocks (a tile of kernel 1 covers two of
     // its cell blocks exactly and two or three of its gene blocks).
-    std::vector<int32_t> gdesc, cdesc, g1desc, c1desc, sdesc, segdesc;
+    std::vector<int32_t> gdesc, cdesc, g1desc, c1desc, sdesc, segdesc, sw1desc, sw2desc;
     if (median_is_9x9(window_size)) {
         for (int k = 0; k < n_chr; ++k) {
             const int32_t cs = chr_start[k], xdim = chr_start[k + 1] - chr_start[k];
@@ -2089,9 +2089,17 @@ int icnv_median_filter_dev(const double *expr_in, double *expr_out, int64_t G, i
                 const int32_t r[4] = {cs, xdim, g0, std::min(g0 + MEDIAN_GENES_PER_PATCH, xdim - 4)};
                 gdesc.insert(gdesc.end(), r, r + 4);
             }
+            const int32_t kb1 = (int32_t)(g1desc.size() / 4);   // the chromosome's first gene block of kernel 1
             for (int g0 = 0; g0 < xdim; g0 += MEDIAN9_K1_GENES) {
                 const int32_t r1[4] = {cs, xdim, g0, kb2};
                 g1desc.insert(g1desc.end(), r1, r1 + 4);
+            }
+            for (int nh = 1; nh <= 2; ++nh) {                   // the sweep's gene blocks: 56 genes (one 64-gene row per wavefront) and 120 (two)
+                std::vector<int32_t> &sw = nh == 1 ? sw1desc : sw2desc;
+                for (int g0 = 0; g0 < xdim; g0 += 64 * nh - 8) {
+                    const int32_t r[8] = {cs, xdim, g0, kb2, kb1, 0, 0, 0};
+                    sw.insert(sw.end(), r, r + 8);
+                }
             }
         }
         for (int t = 0; t < n_tiles; ++t) {
@@ -2114,7 +2122,9 @@ int icnv_median_filter_dev(const double *expr_in, double *expr_out, int64_t G, i
         const int32_t r1[4] = {0, 0, 0, 0};
         c1desc.insert(c1desc.end(), r1, r1 + 4);
     }
-    DevBuf d_chr, d_idx, d_off, d_blk, d_gd, d_cd, d_g1, d_c1, d_sd, d_seg;
+    DevBuf d_chr, d_idx, d_off, d_blk, d_gd, d_cd, d_g1, d_c1, d_sd, d_seg, d_sw1, d_sw2;
+    if (!sw1desc.empty() && (rc = upload(d_sw1, sw1desc.data(), sw1desc.size(), s))) return rc;
+    if (!sw2desc.empty() && (rc = upload(d_sw2, sw2desc.data(), sw2desc.size(), s))) return rc;
     if (!sdesc.empty() && (rc = upload(d_sd, sdesc.data(), sdesc.size(), s))) return rc;
     if (!segdesc.empty() && (rc = upload(d_seg, segdesc.data(), segdesc.size(), s))) return rc;
     if (!gdesc.empty() && (rc = upload(d_gd, gdesc.data(), gdesc.size(), s))) return rc;
@@ -2141,6 +2151,10 @@ int icnv_median_filter_dev(const double *expr_in, double *expr_out, int64_t G, i
     plan9.n_strips = (int32_t)(sdesc.size() / 4);
     plan9.n_segs = (int32_t)(segdesc.size() / 4);
     plan9.n_list = tile_off[n_tiles];
+    plan9.sweep_desc1 = d_sw1.as<int32_t>();
+    plan9.sweep_desc2 = d_sw2.as<int32_t>();
+    plan9.n_sweep_blocks1 = (int32_t)(sw1desc.size() / 8);
+    plan9.n_sweep_blocks2 = (int32_t)(sw2desc.size() / 8);
     return launch_median_filter(expr_in, expr_out, (int32_t)G, C, d_chr.as<int32_t>(), n_chr, d_idx.as<int32_t>(),
                                 d_off.as<int32_t>(), n_tiles, d_blk.as<int32_t>(), chr_start, blk_off[n_tiles],
                                 window_size, plan9, s);

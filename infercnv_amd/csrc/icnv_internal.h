@@ -289,6 +289,10 @@ struct Median9Plan {
     const int32_t *seg_desc = nullptr;          // 4 ints: {offset of the tile's cells, tile length, segment's first cell, index of that cell's dense-pass cell block}
     int32_t n_strips = 0, n_segs = 0;
     int32_t n_list = 0;                         // entries of the tiles' cell lists (the probe samples them)
+    // the sweep form of the classification pass (round 6): gene blocks of 56 / 120 genes, two records of 4 ints each:
+    // {chromosome's first gene, its length, block's first gene, index of the chromosome's first dense-pass gene block}, {index of the chromosome's first gene block of kernel 1, 0, 0, 0}
+    const int32_t *sweep_desc1 = nullptr, *sweep_desc2 = nullptr;
+    int32_t n_sweep_blocks1 = 0, n_sweep_blocks2 = 0;
     DevBuf *queue = nullptr;                    // workspace of the three-kernel scheme's lists (allocated by the launch, owned by the caller)
 };
 int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, const int32_t *chr_start_dev,

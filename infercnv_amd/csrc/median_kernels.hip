@@ -1040,10 +1040,11 @@ struct SweepArgs {
     double *out;
     int G;
     const int32_t *tile_idx;
-    const int4 *gene1_desc;     // {chromosome's first gene, its length, block's first gene, index of the chromosome's first dense-pass gene block}
+    const int4 *gene_desc;      // per gene block of the sweep, two records: {chromosome's first gene, its length, block's first gene, index of the chromosome's first dense-pass gene block},
+                                //                                           {index of the chromosome's first gene block of kernel 1 (the slow list names ITS tiles), 0, 0, 0}
     const int4 *seg_desc;       // {offset of the cell tile's list, its length, segment's first cell, dense-pass cell block of that cell}
-    int gene_blocks1, gene_blocks2;
-    int64_t n_units;            // gene_blocks1 x segments
+    int gene_blocks, gene_blocks1, gene_blocks2;      // of the sweep | of kernel 1 | of the dense pass
+    int64_t n_units;            // gene_blocks x segments
     Median9Lists L;             // segments per WAVEFRONT of this grid
     int dev_mode;
     const StripParams *P;
@@ -1051,7 +1052,12 @@ struct SweepArgs {
 };
 constexpr int SW_ROWS = MS_SEG * MF9_TC;      // cells per segment (the strip kernel's segments)
 
+// NH = 64-gene halves of a row: 1 -> 56 output genes per wavefront (kernel 1's gene blocks), 2 -> 120 (a 1 024-byte row straddles 9 lines for 120
+// outputs where a 512-byte row straddles 5 for 56: 16 % fewer bytes read).  Lane l loads gene g0 - 4 + 64 h + l of half h and owns the outputs
+// g0 + 64 k + l, k < NH (the last slot: l < 56); the 128-bit masks of a row are two ballots per side.
+template <int NH>
 __global__ void __launch_bounds__(256) median9_sweep_kernel(const SweepArgs A) {
+    constexpr int NOUT = 64 * NH - 8;         // output genes per block
     const int lane = threadIdx.x & 63;
     const int sgm = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);      // this wavefront's segment of the lists
     if (!median9_has_dominant_value(A.P)) {
@@ -1065,85 +1071,120 @@ __global__ void __launch_bounds__(256) median9_sweep_kernel(const SweepArgs A) {
     int32_t *slist = A.L.slow + (int64_t)sgm * A.L.lcap;
     int qn = 0, sn = 0;
     const unsigned long long lower = (1ull << lane) - 1ull;
-    constexpr unsigned long long HALF0 = 0x0000000FFFFFFFF0ull, HALF1 = 0x0FFFFFF000000000ull;      // lanes 4 .. 35 | 36 .. 59: the tile's two dense-pass gene blocks
     const int64_t n_waves = (int64_t)gridDim.x * 4;
     for (int64_t u = sgm; u < A.n_units; u += n_waves) {
-        const int gb = (int)(u % A.gene_blocks1);
-        const int4 gd = A.gene1_desc[gb], sd = A.seg_desc[u / A.gene_blocks1];
-        const int cs = gd.x, xdim = gd.y, g0 = gd.z, kb2 = gd.w;
+        const int gb = (int)(u % A.gene_blocks);
+        const int4 gd = A.gene_desc[2 * gb], gd2 = A.gene_desc[2 * gb + 1], sd = A.seg_desc[u / A.gene_blocks];
+        const int cs = gd.x, xdim = gd.y, g0 = gd.z, kb2 = gd.w, kb1 = gd2.x;
         const int idx_off = sd.x, ydim = sd.y, c0 = sd.z, kc = sd.w;
         const int n_out = (c0 + SW_ROWS < ydim ? c0 + SW_ROWS : ydim) - c0;       // outputs: cells c0 .. c0 + n_out - 1; stream row j is cell c0 - 4 + j
         const int n_groups = (n_out + 8 + 8) / 9;                                 // groups of nine stream rows
-        const int gx = g0 - 4 + lane;
-        const bool gok = gx >= 0 && gx < xdim;
-        const bool g_act = lane >= 4 && lane < 4 + K1G && gx < xdim;
-        const bool g_int = g_act && gx >= 4 && gx < xdim - 4;
-        const int nx = (gx + 4 < xdim - 1 ? gx + 4 : xdim - 1) - (gx - 4 > 0 ? gx - 4 : 0) + 1;
-        const int sh = lane >= 4 ? lane - 4 : 0;
-        const int off = cs + (gx < 0 ? 0 : (gx < xdim ? gx : xdim - 1));
-        const int a_abs = cs + gx;
+        bool gok[NH], g_act[NH], g_int[NH];
+        int nx[NH], off[NH], a_abs[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const int gl = g0 - 4 + 64 * h + lane;          // the gene this lane LOADS in half h
+            gok[h] = gl >= 0 && gl < xdim;
+            off[h] = cs + (gl < 0 ? 0 : (gl < xdim ? gl : xdim - 1));
+            const int go = g0 + 64 * h + lane;              // the gene of this lane's OUTPUT slot h
+            g_act[h] = 64 * h + lane < NOUT && go < xdim;
+            g_int[h] = g_act[h] && go >= 4 && go < xdim - 4;
+            nx[h] = (go + 4 < xdim - 1 ? go + 4 : xdim - 1) - (go - 4 > 0 ? go - 4 : 0) + 1;
+            a_abs[h] = cs + go;
+        }
         auto load_rc = [&](int g) -> int32_t {        // lane i < 9: the matrix column of stream row 9 g + i, -1 outside the tile
             const int cy = c0 - 4 + 9 * g + lane;
             return (lane < 9 && g < n_groups && cy >= 0 && cy < ydim) ? A.tile_idx[idx_off + cy] : -1;
         };
-        double cur[9], nxt[9];
-        auto gather = [&](double (&v)[9], int32_t rc) {
+        double cur[NH][9], nxt[NH][9];
+        auto gather = [&](double (&v)[NH][9], int32_t rc) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
                 const int32_t row = __builtin_amdgcn_readlane(rc, i);
-                double x = 0.0;
-                if (row >= 0) x = (A.in + (int64_t)row * A.G)[off];
-                v[i] = x;
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    double x = 0.0;
+                    if (row >= 0) x = (A.in + (int64_t)row * A.G)[off[h]];
+                    v[h][i] = x;
+                }
             }
         };
         int32_t rc_prev = -1, rc_cur = load_rc(0), rc_nxt = load_rc(1);
         gather(cur, rc_cur);
-        int hl[9], hg[9];
+        int hl[NH][9], hg[NH][9], sl[NH], sg[NH];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) { hl[i] = 0; hg[i] = 0; }
-        int sl = 0, sg = 0;
+        for (int h = 0; h < NH; ++h) {
+            sl[h] = 0; sg[h] = 0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { hl[h][i] = 0; hg[h][i] = 0; }
+        }
         // this lane's outputs of the current and the next block of 16 cells, undecided / interior (bit (c - c0) mod 32: a block is finished outside the
-        // unrolled rows, up to nine rows after its last one), and the undecided interior outputs of the two gene halves per block parity
-        uint32_t und32 = 0, inter32 = 0;
-        int n0e = 0, n1e = 0, n0o = 0, n1o = 0;
+        // unrolled rows, up to nine rows after its last one), and the undecided interior outputs of the 32-gene pieces of the block (2 NH pieces: lanes
+        // 0 .. 31 | 32 .. 63 of every slot) per block parity
+        uint32_t und32[NH], inter32[NH];
+        int np[2][2 * NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) { und32[h] = 0; inter32[h] = 0; np[0][2 * h] = np[0][2 * h + 1] = np[1][2 * h] = np[1][2 * h + 1] = 0; }
         int next_blk = 0;
         auto finish_block = [&](int kblk) {
             const int par = kblk & 1;
-            const int n0 = par ? n0o : n0e, n1 = par ? n1o : n1e;
-            const uint32_t und16 = (und32 >> (16 * par)) & 0xFFFFu, inter16 = (inter32 >> (16 * par)) & 0xFFFFu;
-            const bool dense0 = n0 > MF9_SPARSE_T || ((A.dev_mode & 2) && n0 > 0), dense1 = n1 > MF9_SPARSE_T || ((A.dev_mode & 2) && n1 > 0);
-            const bool my_dense = lane >= 4 + MF_TG ? dense1 : dense0;
-            const uint32_t keep16 = und16 & ~(my_dense ? inter16 : 0u);      // a dense tile's interior outputs are all rewritten by the dense pass
+            bool dense[2 * NH];
+            uint32_t keep16[NH];
             int n_push = 0;
+            bool any_dense = false;
 #pragma unroll
-            for (int i = 0; i < MF9_TC; ++i) n_push += __builtin_popcountll(__ballot((keep16 >> i) & 1u));
+            for (int t = 0; t < 2 * NH; ++t) {
+                const int n = par ? np[1][t] : np[0][t];
+                dense[t] = n > MF9_SPARSE_T || ((A.dev_mode & 2) && n > 0);
+                any_dense = any_dense || dense[t];
+            }
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const uint32_t und16 = (und32[h] >> (16 * par)) & 0xFFFFu, inter16 = (inter32[h] >> (16 * par)) & 0xFFFFu;
+                const bool my_dense = lane >= 32 ? dense[2 * h + 1] : dense[2 * h];
+                keep16[h] = und16 & ~(my_dense ? inter16 : 0u);      // a dense tile's interior outputs are all rewritten by the dense pass
+#pragma unroll
+                for (int i = 0; i < MF9_TC; ++i) n_push += __builtin_popcountll(__ballot((keep16[h] >> i) & 1u));
+            }
             if (n_push > 0) {
                 if (qn + n_push > A.L.qcap) {
-                    // the records do not fit this wavefront's segment: the tile of kernel 1 that holds the block is left to kernel 3 as a whole
-                    if (lane == 0 && sn < A.L.lcap) slist[sn] = (int32_t)((int64_t)((kc + kblk) >> 1) * A.gene_blocks1 + gb);
-                    ++sn;
+                    // the records do not fit this wavefront's segment: the tiles of kernel 1 that hold the block are left to kernel 3 as a whole
+                    const int t_lo = g0 / K1G, t_hi = ((g0 + NOUT < xdim ? g0 + NOUT : xdim) - 1) / K1G;
+                    for (int t = t_lo; t <= t_hi; ++t) {
+                        if (lane == 0 && sn < A.L.lcap) slist[sn] = (int32_t)((int64_t)((kc + kblk) >> 1) * A.gene_blocks1 + kb1 + t);
+                        ++sn;
+                    }
                 } else {
                     int at = qn;
 #pragma unroll
                     for (int i = 0; i < MF9_TC; ++i) {
-                        const unsigned long long row = __ballot((keep16 >> i) & 1u);
-                        if ((keep16 >> i) & 1u) {
-                            const int cy = c0 + MF9_TC * kblk + i;
-                            queue[at + __builtin_popcountll(row & lower)] = make_uint4((unsigned int)(idx_off + cy), (unsigned int)a_abs, median9_clamp_bits(gx, xdim, cy, ydim), 0u);
+                        const int cy = c0 + MF9_TC * kblk + i;
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) {
+                            const unsigned long long row = __ballot((keep16[h] >> i) & 1u);
+                            if ((keep16[h] >> i) & 1u)
+                                queue[at + __builtin_popcountll(row & lower)] = make_uint4((unsigned int)(idx_off + cy), (unsigned int)a_abs[h], median9_clamp_bits(a_abs[h] - cs, xdim, cy, ydim), 0u);
+                            at += __builtin_popcountll(row);
                         }
-                        at += __builtin_popcountll(row);
                     }
                     qn += n_push;
                 }
             }
-            if (lane < 4 && (dense0 || dense1)) {
-                const int gh = lane >> 1, which = lane & 1;
-                const int lo = g0 + MF_TG * gh, hi = (lo + (gh ? K1G - MF_TG : MF_TG) < xdim ? lo + (gh ? K1G - MF_TG : MF_TG) : xdim) - 1;
-                if ((gh ? dense1 : dense0) && lo <= hi) A.L.dflag[(int64_t)(kc + kblk) * A.gene_blocks2 + (kb2 + (which ? hi / MF_TG : lo / MF_TG))] = 1;
+            if (any_dense && lane < 4 * NH) {
+                // piece t (32 genes from g0 + 32 t, the last one 24) marks the one or two dense-pass tiles its genes fall into
+                const int t = lane >> 1, which = lane & 1;
+                const int lo = g0 + MF_TG * t, wd = t == 2 * NH - 1 ? MF_TG - 8 : MF_TG, hi = (lo + wd < xdim ? lo + wd : xdim) - 1;
+                bool d = false;
+#pragma unroll
+                for (int q = 0; q < 2 * NH; ++q) d = d || (q == t && dense[q]);
+                if (d && lo <= hi) A.L.dflag[(int64_t)(kc + kblk) * A.gene_blocks2 + (kb2 + (which ? hi / MF_TG : lo / MF_TG))] = 1;
             }
-            und32 &= ~(0xFFFFu << (16 * par));
-            inter32 &= ~(0xFFFFu << (16 * par));
-            if (par) { n0o = 0; n1o = 0; } else { n0e = 0; n1e = 0; }
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                und32[h] &= ~(0xFFFFu << (16 * par));
+                inter32[h] &= ~(0xFFFFu << (16 * par));
+                if (par) { np[1][2 * h] = 0; np[1][2 * h + 1] = 0; } else { np[0][2 * h] = 0; np[0][2 * h + 1] = 0; }
+            }
         };
         for (int g = 0; g < n_groups; ++g) {
             const int32_t rc_nn = load_rc(g + 2);
@@ -1151,36 +1192,51 @@ __global__ void __launch_bounds__(256) median9_sweep_kernel(const SweepArgs A) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
                 const int j = 9 * g + i, cyr = c0 - 4 + j;
-                const bool ok = gok && cyr >= 0 && cyr < ydim && !(A.dev_mode & 1);
-                const double x = cur[i];
-                const bool is_nan = ((unsigned long long)__double_as_longlong(x) & 0x7fffffffffffffffull) > 0x7ff0000000000000ull;
-                const unsigned long long ml = __ballot(ok && (x < vg || is_nan)), mg = __ballot(ok && (x > vg || is_nan));
-                const int nl = __builtin_popcount((unsigned int)(ml >> sh) & 0x1FFu), ng = __builtin_popcount((unsigned int)(mg >> sh) & 0x1FFu);
-                sl += nl - hl[i]; hl[i] = nl;
-                sg += ng - hg[i]; hg[i] = ng;
+                const bool row_ok = cyr >= 0 && cyr < ydim && !(A.dev_mode & 1);
+                unsigned long long ml[NH], mg[NH];
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const double x = cur[h][i];
+                    const bool is_nan = ((unsigned long long)__double_as_longlong(x) & 0x7fffffffffffffffull) > 0x7ff0000000000000ull;
+                    ml[h] = __ballot(gok[h] && row_ok && (x < vg || is_nan));
+                    mg[h] = __ballot(gok[h] && row_ok && (x > vg || is_nan));
+                }
                 const int c = cyr - 4;                       // the output whose window this row completes
-                if (j >= 8 && c < c0 + n_out) {              // (wave-uniform)
-                    const int ny = (c + 4 < ydim - 1 ? c + 4 : ydim - 1) - (c - 4 > 0 ? c - 4 : 0) + 1;
-                    const bool dec = !(A.dev_mode & 1) && 2 * sl < nx * ny && 2 * sg < nx * ny;
-                    const int32_t ccol = i >= 4 ? __builtin_amdgcn_readlane(rc_cur, i >= 4 ? i - 4 : 0) : __builtin_amdgcn_readlane(rc_prev, i < 4 ? i + 5 : 0);
-                    if (g_act && dec) __builtin_nontemporal_store(vg, (A.out + (int64_t)ccol * A.G) + a_abs);      // (written once, read by nobody in this call)
-                    const bool und = g_act && !dec, inter = g_int && c >= 4 && c < ydim - 4;
-                    const int bi = (c - c0) & 31;
-                    und32 |= (und ? 1u : 0u) << bi;
-                    inter32 |= (inter ? 1u : 0u) << bi;
-                    const unsigned long long ub = __ballot(und && inter);
-                    const int u0 = __builtin_popcountll(ub & HALF0), u1 = __builtin_popcountll(ub & HALF1);
-                    if (bi & 16) { n0o += u0; n1o += u1; } else { n0e += u0; n1e += u1; }
+                const bool out_row = j >= 8 && c < c0 + n_out;      // (wave-uniform)
+                const int ny = (c + 4 < ydim - 1 ? c + 4 : ydim - 1) - (c - 4 > 0 ? c - 4 : 0) + 1;
+                const int bi = (c - c0) & 31;
+                int32_t ccol = 0;
+                if (out_row) ccol = i >= 4 ? __builtin_amdgcn_readlane(rc_cur, i >= 4 ? i - 4 : 0) : __builtin_amdgcn_readlane(rc_prev, i < 4 ? i + 5 : 0);
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    // the nine mask bits from position 64 h + lane on: this lane's window in the row
+                    unsigned long long wl = ml[h] >> lane, wg = mg[h] >> lane;
+                    if (h + 1 < NH && lane > 55) { wl |= ml[h + 1 < NH ? h + 1 : h] << (64 - lane); wg |= mg[h + 1 < NH ? h + 1 : h] << (64 - lane); }
+                    const int nl = __builtin_popcount((unsigned int)wl & 0x1FFu), ng = __builtin_popcount((unsigned int)wg & 0x1FFu);
+                    sl[h] += nl - hl[h][i]; hl[h][i] = nl;
+                    sg[h] += ng - hg[h][i]; hg[h][i] = ng;
+                    if (out_row) {
+                        const bool dec = !(A.dev_mode & 1) && 2 * sl[h] < nx[h] * ny && 2 * sg[h] < nx[h] * ny;
+                        if (g_act[h] && dec) __builtin_nontemporal_store(vg, (A.out + (int64_t)ccol * A.G) + a_abs[h]);      // (written once, read by nobody in this call)
+                        const bool und = g_act[h] && !dec, inter = g_int[h] && c >= 4 && c < ydim - 4;
+                        und32[h] |= (und ? 1u : 0u) << bi;
+                        inter32[h] |= (inter ? 1u : 0u) << bi;
+                        const unsigned long long ub = __ballot(und && inter);
+                        const int u0 = __builtin_popcount((unsigned int)ub), u1 = __builtin_popcount((unsigned int)(ub >> 32));
+                        if (bi & 16) { np[1][2 * h] += u0; np[1][2 * h + 1] += u1; } else { np[0][2 * h] += u0; np[0][2 * h + 1] += u1; }
+                    }
                 }
             }
             // blocks whose last output lies behind us (one per group at most, two at the end of the unit)
             {
-                const int done = 9 * g + 8 - 8 < n_out - 1 ? 9 * g + 8 - 8 : n_out - 1;      // outputs c0 .. c0 + done are complete (done < 0: none yet)
+                const int done = 9 * g < n_out - 1 ? 9 * g : n_out - 1;      // outputs c0 .. c0 + done are complete
                 while (next_blk * MF9_TC <= done && (next_blk * MF9_TC + MF9_TC - 1 <= done || done == n_out - 1)) finish_block(next_blk++);
             }
             rc_prev = rc_cur; rc_cur = rc_nxt; rc_nxt = rc_nn;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) cur[i] = nxt[i];
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int i = 0; i < 9; ++i) cur[h][i] = nxt[h][i];
         }
     }
     if (lane == 0) { A.L.qcount[sgm] = qn; A.L.scount[sgm] = sn < A.L.lcap ? sn : A.L.lcap; }
@@ -1284,11 +1340,11 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
             static const int dev_mode = std::getenv("ICNV_MF9_MODE") ? std::atoi(std::getenv("ICNV_MF9_MODE")) : 0;   // developer switch
             static const int strip_mode = std::getenv("ICNV_MF9_STRIP") ? std::atoi(std::getenv("ICNV_MF9_STRIP")) : 1;   // developer switch: 0 = the fp64 dense pass of rounds 2-5
             static const int probe_mode = std::getenv("ICNV_MF9_PROBE") ? std::atoi(std::getenv("ICNV_MF9_PROBE")) : 1;   // developer switch: 0 = kernel 1 looks for a dominant value by itself, as in round 5
-            static const int sweep_mode = std::getenv("ICNV_MF9_SWEEP") ? std::atoi(std::getenv("ICNV_MF9_SWEEP")) : 1;   // developer switch: 0 = kernel 1 (tiles of 56 x 32, four wavefronts each) also when the probe ran
+            static const int sweep_mode = std::getenv("ICNV_MF9_SWEEP") ? std::atoi(std::getenv("ICNV_MF9_SWEEP")) : 1;   // developer switch: 0 = kernel 1 (tiles of 56 x 32, four wavefronts each) also when the probe ran, 1 = the sweep on 56-gene blocks, 2 = on 120-gene blocks (16 % fewer bytes read, 209 registers: measured slower, 4.58 vs 4.06 ms)
             const bool strip = strip_mode != 0 && plan9.n_strips > 0 && plan9.n_segs > 0;
             const bool probed = plan9.n_list > 0 && (strip || probe_mode != 0);
             static const int border_mode = std::getenv("ICNV_MF9_BORDER") ? std::atoi(std::getenv("ICNV_MF9_BORDER")) : 1;   // developer switch: 0 = without a dominant value kernel 1 still walks the tiles and queues the border outputs
-            const bool sweep = probed && probe_mode != 0 && sweep_mode != 0 && border_mode != 0 && plan9.n_segs > 0;
+            const bool sweep = probed && probe_mode != 0 && sweep_mode != 0 && border_mode != 0 && plan9.n_segs > 0 && plan9.n_sweep_blocks1 > 0 && plan9.n_sweep_blocks2 > 0;
             // kernel 1: four workgroups per CU (<= 128 registers; ten 8-byte loads in flight per lane), persistent; their list segments
             const int64_t n_runs1 = n_tiles9 / K1RUN;      // (the host pads kernel 1's cell blocks to a multiple of K1RUN)
             int64_t grid1 = (int64_t)num_cus() * 4;
@@ -1296,13 +1352,17 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
             Median9Lists L;
             L.n_seg = (int)grid1;
             L.lcap = (int)((n_runs1 / grid1 + 1) * K1RUN + 2);
-            // kernel 1s (the sweep): one list segment per WAVEFRONT, units (56 genes x 128 cells) dealt round-robin -- a wavefront's slow list can hold every block it may meet
-            const int64_t n_units_s = (int64_t)plan9.n_gene_blocks1 * plan9.n_segs;
-            int64_t grid_s = (int64_t)num_cus() * 6;
+            // kernel 1s (the sweep): one list segment per WAVEFRONT, units (56 or 120 genes x 128 cells) dealt round-robin -- a wavefront's slow list can hold every block it may meet
+            const int sweep_nh = sweep_mode == 2 ? 2 : 1;
+            const int sweep_blocks = sweep_nh == 1 ? plan9.n_sweep_blocks1 : plan9.n_sweep_blocks2;
+            const int4 *sweep_desc = reinterpret_cast<const int4 *>(sweep_nh == 1 ? plan9.sweep_desc1 : plan9.sweep_desc2);
+            const int64_t n_units_s = (int64_t)sweep_blocks * plan9.n_segs;
+            static const int sweep_wg = std::getenv("ICNV_MF9_SWEEP_WG") ? std::atoi(std::getenv("ICNV_MF9_SWEEP_WG")) : 0;   // developer switch: workgroups per CU of the sweep
+            int64_t grid_s = (int64_t)num_cus() * (sweep_wg > 0 ? sweep_wg : 6);
             if (grid_s * 4 > n_units_s) grid_s = (n_units_s + 3) / 4;
             if (sweep) {
                 L.n_seg = (int)(grid_s * 4);
-                L.lcap = (int)((n_units_s / L.n_seg + 1) * MS_SEG + 2);
+                L.lcap = (int)((n_units_s / L.n_seg + 1) * MS_SEG * 4 + 2);      // (a block names up to four of kernel 1's tiles)
                 grid1 = L.n_seg;      // (the sizes below are per segment)
             }
             // queue of single outputs: sized for 5 % of a workgroup's outputs, at least two tiles' worth (a neutral region leaves
@@ -1351,11 +1411,12 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
             if (sweep) {
                 SweepArgs S;
                 S.in = in; S.out = out; S.G = G; S.tile_idx = tile_idx_dev;
-                S.gene1_desc = g1; S.seg_desc = reinterpret_cast<const int4 *>(plan9.seg_desc);
-                S.gene_blocks1 = plan9.n_gene_blocks1; S.gene_blocks2 = plan9.n_gene_blocks;
+                S.gene_desc = sweep_desc; S.seg_desc = reinterpret_cast<const int4 *>(plan9.seg_desc);
+                S.gene_blocks = sweep_blocks; S.gene_blocks1 = plan9.n_gene_blocks1; S.gene_blocks2 = plan9.n_gene_blocks;
                 S.n_units = n_units_s; S.L = L; S.dev_mode = dev_mode; S.P = probe;
                 S.n_flags = (int64_t)b_flag;
-                hipLaunchKernelGGL(median9_sweep_kernel, dim3((unsigned)grid_s), dim3(256), 0, stream, S);
+                if (sweep_nh == 1) hipLaunchKernelGGL(median9_sweep_kernel<1>, dim3((unsigned)grid_s), dim3(256), 0, stream, S);
+                else hipLaunchKernelGGL(median9_sweep_kernel<2>, dim3((unsigned)grid_s), dim3(256), 0, stream, S);
             } else {
                 hipLaunchKernelGGL(median9_classify_kernel, dim3((unsigned)grid1), dim3(256), 0, stream, in, out, G, tile_idx_dev, g1, c1,
                                    plan9.n_gene_blocks1, n_tiles9, plan9.n_gene_blocks, L, dev_mode,

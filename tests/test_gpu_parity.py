@@ -951,7 +951,7 @@ for case in ("continuous", "dominant_islands", "rounded", "three_values", "six_v
     assert np.array_equal(got, want), (case, int((got != want).sum()))
 print("MF9_STRIP_OK")
 """ % (root, root)
-    for env in ({}, {"ICNV_MF9_STRIP": "0"}, {"ICNV_MF9_FQCAP": "0"}, {"ICNV_MF9_FQCAP": "7"}, {"ICNV_MF9_PROBE": "0"}, {"ICNV_MF9_BORDER": "0"}, {"ICNV_MF9_SWEEP": "0"}, {"ICNV_MF9_SWEEP": "1", "ICNV_MF9_QCAP": "3", "ICNV_MF9_MODE": "2"}, {"ICNV_MF9_QCAP": "40", "ICNV_MF9_FQCAP": "100"}):
+    for env in ({}, {"ICNV_MF9_STRIP": "0"}, {"ICNV_MF9_FQCAP": "0"}, {"ICNV_MF9_FQCAP": "7"}, {"ICNV_MF9_PROBE": "0"}, {"ICNV_MF9_BORDER": "0"}, {"ICNV_MF9_SWEEP": "0"}, {"ICNV_MF9_SWEEP": "1"}, {"ICNV_MF9_SWEEP": "1", "ICNV_MF9_QCAP": "3", "ICNV_MF9_MODE": "2"}, {"ICNV_MF9_SWEEP": "2", "ICNV_MF9_QCAP": "3"}, {"ICNV_MF9_SWEEP": "2", "ICNV_MF9_MODE": "3"}, {"ICNV_MF9_QCAP": "40", "ICNV_MF9_FQCAP": "100"}):
         res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
         assert res.returncode == 0 and "MF9_STRIP_OK" in res.stdout, (env, res.stdout[-1500:], res.stderr[-1500:])
 
