@@ -820,7 +820,28 @@ struct StripArgs {
     int32_t *fq_count;
     int fq_cap;
     int32_t *unit_counter;      // zeroed before the launch
+    const int32_t *unit_counts; // {full units, partial units} of the list (median9_units_kernel)
+    const int2 *unit_list;      // [n_units]: full units from the front, partial ones from the back
 };
+
+// The units of the strip kernel that hold a marked tile, as a list (one thread per unit; a launch of a few microseconds): full units -- eight cell
+// blocks inside the tile, every one with a marked tile -- are appended at the front, the others at the back.
+__global__ void __launch_bounds__(256) median9_units_kernel(const int4 *__restrict__ strip_desc, const int4 *__restrict__ seg_desc, int n_strips, int64_t n_units,
+                                                            const uint8_t *__restrict__ dflag, int gene_blocks2, const StripParams *__restrict__ P,
+                                                            int32_t *__restrict__ counts /* {front, back}, zeroed */, int2 *__restrict__ list) {
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= n_units || (P->n_sp & 0x100u)) return;
+    const int4 sd = strip_desc[u % n_strips], cd = seg_desc[u / n_strips];
+    const int xdim = sd.y, g0 = sd.z, kb = sd.w, ydim = cd.y, c0 = cd.z, kc = cd.w;
+    uint32_t fm = 0, pm = 0;
+    for (int j = 0; j < MS_SEG; ++j)
+        for (int b = 0; b < 2; ++b)
+            if (c0 + MEDIAN9_CELLS_PER_PATCH * j < ydim && g0 + MF_TG * b < xdim && dflag[(int64_t)(kc + j) * gene_blocks2 + kb + b]) { fm |= 1u << (2 * j + b); pm |= 1u << j; }
+    if (!fm) return;
+    const bool full = pm == (1u << MS_SEG) - 1u;
+    if (full) list[atomicAdd(&counts[0], 1)] = make_int2((int)u, (int)fm);
+    else list[n_units - 1 - atomicAdd(&counts[1], 1)] = make_int2((int)u, (int)fm);
+}
 
 __global__ void __launch_bounds__(256, MS_WAVES_PER_SIMD) median9_strip_kernel(const StripArgs A) {
     __shared__ double ring_all[4][MS_RING][MS_W];
@@ -858,34 +879,33 @@ __global__ void __launch_bounds__(256, MS_WAVES_PER_SIMD) median9_strip_kernel(c
         return (code << 8) | id;
     };
     // Units are handed out by a counter (the marked tiles cluster in a few chromosomes: dealt round-robin, 5 +- 2 of a wavefront's 32 units
-    // carried work and the launch waited for the unluckiest wavefront); the next unit's number is requested before this one is processed
-    auto next_unit = [&]() -> int64_t {
+    // carried work and the launch waited for the unluckiest wavefront) from the LIST median9_units_kernel made of the units that hold a marked tile
+    // (five of six units of the denoised matrix hold none: finding that out cost a wavefront three dependent loads per unit) -- the full units
+    // first, the partial ones (tile ends, partly marked) last, so that the launch ends on its smallest pieces.  The next entry's number is
+    // requested before this one is processed.
+    const int n_full = A.unit_counts[0], n_part = A.unit_counts[1];
+    auto next_unit = [&]() -> int {
         int v = 0;
         if (lane == 0) v = atomicAdd(A.unit_counter, 1);
-        return (int64_t)__builtin_amdgcn_readfirstlane(v);
+        return __builtin_amdgcn_readfirstlane(v);
     };
-    int64_t u_next = next_unit();
+    int i_next = next_unit();
     for (;;) {
-        const int64_t u = u_next;
-        if (u >= A.n_units) break;
-        u_next = next_unit();
+        const int i_cur = i_next;
+        if (i_cur >= n_full + n_part) break;
+        i_next = next_unit();
+        const int2 entry = A.unit_list[i_cur < n_full ? (int64_t)i_cur : A.n_units - 1 - (int64_t)(i_cur - n_full)];      // {unit, its marks: bit 2 j + b}
+        const int64_t u = entry.x;
+        const uint32_t fm = (uint32_t)entry.y;
         const int4 sd = A.strip_desc[u % A.n_strips], cd = A.seg_desc[u / A.n_strips];
-        const int cs = sd.x, xdim = sd.y, g0 = sd.z, kb = sd.w;
-        const int idx_off = cd.x, ydim = cd.y, c0 = cd.z, kc = cd.w;
-        // the marks of this unit's 8 cell blocks x 2 gene blocks (kernel 1 wrote them): bit 2 j + b
-        uint32_t fm;
-        {
-            const int j = lane >> 1, b = lane & 1;
-            const bool have = lane < 2 * MS_SEG && c0 + MEDIAN9_CELLS_PER_PATCH * j < ydim && g0 + MF_TG * b < xdim;
-            const uint8_t f = have ? A.dflag[(int64_t)(kc + j) * A.gene_blocks2 + kb + b] : (uint8_t)0;
-            fm = (uint32_t)__ballot(f != 0);
-        }
+        const int cs = sd.x, xdim = sd.y, g0 = sd.z;
+        const int idx_off = cd.x, ydim = cd.y, c0 = cd.z;
         uint32_t pm = 0;     // bit j: cell block j has a marked tile
 #pragma unroll
         for (int j = 0; j < MS_SEG; ++j) pm |= ((fm >> (2 * j)) & 3u) ? (1u << j) : 0u;
         const int go = g0 + lane;                              // this lane's output gene (in the chromosome)
         const bool lane_ok = go >= 4 && go < xdim - 4;         // interior outputs only (kernel 1 / 3 own the borders)
-        const int gl = g0 - 4 + lane, ge = g0 + 60 + lane;     // the genes this lane loads per row: column `lane`, and column 64 + lane (lanes 0 .. 7)
+        const int gl = g0 - 4 + lane;                          // the gene this lane loads per row: column `lane`
         // (a row's address is a wave-uniform base -- the scalar unit's -- plus these 32-bit lane offsets)
         const int off_l = cs + (gl < 0 ? 0 : (gl < xdim ? gl : xdim - 1));
         const int ge2 = g0 + 60 + (lane & 7);                  // (lanes 0 .. 7 and 8 .. 15: the genes of columns 64 .. 71)
@@ -1380,7 +1400,8 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
             // (round 6) the strip form of the dense pass: the probe's result, the counter and the queue of its uncertified outputs
             int fq_cap = (int)std::min<int64_t>(std::max<int64_t>(n_tiles2 * (MF_TG * MF9_TC) / 64, 1 << 16), 1 << 22);
             if (const char *e = std::getenv("ICNV_MF9_FQCAP")) fq_cap = std::max(0, std::atoi(e));   // developer / test switch: 0 sends every uncertified output's tile to the gated fp64 pass
-            const size_t b_probe = 64 + ((sizeof(ProbeScratch) + 63) & ~(size_t)63), b_fq = strip ? (size_t)fq_cap * sizeof(uint4) : 0;
+            const size_t b_ulist = strip ? (((size_t)plan9.n_strips * plan9.n_segs * sizeof(int2) + 15) & ~(size_t)15) : 0;      // the strip kernel's list of units
+            const size_t b_probe = 64 + ((sizeof(ProbeScratch) + 63) & ~(size_t)63), b_fq = (strip ? (size_t)fq_cap * sizeof(uint4) : 0) + b_ulist;
             size_t b_queue = 0;
             for (;;) {   // a pool that cannot give the queue gets a shorter one: more tiles take the slow list, nothing fails
                 b_queue = (size_t)grid1 * L.qcap * sizeof(uint4);
@@ -1443,6 +1464,11 @@ int launch_median_filter(const double *in, double *out, int32_t G, int64_t C, co
                 A.dflag = L.dflag; A.gene_blocks2 = plan9.n_gene_blocks;
                 A.P = probe; A.fq = fq; A.fq_count = fq_count; A.fq_cap = fq_cap;
                 A.unit_counter = fq_count + 1;
+                A.unit_counts = fq_count + 2;
+                int2 *ulist = reinterpret_cast<int2 *>(reinterpret_cast<char *>(fq) + (size_t)fq_cap * sizeof(uint4));
+                A.unit_list = ulist;
+                hipLaunchKernelGGL(median9_units_kernel, dim3((unsigned)((A.n_units + 255) / 256)), dim3(256), 0, stream, A.strip_desc, A.seg_desc, A.n_strips, A.n_units,
+                                   (const uint8_t *)L.dflag, plan9.n_gene_blocks, (const StripParams *)probe, fq_count + 2, ulist);
                 int64_t grid2s = (int64_t)num_cus() * MS_WAVES_PER_SIMD;       // resident workgroups of four independent wavefronts
                 if (grid2s * 4 > A.n_units) grid2s = (A.n_units + 3) / 4;
                 hipLaunchKernelGGL(median9_strip_kernel, dim3((unsigned)grid2s), dim3(256), 0, stream, A);
