@@ -33,7 +33,7 @@ for t in ("copy", "bench"):
 # inputs runs once and is left out)
 STEP_KERNELS = {"cfg4": ("block_cell_reduce_kernel", "group_partial_sums_kernel", "group_means_finish_kernel", "reduce_moments_kernel", "i3_params_kernel", "viterbi_redo_kernel",
                          "viterbi_kernel", "viterbi_fast_kernel", "broadcast_states_kernel"),
-                "cfg5": ("median9_probe_count_kernel", "median9_probe_finish_kernel", "median9_classify_kernel", "median9_sweep_kernel", "median9_border_kernel", "median9_strip_kernel", "median_filter9_kernel", "median9_sparse_kernel", "median_filter_kernel")}
+                "cfg5": ("median9_probe_count_kernel", "median9_probe_finish_kernel", "median9_classify_kernel", "median9_sweep_kernel", "median9_border_kernel", "median9_units_kernel", "median9_strip_kernel", "median_filter9_kernel", "median9_sparse_kernel", "median_filter_kernel")}
 def load_all(path):
     agg = collections.defaultdict(list)
     if not os.path.exists(path):
