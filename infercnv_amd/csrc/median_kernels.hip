@@ -1,12 +1,15 @@
 // 2-D median denoise (apply_median_filtering / .median_filter,
-// R/noise_reduction.R:43-113) for gfx950.
-//
-// A workgroup produces a patch of 32 genes x 8 (16 for the default window) cells of one (tile, chromosome)
-// block: the (32+2h) x (cells+2h) input patch (h = half_window+1, so the effective
-// window is (window_size+2)^2, clamped at the block's edges) is gathered
-// through the tile's cell-index vector into LDS.
-//   window_size 7 (9 x 9 windows, the default): median_filter9_kernel -- sorted columns shared through LDS,
-//     two outputs per thread that share eight of their nine columns, branch-free min/max networks;
+// R/noise_reduction.R:43-113) for gfx950.  The effective window is (window_size+2)^2, clamped at the edges of the
+// (cell tile, chromosome) block; rows of a block are gathered through the tile's cell-index vector.
+//   window_size 7 (9 x 9 windows, the default), launches of one call (round 6):
+//     median9_probe_count / _finish   a sample: the dominant value, up to three repeated values, the value range (on the device)
+//     median9_sweep_kernel            classification: a wavefront per 56-gene block sweeps down the cells, writes the outputs whose
+//                                     median is the dominant value, marks tiles for the dense pass, queues the rest
+//                                     (median9_classify_kernel, round 5's tiled form, when the probe is switched off)
+//     median9_border_kernel           without a dominant value: the blocks' border outputs straight from the geometry
+//     median9_units_kernel + median9_strip_kernel   the dense pass: one gene column per lane sliding down the cells, shared merges in
+//                                     registers on 32-bit compound keys; median_filter9_kernel (fp64, rounds 2-5) behind a gate
+//     median9_sparse_kernel           single outputs (queues, slow lists)
 //   other window sizes: median_filter_kernel -- every thread selects the median of its clamped window by a
 //     value-bounded quickselect (exact order statistics; even counts average the two middle values like
 //     stats::median).
@@ -123,7 +126,8 @@ __global__ void __launch_bounds__(MF_TG *MF_TC) median_filter_kernel(
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 9 x 9 windows (window_size 7, the default) in three launches.
+// 9 x 9 windows (window_size 7, the default): round 5's three launches (kernel 1 = median9_classify_kernel, kernel 2 = median_filter9_kernel,
+// kernel 3 = median9_sparse_kernel); round 6 put the sweep in front of kernel 1 and the strip kernel in front of kernel 2 (further down).
 //
 // Majority shortcut (exact, data-dependent).  A window in which one value occupies more than half of the positions has that
 // value as its median, whatever the rest is (for an even number of positions -- clamped border windows -- both middle values
